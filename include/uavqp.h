@@ -1,0 +1,112 @@
+/*
+ * uavqp.h -- C ABI of the MI355X-native batched minimum-jerk / minimum-snap trajectory QP back-end.
+ *
+ * Drop-in boundary for ONE hot path of peiyu-cui/uav_motion_planning: the polynomial-trajectory QP
+ * of traj_optimization::MinimumControl (reference: src/planner/traj_optimization/include/
+ * traj_optimization/minimum_control.h:10-48, src/minimum_control.cpp:5-202).  The reference has no
+ * FFI; its interface for this path is the C++ class, so the bindings a maintainer adds are the two
+ * C++ facades in uav_motion_planning_amd/cpp/ (MinimumControl, TrajOptimizer) -- see INTEGRATION.md.
+ *
+ * Plain pointers and sizes only: no Eigen, STL, torch or HIP types cross this boundary.
+ * All floating-point data is IEEE float64 (the reference's c_float/VectorXd type); indices int32.
+ *
+ * -------------------------------------------------------------------------------------------------
+ * Problem solved per trajectory and per axis (r = 3 min-jerk: the reference; r = 4 min-snap):
+ *   minimise   sum_i  integral_0^{T_i} (d^r p_i/dt^r)^2 dt          [getHessian,  minimum_control.cpp:5-19]
+ *   subject to p_0^(d)(0)   = start derivative d, d = 0..r-1        [rows 0..r-1,          :29-31, :101-107]
+ *              p_i(T_i)     = waypoint i+1                          [waypoint rows,        :34-42, :118-124]
+ *              p_i^(d)(T_i) = p_{i+1}^(d)(0), d = 0..r-1            [continuity rows,      :45-74]
+ *              p_{M-1}^(d)(T) = end derivative d                    [end rows,             :77-95, :109-115]
+ * Every row is an equality (lb == ub in the reference), so the QP has a unique minimiser; the device
+ * path computes that minimiser directly (reduced SPD block-tridiagonal system)
+ * instead of iterating ADMM to OSQP's eps = 1e-3.
+ *
+ * Data layout (one batch = n_traj independent trajectories, 3 axes each):
+ *   seg_offsets [n_traj+1] int32   CSR offsets into the segment arrays; trajectory b has
+ *                                  M_b = seg_offsets[b+1]-seg_offsets[b] segments and M_b+1 waypoints.
+ *                                  May be NULL when uniform_segments > 0 (then M_b = uniform_segments).
+ *   waypoints   [sum_b (M_b+1)][3] xyz interleaved, trajectory b starts at row seg_offsets[b] + b
+ *                                  (= what A* / RRT* hand over: std::vector<Eigen::Vector3d>,
+ *                                  test_minimum_jerk.cpp:41-57).
+ *   times       [sum_b M_b]        segment durations (time_vec, test_minimum_jerk.cpp:65-71), > 0.
+ *   bc          [n_traj][2][r-1][3] boundary derivatives: [start|end][vel,acc(,jerk)][xyz]
+ *                                  (bound_vel / bound_acc of MinimumControl::solve, minimum_control.h:32-35).
+ *   coeff_out   [sum_b 3*M_b*2r]   trajectory b at 3*2r*seg_offsets[b], layout [axis][segment][2r]:
+ *                                  each [axis] slice IS the reference's coef_1d_ vector for that axis --
+ *                                  coef[2r*i + k] multiplies t^k (ascending powers) in segment-local time
+ *                                  (minimum_control.cpp:186, consumer poly_traj_server.cpp:68-78).
+ *   status_out  [n_traj] int32     UAVQP_SOLVED or a negative per-trajectory code (may be NULL).
+ */
+#ifndef UAVQP_H_
+#define UAVQP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uavqp_ctx uavqp_ctx;
+
+/* return codes of every entry point (never throws) */
+enum {
+    UAVQP_OK = 0,
+    UAVQP_ERR_INVALID_ARG = -1,
+    UAVQP_ERR_HIP = -2,       /* HIP runtime error; uavqp_last_error() has the text */
+    UAVQP_ERR_NO_DEVICE = -3, /* no usable gfx950 device: the product path never falls back to CPU */
+    UAVQP_ERR_ALLOC = -4
+};
+
+/* per-trajectory status (positive = OSQP's OSQP_SOLVED value, which the reference's solve() maps to true) */
+enum {
+    UAVQP_SOLVED = 1,
+    UAVQP_INVALID_INPUT = -10, /* M < 1, M > max_segments, T <= 0 or non-finite input */
+    UAVQP_NON_FINITE = -11     /* solution overflowed / NaN (pathological time allocation) */
+};
+
+const char* uavqp_version(void);
+const char* uavqp_last_error(void);
+
+/* Replaces construction of traj_optimization::MinimumControl + OsqpEigen::Solver
+ * (minimum_control.h:14,44).  One ctx per host thread / device; owns a HIP stream and workspaces. */
+int uavqp_create(uavqp_ctx** out_ctx, int device);
+int uavqp_destroy(uavqp_ctx* ctx);
+
+/* Run all subsequent device work of this ctx on an existing hipStream_t (e.g. the caller's compute
+ * stream).  NULL restores the ctx-owned stream. */
+int uavqp_set_stream(uavqp_ctx* ctx, void* hip_stream);
+int uavqp_synchronize(uavqp_ctx* ctx);
+
+/* Kernel variant selection: 0 = auto, 1 = generic lane-per-trajectory kernel, 2 = register-resident
+ * specialised kernel (uniform batches only).  For benchmarking/tests; results are identical. */
+int uavqp_set_variant(uavqp_ctx* ctx, int variant);
+
+/* Batched solve, DEVICE pointers, asynchronous on the ctx stream.
+ * Replaces, for a whole batch and 3 axes at once, MinimumControl::solve + getCoef1d
+ * (minimum_control.cpp:127-192, :199-202).
+ *   r                 3 (min-jerk, reference) or 4 (min-snap)
+ *   uniform_segments  > 0: every trajectory has that many segments (seg_offsets may be NULL)
+ *                     0  : ragged batch, seg_offsets required
+ *   max_segments      upper bound on M_b (ragged); ignored for uniform batches                    */
+int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                             const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                             const double* d_bc, double* d_coeff_out, int32_t* d_status_out);
+
+/* Same with HOST pointers: H2D copy, solve, D2H copy, synchronous.  total_segments = sum_b M_b. */
+int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                           const int32_t* seg_offsets, const double* waypoints, const double* times,
+                           const double* bc, double* coeff_out, int32_t* status_out);
+
+/* Single-axis entry with the exact argument meaning of
+ *   bool MinimumControl::solve(VectorXd& pos_1d, Vector2d& bound_vel, Vector2d& bound_acc, VectorXd& time_vec)
+ * (minimum_control.h:32-35): pos_1d[n_seg+1], bound_*[2] = (start, end), time_vec[n_seg]; writes
+ * coef_1d[2r*n_seg].  bound_jerk is read only when r == 4 (NULL = zeros).  Host pointers, synchronous.
+ * Returns UAVQP_OK and *status_out = UAVQP_SOLVED on success. */
+int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const double* pos_1d, const double* bound_vel,
+                          const double* bound_acc, const double* bound_jerk, const double* time_vec,
+                          double* coef_1d, int32_t* status_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVQP_H_ */

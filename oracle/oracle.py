@@ -1,0 +1,120 @@
+"""ctypes binding of the CPU oracle (oracle/qp_oracle.c, oracle/osqp_port.c).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; nothing under
+uav_motion_planning_amd/ may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds).  Never touches /root/reference."""
+    srcs = [os.path.join(_HERE, f) for f in ("qp_oracle.c", "osqp_port.c") if os.path.exists(os.path.join(_HERE, f))]
+    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_cost.restype = ctypes.c_double
+        _lib.oracle_residual.restype = ctypes.c_double
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def dims(r, M):
+    L = lib()
+    return L.oracle_num_vars(r, M), L.oracle_num_cons(r, M)
+
+
+def assemble(r, T):
+    """Dense (P, A) exactly as minimum_control.cpp:5-96 builds them."""
+    T, pT = _d(T)
+    M = T.size
+    n, m = dims(r, M)
+    P = np.zeros((n, n))
+    A = np.zeros((m, n))
+    lib().oracle_assemble_P(r, M, pT, P.ctypes.data_as(_dp))
+    lib().oracle_assemble_A(r, M, pT, A.ctypes.data_as(_dp))
+    return P, A
+
+
+def bounds(r, pos, bc_start, bc_end):
+    pos, pp = _d(pos)
+    bs, pbs = _d(bc_start)
+    be, pbe = _d(bc_end)
+    M = pos.size - 1
+    _, m = dims(r, M)
+    l = np.zeros(m)
+    u = np.zeros(m)
+    lib().oracle_bounds(r, M, pp, pbs, pbe, l.ctypes.data_as(_dp), u.ctypes.data_as(_dp))
+    return l, u
+
+
+def solve_exact(r, pos, bc_start, bc_end, T):
+    """One axis: exact minimiser (binary128 KKT solve) of the reference QP; returns coef[2r*M]."""
+    pos, pp = _d(pos)
+    bs, pbs = _d(bc_start)
+    be, pbe = _d(bc_end)
+    T, pT = _d(T)
+    M = T.size
+    assert pos.size == M + 1 and bs.size == r - 1 and be.size == r - 1
+    out = np.zeros(2 * r * M)
+    rc = lib().oracle_solve_exact(r, M, pp, pbs, pbe, pT, out.ctypes.data_as(_dp))
+    if rc != 0:
+        raise RuntimeError(f"oracle_solve_exact rc={rc}")
+    return out
+
+
+def solve_exact_batch(r, seg_offsets, waypoints, times, bc):
+    """Batch in the C-ABI layout; returns (coef_flat, status)."""
+    so, pso = _i(seg_offsets)
+    wp, pwp = _d(waypoints)
+    tt, ptt = _d(times)
+    bcv, pbc = _d(bc)
+    n_traj = so.size - 1
+    out = np.zeros(3 * 2 * r * int(so[-1]))
+    status = np.zeros(n_traj, dtype=np.int32)
+    rc = lib().oracle_solve_exact_batch(r, n_traj, pso, pwp, ptt, pbc, out.ctypes.data_as(_dp), status.ctypes.data_as(_ip))
+    if rc != 0:
+        raise RuntimeError(f"oracle_solve_exact_batch rc={rc}")
+    return out, status
+
+
+def cost(r, T, coef):
+    T, pT = _d(T)
+    c, pc = _d(coef)
+    return lib().oracle_cost(r, T.size, pT, pc)
+
+
+def residual(r, pos, bc_start, bc_end, T, coef):
+    pos, pp = _d(pos)
+    bs, pbs = _d(bc_start)
+    be, pbe = _d(bc_end)
+    T, pT = _d(T)
+    c, pc = _d(coef)
+    return lib().oracle_residual(r, T.size, pp, pbs, pbe, pT, pc)

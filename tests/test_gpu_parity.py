@@ -1,0 +1,66 @@
+"""-m gpu parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerance: the north star allows 1e-5 relative to the reference solution; the HIP
+path is an exact (direct) solve in float64, so the tests hold it to 1e-9 relative to max|coef| per
+trajectory against the binary128 KKT oracle (1e-7 for the 'wide' stress allocation T in [0.2, 5] s)."""
+import numpy as np
+import pytest
+
+from uav_motion_planning_amd import UAVQP_INVALID_INPUT, UAVQP_SOLVED
+from uav_motion_planning_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err_per_traj(got, ref, seg_offsets, r):
+    nc = 2 * r
+    errs = []
+    for b in range(len(seg_offsets) - 1):
+        lo, hi = 3 * nc * seg_offsets[b], 3 * nc * seg_offsets[b + 1]
+        if hi > lo:
+            errs.append(np.max(np.abs(got[lo:hi] - ref[lo:hi])) / max(np.max(np.abs(ref[lo:hi])), 1e-300))
+    return np.array(errs)
+
+
+def test_reference_kat_qpsolve(gpu_ctx):
+    """The reference's only fixed input (test_qpsolve.cpp:10-17) -> exact rational minimiser."""
+    rc, st, c = gpu_ctx.solve_axis_host(3, [1.0, 2.0, 3.0, 4.0], [0.0, 0.0], [0.0, 0.0], [1.0, 1.0, 1.0])
+    assert rc == 0 and st == UAVQP_SOLVED
+    exp = np.array([1, 0, 0, 190 / 51, -65 / 17, 56 / 51,
+                    2, 70 / 51, -40 / 51, -10 / 17, 5 / 3, -2 / 3,
+                    3, 70 / 51, 40 / 51, -10 / 17, -5 / 3, 56 / 51])
+    assert np.max(np.abs(c - exp)) < 1e-12
+
+
+@pytest.mark.parametrize("r", [3, 4])
+@pytest.mark.parametrize("M", [1, 2, 3, 7, 8, 16, 24])
+@pytest.mark.parametrize("time_mode", ["reference", "distance", "wide"])
+def test_uniform_batch_vs_oracle(gpu_ctx, oracle, r, M, time_mode):
+    n = 48
+    b = W.uniform_batch(100 + M, n, M, r, time_mode=time_mode)
+    got, st = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    ref, st_ref = oracle.solve_exact_batch(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+    assert np.all(st == UAVQP_SOLVED) and np.all(st_ref == 0)
+    err = rel_err_per_traj(got, ref, b["seg_offsets"], r)
+    tol = 1e-7 if time_mode == "wide" else 1e-9
+    assert err.max() < tol, f"max rel err {err.max():.3e}"
+
+
+@pytest.mark.parametrize("r", [3, 4])
+def test_ragged_batch_vs_oracle(gpu_ctx, oracle, r):
+    b = W.ragged_batch(4, 96, r, m_lo=1, m_hi=24)
+    got, st = gpu_ctx.solve_batch_host(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+    ref, _ = oracle.solve_exact_batch(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+    assert np.all(st == UAVQP_SOLVED)
+    assert rel_err_per_traj(got, ref, b["seg_offsets"], r).max() < 1e-8
+
+
+def test_invalid_inputs_are_flagged_not_fatal(gpu_ctx):
+    b = W.uniform_batch(7, 8, 4, 3)
+    T = b["times"].copy()
+    T[2, 1] = 0.0
+    T[5, 3] = np.nan
+    T[6, 0] = -1.0
+    got, st = gpu_ctx.solve_batch_host(3, None, b["waypoints"], T, b["bc"], uniform_segments=4)
+    assert list(st[[2, 5, 6]]) == [UAVQP_INVALID_INPUT] * 3
+    assert np.all(np.delete(st, [2, 5, 6]) == UAVQP_SOLVED)
+    assert np.all(np.isfinite(got))

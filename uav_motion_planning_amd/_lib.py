@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI in include/uavqp.h (libuavqp.so, built in-tree by csrc/Makefile).
+
+There is no CPU fallback: if the shared library is missing this module raises at import of the
+symbol table, and every solve call raises UavqpError when no gfx950 device is usable.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libuavqp.so")
+
+UAVQP_OK = 0
+UAVQP_ERR_INVALID_ARG = -1
+UAVQP_ERR_HIP = -2
+UAVQP_ERR_NO_DEVICE = -3
+UAVQP_ERR_ALLOC = -4
+
+UAVQP_SOLVED = 1
+UAVQP_INVALID_INPUT = -10
+UAVQP_NON_FINITE = -11
+
+# every symbol include/uavqp.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = (
+    "uavqp_version",
+    "uavqp_last_error",
+    "uavqp_create",
+    "uavqp_destroy",
+    "uavqp_set_stream",
+    "uavqp_synchronize",
+    "uavqp_set_variant",
+    "uavqp_solve_batch_device",
+    "uavqp_solve_batch_host",
+    "uavqp_solve_axis_host",
+)
+
+
+class UavqpError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    csrc = os.path.join(_PKG, "csrc")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", csrc])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UavqpError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The uavqp product path has no CPU fallback."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, dp, ip = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p
+    L.uavqp_version.restype = ctypes.c_char_p
+    L.uavqp_last_error.restype = ctypes.c_char_p
+    L.uavqp_create.argtypes = [ctypes.POINTER(vp), i32]
+    L.uavqp_destroy.argtypes = [vp]
+    L.uavqp_set_stream.argtypes = [vp, vp]
+    L.uavqp_synchronize.argtypes = [vp]
+    L.uavqp_set_variant.argtypes = [vp, i32]
+    L.uavqp_solve_batch_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
+    L.uavqp_solve_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
+    L.uavqp_solve_axis_host.argtypes = [vp, i32, i32, dp, dp, dp, dp, dp, dp, ctypes.POINTER(ctypes.c_int32)]
+    for name in SYMBOLS:
+        getattr(L, name)  # AttributeError here = the library does not match the header
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != UAVQP_OK:
+        msg = lib().uavqp_last_error().decode() if rc == UAVQP_ERR_HIP or rc == UAVQP_ERR_NO_DEVICE else ""
+        raise UavqpError(f"{what} failed with code {rc} {msg}")

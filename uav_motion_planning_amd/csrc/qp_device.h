@@ -1,0 +1,159 @@
+// qp_device.h -- device-side maths of the reduced min-jerk / min-snap solve (gfx950, float64).
+//
+// The reference QP (minimum_control.cpp:5-125) is posed in 2r monomial coefficients per segment with
+// equality rows only.  Each segment polynomial is fixed by its endpoint derivatives 0..r-1 (Hermite
+// data); positions at every knot and all derivatives at the two ends are given, so the only free
+// quantities are the r-1 derivatives y_k = (v_k, a_k[, j_k]) at the M-1 interior knots.  In
+// normalised time tau = t/T the segment cost is
+//     J = T^(1-2r) e' W e,   e = s1 - C s0,   s*_d = T^d p^(d)(end)
+// (W, V = C'W, U = C'WC, K: exact-rational constants, hermite_tables.h / tools/derive_tables.py).
+// Stationarity in y_k gives an SPD block-tridiagonal system with (r-1)x(r-1) blocks that depends
+// only on the time allocation -- the three axes are three right-hand sides of one factorisation
+// (the reference re-runs OSQP setup per axis on identical P, A: test_minimum_jerk.cpp:75,100,125).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hermite_tables.h"
+
+namespace uavqp {
+
+template <int R> struct Tab;
+template <> struct Tab<3> {
+    static __device__ __forceinline__ constexpr double K(int i, int j) { return HK3[i][j]; }
+    static __device__ __forceinline__ constexpr double W(int i, int j) { return HW3[i][j]; }
+    static __device__ __forceinline__ constexpr double V(int i, int j) { return HV3[i][j]; }
+    static __device__ __forceinline__ constexpr double U(int i, int j) { return HU3[i][j]; }
+};
+template <> struct Tab<4> {
+    static __device__ __forceinline__ constexpr double K(int i, int j) { return HK4[i][j]; }
+    static __device__ __forceinline__ constexpr double W(int i, int j) { return HW4[i][j]; }
+    static __device__ __forceinline__ constexpr double V(int i, int j) { return HV4[i][j]; }
+    static __device__ __forceinline__ constexpr double U(int i, int j) { return HU4[i][j]; }
+};
+
+__device__ __forceinline__ constexpr double inv_fact(int k) {
+    double f = 1.0;
+    for (int j = 2; j <= k; ++j) f *= (double)j;
+    return 1.0 / f;
+}
+
+// T-dependent blocks of one segment (ND = R-1 derivative unknowns per knot).
+//   A11: end/end block      T^(a+b+1-2R) W[a][b]          (symmetric)
+//   A00: start/start block  T^(a+b+1-2R) U[a][b]          (symmetric; U = (-1)^(a+b) W)
+//   A01: start/end block   -T^(a+b+1-2R) V[a][b]
+//   gw, gv: position couplings T^(a+1-2R) W[a][0], T^(a+1-2R) V[a][0]
+template <int R>
+struct SegBlocks {
+    static constexpr int ND = R - 1;
+    double A11[ND][ND];
+    double A00[ND][ND];
+    double A01[ND][ND];
+    double gw[ND];
+    double gv[ND];
+    __device__ __forceinline__ void build(double T) {
+        const double it = 1.0 / T;
+        double ip[2 * R];  // ip[j] = T^-j
+        ip[0] = 1.0;
+#pragma unroll
+        for (int j = 1; j < 2 * R; ++j) ip[j] = ip[j - 1] * it;
+#pragma unroll
+        for (int a = 1; a < R; ++a) {
+#pragma unroll
+            for (int b = 1; b < R; ++b) {
+                const double p = ip[2 * R - 1 - a - b];
+                A11[a - 1][b - 1] = p * Tab<R>::W(a, b);
+                A00[a - 1][b - 1] = p * Tab<R>::U(a, b);
+                A01[a - 1][b - 1] = -p * Tab<R>::V(a, b);
+            }
+            gw[a - 1] = ip[2 * R - 1 - a] * Tab<R>::W(a, 0);
+            gv[a - 1] = ip[2 * R - 1 - a] * Tab<R>::V(a, 0);
+        }
+    }
+};
+
+// In-place LDL' of a small SPD matrix (only the lower triangle is read), then solves.
+template <int N>
+struct SmallLDL {
+    double l[N][N];  // strictly-lower entries of L
+    double d[N];
+    double dinv[N];
+    __device__ __forceinline__ void factor(const double (&S)[N][N]) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double w[N];
+            double dj = S[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                w[k] = l[j][k] * d[k];
+                dj -= l[j][k] * w[k];
+            }
+            d[j] = dj;
+            dinv[j] = 1.0 / dj;
+#pragma unroll
+            for (int i = j + 1; i < N; ++i) {
+                double s = S[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) s -= l[i][k] * w[k];
+                l[i][j] = s * dinv[j];
+            }
+        }
+    }
+    // x <- S^-1 x
+    __device__ __forceinline__ void solve(double (&x)[N]) const {
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+#pragma unroll
+            for (int k = 0; k < i; ++k) x[i] -= l[i][k] * x[k];
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] *= dinv[i];
+#pragma unroll
+        for (int i = N - 2; i >= 0; --i)
+#pragma unroll
+            for (int k = i + 1; k < N; ++k) x[i] -= l[k][i] * x[k];
+    }
+};
+
+// Monomial coefficients (ascending powers, segment-local time: the reference's coef_1d_ layout,
+// minimum_control.cpp:186) of one segment of one axis from its Hermite data.
+//   ys / ye : derivatives 1..R-1 at the segment start / end;  p0 / p1 : positions.
+template <int R>
+__device__ __forceinline__ void segment_coeffs(double p0, const double (&ys)[R - 1], double p1,
+                                               const double (&ye)[R - 1], double T, double it,
+                                               double (&c)[2 * R]) {
+    double tp[R];  // T^d
+    tp[0] = 1.0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) tp[d] = tp[d - 1] * T;
+    double s0[R], s1[R];
+    s0[0] = 0.0;  // position handled through dp = p1 - p0 (translation invariance)
+    s1[0] = p1 - p0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) {
+        s0[d] = tp[d] * ys[d - 1];
+        s1[d] = tp[d] * ye[d - 1];
+    }
+    double e[R];
+#pragma unroll
+    for (int d = 0; d < R; ++d) {
+        double acc = s1[d];
+#pragma unroll
+        for (int k = (d > 1 ? d : 1); k < R; ++k) acc -= s0[k] * inv_fact(k - d);
+        e[d] = acc;
+    }
+    c[0] = p0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) c[d] = ys[d - 1] * inv_fact(d);
+    double ipw = 1.0;
+#pragma unroll
+    for (int d = 0; d < R; ++d) ipw *= it;  // T^-R
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        double q = 0.0;
+#pragma unroll
+        for (int d = 0; d < R; ++d) q += Tab<R>::K(j, d) * e[d];
+        c[R + j] = q * ipw;
+        ipw *= it;
+    }
+}
+
+}  // namespace uavqp

@@ -1,0 +1,456 @@
+// uavqp.hip -- HIP kernels + C ABI (include/uavqp.h) of the batched min-jerk / min-snap QP back-end.
+// gfx950 only.  The product path has no CPU fallback: every entry point fails with a negative code
+// when no device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/uavqp.h"
+#include "qp_device.h"
+
+namespace uavqp {
+
+struct BatchArgs {
+    int n_traj;
+    int uniform;       // > 0: uniform segment count
+    int max_segments;  // ragged upper bound
+    const int32_t* seg_offsets;
+    const double* waypoints;
+    const double* times;
+    const double* bc;
+    double* coeff;
+    int32_t* status;
+    double* ws;  // forward-sweep workspace (generic kernel)
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Generic kernel: one lane per trajectory, any segment count (ragged batches), r = 3 or 4.
+// Forward block elimination keeps E_k = S_k^-1 A01(k) and h_k = S_k^-1 z_k per interior knot in a
+// lane-interleaved HBM workspace  ws[((k-1)*F + f) * n_slots + slot]  (coalesced across the wave),
+// the backward sweep re-reads them and emits segment coefficients as it goes.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
+    constexpr int ND = R - 1, NC = 2 * R, F = ND * ND + 3 * ND;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_slots = gridDim.x * blockDim.x;
+    double* __restrict__ ws = a.ws + slot;
+    const size_t wstride = (size_t)n_slots;
+
+    for (int b = slot; b < a.n_traj; b += n_slots) {
+        int s0, M;
+        if (a.uniform > 0) {
+            M = a.uniform;
+            s0 = b * M;
+        } else {
+            s0 = a.seg_offsets[b];
+            M = a.seg_offsets[b + 1] - s0;
+        }
+        const double* __restrict__ wp = a.waypoints + 3 * (size_t)(s0 + b);
+        const double* __restrict__ T = a.times + s0;
+        const double* __restrict__ bc = a.bc + (size_t)b * 2 * ND * 3;
+        double* __restrict__ out = a.coeff + (size_t)3 * NC * s0;
+
+        bool ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments);
+        if (ok)
+            for (int i = 0; i < M; ++i) ok = ok && (T[i] > 0.0) && (T[i] < INFINITY);
+        if (!ok) {
+            if (a.status) a.status[b] = UAVQP_INVALID_INPUT;
+            continue;
+        }
+
+        double y0[ND][3], yM[ND][3];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                y0[d][ax] = bc[d * 3 + ax];
+                yM[d][ax] = bc[(ND + d) * 3 + ax];
+            }
+
+        // ---------------- forward elimination over interior knots k = 1..M-1 ----------------
+        SegBlocks<R> sa;
+        sa.build(T[0]);
+        double pb[3], dpa[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            pb[ax] = wp[3 + ax];
+            dpa[ax] = pb[ax] - wp[ax];
+        }
+        double Eprev[ND][ND], hprev[ND][3];
+        for (int k = 1; k < M; ++k) {
+            SegBlocks<R> sb;
+            sb.build(T[k]);
+            double dpb[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double pc = wp[3 * (k + 1) + ax];
+                dpb[ax] = pc - pb[ax];
+                pb[ax] = pc;
+            }
+            double S[ND][ND], z[ND][3];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+#pragma unroll
+                for (int j = 0; j < ND; ++j) S[i][j] = sa.A11[i][j] + sb.A00[i][j];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) z[i][ax] = sb.gv[i] * dpb[ax] - sa.gw[i] * dpa[ax];
+            }
+            if (k == 1) {
+#pragma unroll
+                for (int i = 0; i < ND; ++i)
+#pragma unroll
+                    for (int j = 0; j < ND; ++j)
+#pragma unroll
+                        for (int ax = 0; ax < 3; ++ax) z[i][ax] -= sa.A01[j][i] * y0[j][ax];
+            } else {
+#pragma unroll
+                for (int i = 0; i < ND; ++i)
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) {
+#pragma unroll
+                        for (int c = 0; c < ND; ++c) S[i][c] -= sa.A01[j][i] * Eprev[j][c];
+#pragma unroll
+                        for (int ax = 0; ax < 3; ++ax) z[i][ax] -= sa.A01[j][i] * hprev[j][ax];
+                    }
+            }
+            if (k == M - 1) {
+#pragma unroll
+                for (int i = 0; i < ND; ++i)
+#pragma unroll
+                    for (int j = 0; j < ND; ++j)
+#pragma unroll
+                        for (int ax = 0; ax < 3; ++ax) z[i][ax] -= sb.A01[i][j] * yM[j][ax];
+            }
+            SmallLDL<ND> ldl;
+            ldl.factor(S);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double col[ND];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) col[i] = z[i][ax];
+                ldl.solve(col);
+#pragma unroll
+                for (int i = 0; i < ND; ++i) hprev[i][ax] = col[i];
+            }
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                double col[ND];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) col[i] = sb.A01[i][c];
+                ldl.solve(col);
+#pragma unroll
+                for (int i = 0; i < ND; ++i) Eprev[i][c] = col[i];
+            }
+            double* w = ws + (size_t)(k - 1) * F * wstride;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+#pragma unroll
+                for (int c = 0; c < ND; ++c) w[(size_t)(i * ND + c) * wstride] = Eprev[i][c];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) w[(size_t)(ND * ND + i * 3 + ax) * wstride] = hprev[i][ax];
+            }
+            sa = sb;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) dpa[ax] = dpb[ax];
+        }
+
+        // ---------------- backward substitution + coefficient emission ----------------
+        double ynext[ND][3], pend[3];
+        bool finite = true;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            pend[ax] = wp[3 * M + ax];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) ynext[d][ax] = yM[d][ax];
+        }
+        for (int k = M - 1; k >= 0; --k) {
+            double y[ND][3];
+            if (k == 0) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) y[d][ax] = y0[d][ax];
+            } else {
+                const double* w = ws + (size_t)(k - 1) * F * wstride;
+#pragma unroll
+                for (int i = 0; i < ND; ++i)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) y[i][ax] = w[(size_t)(ND * ND + i * 3 + ax) * wstride];
+                if (k < M - 1) {
+#pragma unroll
+                    for (int i = 0; i < ND; ++i)
+#pragma unroll
+                        for (int c = 0; c < ND; ++c) {
+                            const double e = w[(size_t)(i * ND + c) * wstride];
+#pragma unroll
+                            for (int ax = 0; ax < 3; ++ax) y[i][ax] -= e * ynext[c][ax];
+                        }
+                }
+            }
+            const double Tk = T[k], itk = 1.0 / Tk;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double pk = wp[3 * k + ax];
+                double ys[ND], ye[ND], c[NC];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    ys[d] = y[d][ax];
+                    ye[d] = ynext[d][ax];
+                }
+                segment_coeffs<R>(pk, ys, pend[ax], ye, Tk, itk, c);
+                double* o = out + ((size_t)ax * M + k) * NC;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) o[j] = c[j];
+                finite = finite && (fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY);
+                pend[ax] = pk;
+            }
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) ynext[d][ax] = y[d][ax];
+        }
+        if (a.status) a.status[b] = finite ? UAVQP_SOLVED : UAVQP_NON_FINITE;
+    }
+}
+
+}  // namespace uavqp
+
+// ===================================================================================================
+// C ABI
+// ===================================================================================================
+using uavqp::BatchArgs;
+
+static thread_local std::string g_last_error;
+
+struct uavqp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int variant = 0;
+    int num_cus = 256;
+    double* ws = nullptr;
+    size_t ws_bytes = 0;
+    // staging buffers of the host-pointer entry points
+    void* d_stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+#define UAVQP_HIP(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            return UAVQP_ERR_HIP;                                                                \
+        }                                                                                        \
+    } while (0)
+
+extern "C" const char* uavqp_version(void) { return "uavqp 0.1.0 (gfx950, float64)"; }
+extern "C" const char* uavqp_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
+    if (!out_ctx) return UAVQP_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_last_error = "no HIP device visible (the uavqp product path has no CPU fallback)";
+        return UAVQP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n_dev) {
+        g_last_error = "device index out of range";
+        return UAVQP_ERR_INVALID_ARG;
+    }
+    UAVQP_HIP(hipSetDevice(device));
+    uavqp_ctx* ctx = new (std::nothrow) uavqp_ctx();
+    if (!ctx) return UAVQP_ERR_ALLOC;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete ctx;
+        return UAVQP_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out_ctx = ctx;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_destroy(uavqp_ctx* ctx) {
+    if (!ctx) return UAVQP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_set_stream(uavqp_ctx* ctx, void* hip_stream) {
+    if (!ctx) return UAVQP_ERR_INVALID_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_synchronize(uavqp_ctx* ctx) {
+    if (!ctx) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_set_variant(uavqp_ctx* ctx, int variant) {
+    if (!ctx || variant < 0 || variant > 2) return UAVQP_ERR_INVALID_ARG;
+    ctx->variant = variant;
+    return UAVQP_OK;
+}
+
+static int ensure_ws(uavqp_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return UAVQP_OK;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) UAVQP_HIP(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    UAVQP_HIP(hipMalloc((void**)&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                        const int32_t* d_seg_offsets, const double* d_waypoints,
+                                        const double* d_times, const double* d_bc, double* d_coeff_out,
+                                        int32_t* d_status_out) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!d_waypoints || !d_times || !d_bc || !d_coeff_out) return UAVQP_ERR_INVALID_ARG;
+    if (uniform_segments == 0 && (!d_seg_offsets || max_segments < 1)) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    const int Mmax = uniform_segments > 0 ? uniform_segments : max_segments;
+
+    BatchArgs a;
+    a.n_traj = n_traj;
+    a.uniform = uniform_segments;
+    a.max_segments = Mmax;
+    a.seg_offsets = d_seg_offsets;
+    a.waypoints = d_waypoints;
+    a.times = d_times;
+    a.bc = d_bc;
+    a.coeff = d_coeff_out;
+    a.status = d_status_out;
+
+    const int block = 64;
+    int grid = (n_traj + block - 1) / block;
+    const int max_grid = ctx->num_cus * 8;
+    if (grid > max_grid) grid = max_grid;
+    const int F = (r - 1) * (r - 1) + 3 * (r - 1);
+    const size_t ws_bytes = sizeof(double) * (size_t)(Mmax > 1 ? Mmax - 1 : 1) * F * (size_t)grid * block;
+    int rc = ensure_ws(ctx, ws_bytes);
+    if (rc != UAVQP_OK) return rc;
+    a.ws = ctx->ws;
+    if (r == 3)
+        hipLaunchKernelGGL(uavqp::solve_generic_kernel<3>, dim3(grid), dim3(block), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(uavqp::solve_generic_kernel<4>, dim3(grid), dim3(block), 0, ctx->stream, a);
+    UAVQP_HIP(hipGetLastError());
+    return UAVQP_OK;
+}
+
+static int ensure_stage(uavqp_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->stage_bytes) return UAVQP_OK;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage) UAVQP_HIP(hipFree(ctx->d_stage));
+    ctx->d_stage = nullptr;
+    ctx->stage_bytes = 0;
+    UAVQP_HIP(hipMalloc(&ctx->d_stage, bytes));
+    ctx->stage_bytes = bytes;
+    return UAVQP_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                      const int32_t* seg_offsets, const double* waypoints, const double* times,
+                                      const double* bc, double* coeff_out, int32_t* status_out) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!waypoints || !times || !bc || !coeff_out) return UAVQP_ERR_INVALID_ARG;
+    if (uniform_segments == 0 && !seg_offsets) return UAVQP_ERR_INVALID_ARG;
+    long long total_seg = 0;
+    int Mmax = uniform_segments;
+    if (uniform_segments > 0) {
+        total_seg = (long long)uniform_segments * n_traj;
+    } else {
+        if (seg_offsets[0] != 0) return UAVQP_ERR_INVALID_ARG;
+        for (int b = 0; b < n_traj; ++b) {
+            const int M = seg_offsets[b + 1] - seg_offsets[b];
+            if (M < 0) return UAVQP_ERR_INVALID_ARG;
+            if (M > Mmax) Mmax = M;
+        }
+        total_seg = seg_offsets[n_traj];
+        if (max_segments > 0 && max_segments < Mmax) Mmax = max_segments;  // larger ones are flagged invalid
+        if (Mmax < 1) Mmax = 1;
+    }
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    const size_t b_off = uniform_segments > 0 ? 0 : align256(sizeof(int32_t) * (size_t)(n_traj + 1));
+    const size_t b_wp = align256(sizeof(double) * 3 * (size_t)(total_seg + n_traj));
+    const size_t b_t = align256(sizeof(double) * (size_t)total_seg);
+    const size_t b_bc = align256(sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3);
+    const size_t b_out = align256(sizeof(double) * 3 * 2 * r * (size_t)total_seg);
+    const size_t b_st = align256(sizeof(int32_t) * (size_t)n_traj);
+    int rc = ensure_stage(ctx, b_off + b_wp + b_t + b_bc + b_out + b_st);
+    if (rc != UAVQP_OK) return rc;
+    char* base = (char*)ctx->d_stage;
+    int32_t* d_off = uniform_segments > 0 ? nullptr : (int32_t*)base;
+    double* d_wp = (double*)(base + b_off);
+    double* d_t = (double*)(base + b_off + b_wp);
+    double* d_bc = (double*)(base + b_off + b_wp + b_t);
+    double* d_out = (double*)(base + b_off + b_wp + b_t + b_bc);
+    int32_t* d_st = (int32_t*)(base + b_off + b_wp + b_t + b_bc + b_out);
+    hipStream_t s = ctx->stream;
+    if (d_off) UAVQP_HIP(hipMemcpyAsync(d_off, seg_offsets, sizeof(int32_t) * (size_t)(n_traj + 1), hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_wp, waypoints, sizeof(double) * 3 * (size_t)(total_seg + n_traj), hipMemcpyHostToDevice, s));
+    if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(d_t, times, sizeof(double) * (size_t)total_seg, hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_bc, bc, sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3, hipMemcpyHostToDevice, s));
+    rc = uavqp_solve_batch_device(ctx, r, n_traj, uniform_segments, Mmax, d_off, d_wp, d_t, d_bc, d_out, d_st);
+    if (rc != UAVQP_OK) return rc;
+    if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(coeff_out, d_out, sizeof(double) * 3 * 2 * r * (size_t)total_seg, hipMemcpyDeviceToHost, s));
+    if (status_out) UAVQP_HIP(hipMemcpyAsync(status_out, d_st, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
+    UAVQP_HIP(hipStreamSynchronize(s));
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const double* pos_1d, const double* bound_vel,
+                                     const double* bound_acc, const double* bound_jerk, const double* time_vec,
+                                     double* coef_1d, int32_t* status_out) {
+    if (!ctx || (r != 3 && r != 4) || n_seg < 1 || !pos_1d || !bound_vel || !bound_acc || !time_vec || !coef_1d)
+        return UAVQP_ERR_INVALID_ARG;
+    // One axis of the reference call = a 1-trajectory batch whose other two axes are zero.
+    const int nd = r - 1, nc = 2 * r;
+    double* wp = new (std::nothrow) double[3 * (size_t)(n_seg + 1)]();
+    double* out = new (std::nothrow) double[3 * (size_t)nc * n_seg]();
+    if (!wp || !out) {
+        delete[] wp;
+        delete[] out;
+        return UAVQP_ERR_ALLOC;
+    }
+    for (int i = 0; i <= n_seg; ++i) wp[3 * i] = pos_1d[i];
+    double bc[2 * 3 * 3] = {0};
+    for (int e = 0; e < 2; ++e) {
+        bc[(e * nd + 0) * 3] = bound_vel[e];
+        bc[(e * nd + 1) * 3] = bound_acc[e];
+        if (r == 4) bc[(e * nd + 2) * 3] = bound_jerk ? bound_jerk[e] : 0.0;
+    }
+    int32_t st = 0;
+    int rc = uavqp_solve_batch_host(ctx, r, 1, n_seg, n_seg, nullptr, wp, time_vec, bc, out, &st);
+    if (rc == UAVQP_OK && st == UAVQP_SOLVED) std::memcpy(coef_1d, out, sizeof(double) * (size_t)nc * n_seg);
+    if (status_out) *status_out = st;
+    delete[] wp;
+    delete[] out;
+    return rc;
+}

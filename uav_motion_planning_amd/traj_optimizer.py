@@ -1,0 +1,206 @@
+"""Host-side mirror of the reference optimiser interface over the C ABI (include/uavqp.h).
+
+  * MinimumControl  -- same method names / argument meaning / error behaviour as
+    traj_optimization::MinimumControl (reference minimum_control.h:10-48, minimum_control.cpp:127-202):
+    solve(pos_1d, bound_vel, bound_acc, time_vec) -> bool, getCoef1d(), reset().
+  * TrajOptimizer   -- the batch facade named by BASELINE.json's north_star
+    (setWaypoints / setTimeAllocation / solve / getPolyCoeff); no reference counterpart.
+  * Context         -- thin RAII wrapper of uavqp_ctx for callers that already hold device buffers.
+
+torch is used only for device memory and streams.  No CPU fallback: without libuavqp.so or without a
+GPU every solve raises / returns False exactly as the reference does on solver failure.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(x):
+    """Raw address of a numpy array / torch tensor / None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()  # torch tensor
+
+
+class Context:
+    """Owns one uavqp_ctx (one per host thread / device, as MinimumControl owns one OsqpEigen::Solver)."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().uavqp_create(ctypes.byref(self._h), int(device)), "uavqp_create")
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().uavqp_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream_handle):
+        """hip_stream_handle: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        _lib.check(_lib.lib().uavqp_set_stream(self._h, ctypes.c_void_p(hip_stream_handle or 0)), "uavqp_set_stream")
+
+    def set_variant(self, variant):
+        _lib.check(_lib.lib().uavqp_set_variant(self._h, int(variant)), "uavqp_set_variant")
+
+    def synchronize(self):
+        _lib.check(_lib.lib().uavqp_synchronize(self._h), "uavqp_synchronize")
+
+    def solve_batch_device(self, r, n_traj, uniform_segments, max_segments, seg_offsets, waypoints, times, bc,
+                           coeff_out, status_out=None):
+        """All array arguments are device buffers (torch CUDA tensors or raw integer addresses). Asynchronous."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_solve_batch_device(self._h, r, n_traj, uniform_segments, max_segments, p(seg_offsets),
+                                                 p(waypoints), p(times), p(bc), p(coeff_out), p(status_out))
+        _lib.check(rc, "uavqp_solve_batch_device")
+
+    def solve_batch_host(self, r, seg_offsets, waypoints, times, bc, uniform_segments=0):
+        """numpy in / numpy out (H2D + solve + D2H, synchronous).  Returns (coeff_flat, status)."""
+        waypoints = np.ascontiguousarray(waypoints, dtype=np.float64)
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        bc = np.ascontiguousarray(bc, dtype=np.float64)
+        if uniform_segments > 0:
+            n_traj = times.size // uniform_segments
+            so = None
+            total = n_traj * uniform_segments
+            mmax = uniform_segments
+        else:
+            so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+            n_traj = so.size - 1
+            total = int(so[-1]) if n_traj > 0 else 0
+            mmax = int(np.max(np.diff(so))) if n_traj > 0 else 1
+        assert waypoints.size == 3 * (total + n_traj), "waypoints must hold sum(M_b + 1) xyz rows"
+        assert bc.size == n_traj * 2 * (r - 1) * 3
+        coeff = np.zeros(3 * 2 * r * total, dtype=np.float64)
+        status = np.zeros(n_traj, dtype=np.int32)
+        rc = _lib.lib().uavqp_solve_batch_host(self._h, r, n_traj, uniform_segments, max(mmax, 1), _ptr(so),
+                                               _ptr(waypoints), _ptr(times), _ptr(bc), _ptr(coeff), _ptr(status))
+        _lib.check(rc, "uavqp_solve_batch_host")
+        return coeff, status
+
+    def solve_axis_host(self, r, pos_1d, bound_vel, bound_acc, time_vec, bound_jerk=None):
+        pos = np.ascontiguousarray(pos_1d, dtype=np.float64)
+        bv = np.ascontiguousarray(bound_vel, dtype=np.float64)
+        ba = np.ascontiguousarray(bound_acc, dtype=np.float64)
+        bj = None if bound_jerk is None else np.ascontiguousarray(bound_jerk, dtype=np.float64)
+        tv = np.ascontiguousarray(time_vec, dtype=np.float64)
+        n_seg = tv.size
+        coef = np.zeros(2 * r * max(n_seg, 0), dtype=np.float64)
+        st = ctypes.c_int32(0)
+        rc = _lib.lib().uavqp_solve_axis_host(self._h, r, n_seg, _ptr(pos), _ptr(bv), _ptr(ba), _ptr(bj), _ptr(tv),
+                                              _ptr(coef), ctypes.byref(st))
+        return rc, st.value, coef
+
+
+class MinimumControl:
+    """Drop-in mirror of traj_optimization::MinimumControl (reference minimum_control.h:10-48).
+
+    solve() keeps the reference's contract: inputs are not modified, the return value is a bool,
+    on failure the previously stored coefficients are kept (minimum_control.cpp:173-184), one axis per
+    call, coefficients in ascending powers per segment (minimum_control.cpp:186).  `order` selects
+    r = 3 (min-jerk, the reference) or r = 4 (min-snap extension; bound_jerk defaults to zero).
+    """
+
+    def __init__(self, order=3, device=0):
+        assert order in (3, 4)
+        self._r = order
+        self._ctx = Context(device)
+        self._coef_1d = np.zeros(0)
+
+    def solve(self, pos_1d, bound_vel, bound_acc, time_vec, bound_jerk=None):
+        pos = np.asarray(pos_1d, dtype=np.float64)
+        tv = np.asarray(time_vec, dtype=np.float64)
+        # reference H8: pos_1d.size() < 2 indexes out of range there; here it is a clean failure
+        if pos.ndim != 1 or tv.ndim != 1 or tv.size < 1 or pos.size != tv.size + 1:
+            print("solver init failed!")
+            return False
+        rc, st, coef = self._ctx.solve_axis_host(self._r, pos, bound_vel, bound_acc, tv, bound_jerk)
+        if rc != _lib.UAVQP_OK:
+            print("solver init failed!")
+            return False
+        if st != _lib.UAVQP_SOLVED:
+            print("solver solve failed!")
+            return False
+        self._coef_1d = coef
+        return True
+
+    def reset(self):
+        """minimum_control.cpp:194-197: coef_1d_.setZero()."""
+        self._coef_1d = np.zeros_like(self._coef_1d)
+
+    def getCoef1d(self):
+        """minimum_control.cpp:199-202: returns a copy."""
+        return self._coef_1d.copy()
+
+
+class TrajOptimizer:
+    """Batch facade with the north-star method names; all trajectories and axes in one device pass.
+
+    setWaypoints(xyz, wp_offsets)    xyz [sum(M_b+1)][3]; wp_offsets[n_traj+1] (or None + uniform count)
+    setTimeAllocation(T)             T [sum M_b]
+    setBoundary(bc)                  bc [n_traj][2][r-1][3]; default: all zero (test_minimum_jerk.cpp:59-63)
+    solve() -> bool                  True iff every trajectory solved (statuses in .status)
+    getPolyCoeff()                   flat float64 array, trajectory b at 3*2r*seg_offsets[b], [axis][seg][2r]
+    """
+
+    def __init__(self, order=4, device=0):
+        assert order in (3, 4)
+        self._r = order
+        self._ctx = Context(device)
+        self._wp = self._T = self._bc = self._so = None
+        self._coef = np.zeros(0)
+        self.status = np.zeros(0, dtype=np.int32)
+
+    def setWaypoints(self, xyz, wp_offsets=None, n_waypoints=None):
+        self._wp = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        if wp_offsets is not None:
+            wo = np.asarray(wp_offsets, dtype=np.int64)
+            n_traj = wo.size - 1
+            self._so = (wo - np.arange(n_traj + 1)).astype(np.int32)  # waypoint offsets -> segment offsets
+        else:
+            assert n_waypoints is not None and n_waypoints >= 2 and self._wp.shape[0] % n_waypoints == 0
+            n_traj = self._wp.shape[0] // n_waypoints
+            self._so = (np.arange(n_traj + 1) * (n_waypoints - 1)).astype(np.int32)
+
+    def setTimeAllocation(self, T):
+        self._T = np.ascontiguousarray(T, dtype=np.float64).ravel()
+
+    def setBoundary(self, bc):
+        self._bc = np.ascontiguousarray(bc, dtype=np.float64)
+
+    def solve(self):
+        if self._wp is None or self._T is None:
+            return False
+        n_traj = self._so.size - 1
+        if self._T.size != int(self._so[-1]):
+            return False
+        bc = self._bc if self._bc is not None else np.zeros((n_traj, 2, self._r - 1, 3))
+        try:
+            self._coef, self.status = self._ctx.solve_batch_host(self._r, self._so, self._wp, self._T, bc)
+        except _lib.UavqpError as e:
+            print(f"solver init failed! ({e})")
+            return False
+        return bool(np.all(self.status == _lib.UAVQP_SOLVED))
+
+    def getPolyCoeff(self, traj=None):
+        if traj is None:
+            return self._coef.copy()
+        s0, s1 = int(self._so[traj]), int(self._so[traj + 1])
+        nc = 2 * self._r
+        return self._coef[3 * nc * s0:3 * nc * s1].reshape(3, s1 - s0, nc).copy()

@@ -1,0 +1,97 @@
+"""Synthetic waypoint / time-allocation batches for BASELINE.json's configs.
+
+Seed rule: numpy default_rng(20260925 + config index).  Map box, step lengths, velocities follow the
+reference launch files: map 40 x 20 x 3 m and virtual ceiling 2.5 m (test_minimum_jerk.launch:6-8,37),
+RRT* step_length 1.5 m (:45), start velocity from odometry, all other boundary derivatives zero
+(test_minimum_jerk.cpp:32-37,59-63), constant 1.0 s per segment (test_minimum_jerk.cpp:65-71).
+"""
+import numpy as np
+
+SEED0 = 20260925
+BOX_LO = np.array([-20.0, -10.0, 0.5])
+BOX_HI = np.array([20.0, 10.0, 2.5])
+
+
+def _random_rotation_within(rng, d, max_angle):
+    """Rotate unit vectors d [n,3] by a random angle <= max_angle about a random perpendicular axis."""
+    n = d.shape[0]
+    rnd = rng.normal(size=(n, 3))
+    perp = rnd - np.sum(rnd * d, axis=1, keepdims=True) * d
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True) + 1e-300
+    ang = rng.uniform(0.0, max_angle, size=(n, 1))
+    return np.cos(ang) * d + np.sin(ang) * perp
+
+
+def search_like_paths(rng, n_traj, n_seg, step=(1.0, 2.0), max_turn_deg=60.0):
+    """'A*/RRT*-like' waypoint lists: persistent heading, bounded turn, reflected at the map box."""
+    p = rng.uniform(BOX_LO, BOX_HI, size=(n_traj, 3))
+    d = rng.normal(size=(n_traj, 3))
+    d[:, 2] *= 0.2
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    wps = [p.copy()]
+    for _ in range(n_seg):
+        d = _random_rotation_within(rng, d, np.deg2rad(max_turn_deg))
+        q = p + d * rng.uniform(step[0], step[1], size=(n_traj, 1))
+        for ax in range(3):  # reflect at the walls
+            lo, hi = BOX_LO[ax], BOX_HI[ax]
+            over, under = q[:, ax] > hi, q[:, ax] < lo
+            q[over, ax] = 2 * hi - q[over, ax]
+            q[under, ax] = 2 * lo - q[under, ax]
+            d[over | under, ax] *= -1.0
+        p = q
+        wps.append(p.copy())
+    return np.stack(wps, axis=1)  # [n_traj, n_seg+1, 3]
+
+
+def uniform_batch(config_index, n_traj, n_seg, r, time_mode="reference", seed=None):
+    """Uniform-M batch.  Returns dict(seg_offsets, waypoints[n,M+1,3], times[n,M], bc[n,2,r-1,3], r, M)."""
+    rng = np.random.default_rng(SEED0 + config_index if seed is None else seed)
+    wp = search_like_paths(rng, n_traj, n_seg)
+    if time_mode == "reference":  # test_minimum_jerk.cpp:70: time_vec(i) = 1.0
+        T = np.ones((n_traj, n_seg))
+    elif time_mode == "distance":  # T_i = max(0.3, |dp| / 2 m/s)
+        T = np.maximum(0.3, np.linalg.norm(np.diff(wp, axis=1), axis=2) / 2.0)
+    elif time_mode == "wide":  # stress: T in [0.2, 5] s
+        T = rng.uniform(0.2, 5.0, size=(n_traj, n_seg))
+    else:
+        raise ValueError(time_mode)
+    bc = np.zeros((n_traj, 2, r - 1, 3))
+    bc[:, 0, 0, :] = rng.uniform(-1.0, 1.0, size=(n_traj, 3))  # start velocity from odometry
+    so = (np.arange(n_traj + 1) * n_seg).astype(np.int32)
+    return dict(r=r, M=n_seg, seg_offsets=so, waypoints=wp, times=T, bc=bc)
+
+
+def ragged_batch(config_index, n_traj, r, m_lo=4, m_hi=24, seed=None):
+    """Config-4 style 'kino-A*-like' ragged batch: M ~ U{m_lo..m_hi}; node duration 0.3 s
+    (sample_tau, test_kino_astar_searching.launch:52) except a final one-shot segment U(0.5, 2.0)
+    (kino_astar.cpp:124); waypoints from double-integrator roll-outs with a in {-10,-5,0,5,10}^3,
+    |v| <= 7 (launch :49-51, kino_astar.cpp:651-670)."""
+    rng = np.random.default_rng(SEED0 + config_index if seed is None else seed)
+    Ms = rng.integers(m_lo, m_hi + 1, size=n_traj)
+    so = np.zeros(n_traj + 1, dtype=np.int32)
+    so[1:] = np.cumsum(Ms)
+    total = int(so[-1])
+    wp = np.zeros((total + n_traj, 3))
+    T = np.zeros(total)
+    bc = np.zeros((n_traj, 2, r - 1, 3))
+    acc_set = np.array([-10.0, -5.0, 0.0, 5.0, 10.0])
+    for b in range(n_traj):
+        M = int(Ms[b])
+        p = rng.uniform(BOX_LO, BOX_HI)
+        v = rng.uniform(-2.0, 2.0, size=3)
+        bc[b, 0, 0] = v
+        row = int(so[b]) + b
+        wp[row] = p
+        for i in range(M):
+            tau = 0.3 if i < M - 1 else rng.uniform(0.5, 2.0)
+            a = rng.choice(acc_set, size=3)
+            p = p + v * tau + 0.5 * a * tau * tau
+            v = np.clip(v + a * tau, -7.0, 7.0)
+            wp[row + i + 1] = p
+            T[so[b] + i] = tau
+    return dict(r=r, M=0, seg_offsets=so, waypoints=wp, times=T, bc=bc)
+
+
+def algorithmic_bytes(r, n_seg):
+    """float64, 3 axes, equality-only: in = 8[3(M+1)+M+3*2*(r-1)], out = 8*3*2r*M."""
+    return 8 * (3 * (n_seg + 1) + n_seg + 3 * 2 * (r - 1)) + 8 * 3 * 2 * r * n_seg
