@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- trajectories/s of the batched min-snap QP hot path on N MI355X GPUs (one process per GPU).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (uavqp_solve_batch_device: assembly + factorisation + solve +
+coefficient write-back for all 3 axes) over one batch of synthetic waypoints already resident in HBM.
+Workload at N=1: BASELINE.json configs[1] -- 4096 independent 8-segment 7th-order (min-snap) 3-axis
+trajectories, synthetic A*-like waypoints (uav_motion_planning_amd/workloads.py, seed 20260925+2).
+N>1: every rank solves its own 4096-trajectory shard (weak scaling, no data-path collective in the
+timed loop); the RCCL all-gather of the solved coefficient shards is run and timed separately and
+reported under "allgather" (DESIGN.md section 7).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU per step")
+    ap.add_argument("--segments", type=int, default=8)
+    ap.add_argument("--order", type=int, default=4, help="4 = min-snap (7th-order), 3 = min-jerk")
+    ap.add_argument("--time-mode", default="distance", choices=["reference", "distance", "wide"])
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="trajectories in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-allgather", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, r, n_sample):
+    """OSQP-faithful CPU restatement (oracle/osqp_port.c) timed on this host: one full
+    setup+solve+cleanup per axis, exactly the reference's call pattern (test_minimum_jerk.cpp:75,100,125)."""
+    from oracle import oracle
+    oracle.build()
+    if not hasattr(oracle, "osqp_solve_batch"):
+        return None
+    n = min(n_sample, batch["waypoints"].shape[0])
+    M = batch["M"]
+    so = batch["seg_offsets"][: n + 1]
+    t0 = time.perf_counter()
+    oracle.osqp_solve_batch(r, so, batch["waypoints"][:n], batch["times"][:n], batch["bc"][:n], threads=1)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} trajectories of the same batch (M={M}, r={r}), OSQP-port with the reference's "
+                      f"settings, 3 setup+solve per trajectory, {dt:.2f} s of CPU work",
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import uav_motion_planning_amd as U
+    from uav_motion_planning_amd import workloads as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the uavqp product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    r, M, B = args.order, args.segments, args.batch
+    batch = W.uniform_batch(2, B, M, r, time_mode=args.time_mode, seed=W.SEED0 + 2 + 1000 * rank)
+    d_wp = torch.from_numpy(batch["waypoints"]).to(dev)
+    d_T = torch.from_numpy(batch["times"]).to(dev)
+    d_bc = torch.from_numpy(batch["bc"]).to(dev)
+    d_out = torch.zeros(B * 3 * M * 2 * r, dtype=torch.float64, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    ctx = U.Context(local_rank)
+    stream = torch.cuda.Stream(device=dev)  # explicit side stream: its handle is non-null, events see the kernels
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_variant(args.variant)
+
+    def step():
+        ctx.solve_batch_device(r, B, M, M, None, d_wp, d_T, d_bc, d_out, d_st)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    fence()
+    dt = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert int((d_st == U.UAVQP_SOLVED).sum().item()) == B, "some trajectories were not solved"
+
+    # per-launch kernel duration: HIP events bracketing each launch on the launch stream (post-pass)
+    n_ev = min(args.steps, 200)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    per_launch_ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+    kernel_ms = min(per_launch_ms, region_ms / args.steps)
+
+    gather = None
+    if world > 1 and not args.no_allgather:
+        # RCCL all-gather of the solved coefficient shards over xGMI (equal shards)
+        full = torch.empty(world * d_out.numel(), dtype=torch.float64, device=dev)
+        for _ in range(3):
+            dist.all_gather_into_tensor(full, d_out)
+        fence()
+        g0 = time.perf_counter()
+        n_g = 10
+        for _ in range(n_g):
+            dist.all_gather_into_tensor(full, d_out)
+        fence()
+        g_ms = (time.perf_counter() - g0) / n_g * 1e3
+        ok = bool(torch.equal(full[rank * d_out.numel():(rank + 1) * d_out.numel()], d_out))
+        gather = {"ms": g_ms, "bytes_per_rank_out": d_out.numel() * 8, "bytes_total": full.numel() * 8,
+                  "own_shard_intact": ok,
+                  "value_with_gather": world * B / (dt / args.steps + g_ms * 1e-3)}
+
+    if rank == 0:
+        bytes_per_traj = W.algorithmic_bytes(r, M)
+        achieved = B * bytes_per_traj / (kernel_ms * 1e-3) / 1e9
+        n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 4096
+        cpu = cpu_baseline(batch, r, n_cpu) if (n_cpu > 0 and world == 1) else None
+        out = {
+            "metric": "trajectories/sec (8-seg 7th-order min-snap, 3-axis)",
+            "value": world * B * args.steps / dt,
+            "unit": "trajectories/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch of {B} independent {M}-segment order-{2 * r - 1} "
+                                   f"(r={r}) 3-axis trajectories per GPU, synthetic A*-like waypoints, "
+                                   f"time allocation '{args.time_mode}'",
+                       "batch_per_gpu": B, "segments": M, "r": r, "variant": args.variant,
+                       "parallelism": f"shard{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kernel_ms, "per_launch_event_ms": per_launch_ms,
+                         "region_ms_per_step": region_ms / args.steps,
+                         "algorithmic_bytes_per_trajectory": bytes_per_traj},
+            "cpu_baseline": cpu,
+        }
+        if gather:
+            out["allgather"] = gather
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,10 +34,15 @@ def test_reference_kat_qpsolve(gpu_ctx):
 @pytest.mark.parametrize("r", [3, 4])
 @pytest.mark.parametrize("M", [1, 2, 3, 7, 8, 16, 24])
 @pytest.mark.parametrize("time_mode", ["reference", "distance", "wide"])
-def test_uniform_batch_vs_oracle(gpu_ctx, oracle, r, M, time_mode):
-    n = 48
+@pytest.mark.parametrize("variant", [0, 1])
+def test_uniform_batch_vs_oracle(gpu_ctx, oracle, r, M, time_mode, variant):
+    """variant 1 = generic lane-per-trajectory kernel, 0 = auto (register-resident twisted kernel where
+    an (r, M) instantiation exists).  n = 45 leaves a partial 32-trajectory tile."""
+    n = 45
     b = W.uniform_batch(100 + M, n, M, r, time_mode=time_mode)
+    gpu_ctx.set_variant(variant)
     got, st = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    gpu_ctx.set_variant(0)
     ref, st_ref = oracle.solve_exact_batch(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
     assert np.all(st == UAVQP_SOLVED) and np.all(st_ref == 0)
     err = rel_err_per_traj(got, ref, b["seg_offsets"], r)
@@ -54,13 +59,16 @@ def test_ragged_batch_vs_oracle(gpu_ctx, oracle, r):
     assert rel_err_per_traj(got, ref, b["seg_offsets"], r).max() < 1e-8
 
 
-def test_invalid_inputs_are_flagged_not_fatal(gpu_ctx):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_invalid_inputs_are_flagged_not_fatal(gpu_ctx, variant):
     b = W.uniform_batch(7, 8, 4, 3)
     T = b["times"].copy()
     T[2, 1] = 0.0
     T[5, 3] = np.nan
     T[6, 0] = -1.0
+    gpu_ctx.set_variant(variant)
     got, st = gpu_ctx.solve_batch_host(3, None, b["waypoints"], T, b["bc"], uniform_segments=4)
+    gpu_ctx.set_variant(0)
     assert list(st[[2, 5, 6]]) == [UAVQP_INVALID_INPUT] * 3
     assert np.all(np.delete(st, [2, 5, 6]) == UAVQP_SOLVED)
     assert np.all(np.isfinite(got))

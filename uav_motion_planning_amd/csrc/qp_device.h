@@ -31,6 +31,23 @@ template <> struct Tab<4> {
     static __device__ __forceinline__ constexpr double U(int i, int j) { return HU4[i][j]; }
 };
 
+// 1/x: v_rcp_f64 seed + two Newton steps (full float64 accuracy for normal x; no denormal/inf fix-up,
+// inputs are validated time allocations and SPD pivots).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// exchange a double with the neighbouring lane (lane ^ 1) through DPP quad_perm:[1,0,3,2]
+__device__ __forceinline__ double swap_pair(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ constexpr double inv_fact(int k) {
     double f = 1.0;
     for (int j = 2; j <= k; ++j) f *= (double)j;
@@ -51,7 +68,7 @@ struct SegBlocks {
     double gw[ND];
     double gv[ND];
     __device__ __forceinline__ void build(double T) {
-        const double it = 1.0 / T;
+        const double it = fast_rcp(T);
         double ip[2 * R];  // ip[j] = T^-j
         ip[0] = 1.0;
 #pragma unroll
@@ -88,7 +105,7 @@ struct SmallLDL {
                 dj -= l[j][k] * w[k];
             }
             d[j] = dj;
-            dinv[j] = 1.0 / dj;
+            dinv[j] = fast_rcp(dj);
 #pragma unroll
             for (int i = j + 1; i < N; ++i) {
                 double s = S[i][j];

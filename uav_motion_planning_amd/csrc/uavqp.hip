@@ -220,6 +220,24 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
 
 }  // namespace uavqp
 
+#include "qp_twisted.h"
+
+namespace uavqp {
+// Specialised (R, M) instantiations of the register-resident kernel; everything else takes the generic one.
+typedef void (*twisted_fn)(BatchArgs);
+template <int R, int M>
+static twisted_fn twisted_ptr() { return &solve_twisted_kernel<R, M>; }
+static twisted_fn find_twisted(int r, int M) {
+#define UAVQP_CASE(RR, MM) if (r == RR && M == MM) return twisted_ptr<RR, MM>();
+    UAVQP_CASE(4, 2) UAVQP_CASE(4, 3) UAVQP_CASE(4, 4) UAVQP_CASE(4, 5) UAVQP_CASE(4, 6) UAVQP_CASE(4, 7)
+    UAVQP_CASE(4, 8) UAVQP_CASE(4, 9) UAVQP_CASE(4, 10) UAVQP_CASE(4, 12)
+    UAVQP_CASE(3, 2) UAVQP_CASE(3, 3) UAVQP_CASE(3, 4) UAVQP_CASE(3, 5) UAVQP_CASE(3, 6) UAVQP_CASE(3, 7)
+    UAVQP_CASE(3, 8) UAVQP_CASE(3, 10) UAVQP_CASE(3, 12) UAVQP_CASE(3, 16)
+#undef UAVQP_CASE
+    return nullptr;
+}
+}  // namespace uavqp
+
 // ===================================================================================================
 // C ABI
 // ===================================================================================================
@@ -344,6 +362,21 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     a.coeff = d_coeff_out;
     a.status = d_status_out;
 
+    if (uniform_segments > 0 && ctx->variant != 1) {
+        uavqp::twisted_fn fn = uavqp::find_twisted(r, uniform_segments);
+        if (fn) {
+            a.ws = nullptr;
+            const int n_tiles = (n_traj + 31) / 32;
+            int g = n_tiles < ctx->num_cus * 8 ? n_tiles : ctx->num_cus * 8;
+            hipLaunchKernelGGL(fn, dim3(g), dim3(64), 0, ctx->stream, a);
+            UAVQP_HIP(hipGetLastError());
+            return UAVQP_OK;
+        }
+        if (ctx->variant == 2) {
+            g_last_error = "variant 2 requested but no specialised kernel for this (r, segments)";
+            return UAVQP_ERR_INVALID_ARG;
+        }
+    }
     const int block = 64;
     int grid = (n_traj + block - 1) / block;
     const int max_grid = ctx->num_cus * 8;
