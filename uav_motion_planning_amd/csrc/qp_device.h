@@ -55,18 +55,17 @@ __device__ __forceinline__ constexpr double inv_fact(int k) {
 }
 
 // T-dependent blocks of one segment (ND = R-1 derivative unknowns per knot).
-//   A11: end/end block      T^(a+b+1-2R) W[a][b]          (symmetric)
-//   A00: start/start block  T^(a+b+1-2R) U[a][b]          (symmetric; U = (-1)^(a+b) W)
+//   A11: end/end block      T^(a+b+1-2R) W[a][b]          (symmetric, lower triangle stored)
+//   A00: start/start block  = (-1)^(a+b) A11[a][b]        (U = (-1)^(a+b) W: time-reversal symmetry)
 //   A01: start/end block   -T^(a+b+1-2R) V[a][b]
-//   gw, gv: position couplings T^(a+1-2R) W[a][0], T^(a+1-2R) V[a][0]
+//   gw : position coupling  T^(a+1-2R) W[a][0];   gv[a] = T^(a+1-2R) V[a][0] = (-1)^a gw[a]
+// Only A11 / A01 / gw are materialised; A00 and gv are sign patterns applied at the use sites.
 template <int R>
 struct SegBlocks {
     static constexpr int ND = R - 1;
     double A11[ND][ND];
-    double A00[ND][ND];
     double A01[ND][ND];
     double gw[ND];
-    double gv[ND];
     __device__ __forceinline__ void build(double T) {
         const double it = fast_rcp(T);
         double ip[2 * R];  // ip[j] = T^-j
@@ -78,14 +77,19 @@ struct SegBlocks {
 #pragma unroll
             for (int b = 1; b < R; ++b) {
                 const double p = ip[2 * R - 1 - a - b];
-                A11[a - 1][b - 1] = p * Tab<R>::W(a, b);
-                A00[a - 1][b - 1] = p * Tab<R>::U(a, b);
+                if (b <= a) A11[a - 1][b - 1] = p * Tab<R>::W(a, b);
                 A01[a - 1][b - 1] = -p * Tab<R>::V(a, b);
             }
             gw[a - 1] = ip[2 * R - 1 - a] * Tab<R>::W(a, 0);
-            gv[a - 1] = ip[2 * R - 1 - a] * Tab<R>::V(a, 0);
         }
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+            for (int b = a + 1; b < ND; ++b) A11[a][b] = A11[b][a];
     }
+    // (i, c) 0-based over derivative orders d = i+1, c+1
+    __device__ __forceinline__ double A00(int i, int c) const { return ((i + c) & 1) ? -A11[i][c] : A11[i][c]; }
+    __device__ __forceinline__ double gv(int i) const { return (i & 1) ? gw[i] : -gw[i]; }
 };
 
 // In-place LDL' of a small SPD matrix (only the lower triangle is read), then solves.

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -24,7 +25,11 @@ struct BatchArgs {
     const double* bc;
     double* coeff;
     int32_t* status;
-    double* ws;  // forward-sweep workspace (generic kernel)
+    double* ws;     // forward-sweep workspace (generic kernel)
+    double* dummy;  // 1 KiB sink for the predicated-off stores of the specialised kernel
+#ifdef UAVQP_PHASE_TIMING
+    long long* stamps;  // debug: s_memtime stamps of wave 0 (tools/ubench only)
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -96,9 +101,9 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
 #pragma unroll
             for (int i = 0; i < ND; ++i) {
 #pragma unroll
-                for (int j = 0; j < ND; ++j) S[i][j] = sa.A11[i][j] + sb.A00[i][j];
+                for (int j = 0; j < ND; ++j) S[i][j] = sa.A11[i][j] + sb.A00(i, j);
 #pragma unroll
-                for (int ax = 0; ax < 3; ++ax) z[i][ax] = sb.gv[i] * dpb[ax] - sa.gw[i] * dpa[ax];
+                for (int ax = 0; ax < 3; ++ax) z[i][ax] = sb.gv(i) * dpb[ax] - sa.gw[i] * dpa[ax];
             }
             if (k == 1) {
 #pragma unroll
@@ -226,9 +231,11 @@ namespace uavqp {
 // Specialised (R, M) instantiations of the register-resident kernel; everything else takes the generic one.
 typedef void (*twisted_fn)(BatchArgs);
 template <int R, int M>
-static twisted_fn twisted_ptr() { return &solve_twisted_kernel<R, M>; }
-static twisted_fn find_twisted(int r, int M) {
-#define UAVQP_CASE(RR, MM) if (r == RR && M == MM) return twisted_ptr<RR, MM>();
+static twisted_fn twisted_ptr(int tile) {
+    return tile == 16 ? &solve_twisted_kernel<R, M, 16> : &solve_twisted_kernel<R, M, 32>;
+}
+static twisted_fn find_twisted(int r, int M, int tile) {
+#define UAVQP_CASE(RR, MM) if (r == RR && M == MM) return twisted_ptr<RR, MM>(tile);
     UAVQP_CASE(4, 2) UAVQP_CASE(4, 3) UAVQP_CASE(4, 4) UAVQP_CASE(4, 5) UAVQP_CASE(4, 6) UAVQP_CASE(4, 7)
     UAVQP_CASE(4, 8) UAVQP_CASE(4, 9) UAVQP_CASE(4, 10) UAVQP_CASE(4, 12)
     UAVQP_CASE(3, 2) UAVQP_CASE(3, 3) UAVQP_CASE(3, 4) UAVQP_CASE(3, 5) UAVQP_CASE(3, 6) UAVQP_CASE(3, 7)
@@ -250,9 +257,11 @@ struct uavqp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int variant = 0;
+    int tile_override = 0;  // UAVQP_TILE=16|32 (tuning aid)
     int num_cus = 256;
     double* ws = nullptr;
     size_t ws_bytes = 0;
+    double* dummy = nullptr;
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -296,6 +305,17 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
         return UAVQP_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    e = hipMalloc((void**)&ctx->dummy, 4096);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+        (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return UAVQP_ERR_ALLOC;
+    }
+    if (const char* e = std::getenv("UAVQP_TILE")) {
+        const int t = std::atoi(e);
+        if (t == 16 || t == 32) ctx->tile_override = t;
+    }
     *out_ctx = ctx;
     return UAVQP_OK;
 }
@@ -305,6 +325,7 @@ extern "C" int uavqp_destroy(uavqp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->dummy) (void)hipFree(ctx->dummy);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -361,13 +382,19 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     a.bc = d_bc;
     a.coeff = d_coeff_out;
     a.status = d_status_out;
+    a.dummy = ctx->dummy;
 
     if (uniform_segments > 0 && ctx->variant != 1) {
-        uavqp::twisted_fn fn = uavqp::find_twisted(r, uniform_segments);
+        // small batches: half-wave tiles (16 trajectories) spread the launch over twice as many CUs --
+        // one CU moves only ~10 B/clk, so a 4096-trajectory batch needs all 256 of them
+        int tile = (n_traj <= 16 * ctx->num_cus) ? 16 : 32;
+        if (ctx->tile_override) tile = ctx->tile_override;
+        uavqp::twisted_fn fn = uavqp::find_twisted(r, uniform_segments, tile);
         if (fn) {
             a.ws = nullptr;
-            const int n_tiles = (n_traj + 31) / 32;
-            int g = n_tiles < ctx->num_cus * 8 ? n_tiles : ctx->num_cus * 8;
+            const int n_tiles = (n_traj + tile - 1) / tile;
+            const int max_wg = ctx->num_cus * 4;  // 1 wave / SIMD (register-resident state), persistent over tiles
+            int g = n_tiles < max_wg ? n_tiles : max_wg;
             hipLaunchKernelGGL(fn, dim3(g), dim3(64), 0, ctx->stream, a);
             UAVQP_HIP(hipGetLastError());
             return UAVQP_OK;
