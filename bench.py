@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="trajectories in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--data", default="astar", choices=["astar", "uniform"],
+                    help="astar: configs[1] generator; uniform: iid waypoints/times (tuning aid)")
     return ap.parse_args()
 
 
@@ -85,6 +87,11 @@ def main():
 
     r, M, B = args.order, args.segments, args.batch
     batch = W.uniform_batch(2, B, M, r, time_mode=args.time_mode, seed=W.SEED0 + 2 + 1000 * rank)
+    if args.data == "uniform":
+        rng = np.random.default_rng(1)
+        batch["waypoints"] = rng.uniform(-2, 2, size=batch["waypoints"].shape)
+        batch["times"] = rng.uniform(0.5, 2.0, size=batch["times"].shape)
+        batch["bc"] = np.zeros_like(batch["bc"])
     d_wp = torch.from_numpy(batch["waypoints"]).to(dev)
     d_T = torch.from_numpy(batch["times"]).to(dev)
     d_bc = torch.from_numpy(batch["bc"]).to(dev)

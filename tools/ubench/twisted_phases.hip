@@ -1,5 +1,7 @@
 // Phase-level cycle stamps of the twisted kernel (wave 0) + back-to-back launch timing.  Debug tool.
+#ifndef NO_STAMPS
 #define UAVQP_PHASE_TIMING 1
+#endif
 #ifndef TILE_
 #define TILE_ 32
 #endif
@@ -24,9 +26,12 @@ int main(int argc, char** argv) {
     hipMemcpy(dbc, bc.data(), bc.size() * 8, hipMemcpyHostToDevice);
     uavqp::BatchArgs a{};
     a.n_traj = B; a.uniform = M; a.max_segments = M; a.waypoints = dwp; a.times = dT; a.bc = dbc; a.coeff = dout; a.status = dst;
-    a.stamps = dstamps; hipMalloc(&a.dummy, 4096);
+    hipMalloc(&a.dummy, 4096);
+#ifdef UAVQP_PHASE_TIMING
+    a.stamps = dstamps;
+#endif
     const int n_tiles = (B + TILE_ - 1) / TILE_, grid = n_tiles < 1024 ? n_tiles : 1024;
-    hipStream_t s; hipStreamCreate(&s);
+    hipStream_t s; if (getenv("NB")) hipStreamCreateWithFlags(&s, hipStreamNonBlocking); else hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL((uavqp::solve_twisted_kernel<4, 8, TILE_>), dim3(grid), dim3(64), 0, s, a);
