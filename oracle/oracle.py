@@ -118,3 +118,64 @@ def residual(r, pos, bc_start, bc_end, T, coef):
     T, pT = _d(T)
     c, pc = _d(coef)
     return lib().oracle_residual(r, T.size, pp, pbs, pbe, pT, pc)
+
+
+# ------------------------------------------------------------------------------------------------
+# OSQP-faithful port (oracle/osqp_port.c)
+# ------------------------------------------------------------------------------------------------
+class PortSettings(ctypes.Structure):
+    _fields_ = [("rho", ctypes.c_double), ("sigma", ctypes.c_double), ("alpha", ctypes.c_double),
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("eps_prim_inf", ctypes.c_double),
+                ("eps_dual_inf", ctypes.c_double), ("adaptive_rho_tolerance", ctypes.c_double),
+                ("max_iter", ctypes.c_int), ("scaling", ctypes.c_int), ("adaptive_rho", ctypes.c_int),
+                ("adaptive_rho_interval", ctypes.c_int), ("check_termination", ctypes.c_int)]
+
+
+class PortInfo(ctypes.Structure):
+    _fields_ = [("iters", ctypes.c_int), ("status", ctypes.c_int), ("rho_updates", ctypes.c_int),
+                ("pri_res", ctypes.c_double), ("dua_res", ctypes.c_double), ("rho", ctypes.c_double)]
+
+
+PORT_SOLVED = 1
+PORT_MAX_ITER_REACHED = -2
+
+
+def osqp_settings(**overrides):
+    """OSQP v0.6.2 defaults with the reference's overrides (minimum_control.cpp:160-162)."""
+    s = PortSettings()
+    lib().osqp_port_default_settings(ctypes.byref(s))
+    for k, v in overrides.items():
+        setattr(s, k, v)
+    return s
+
+
+def osqp_solve_axis(r, pos, bc_start, bc_end, T, settings=None):
+    pos, pp = _d(pos)
+    bs, pbs = _d(bc_start)
+    be, pbe = _d(bc_end)
+    T, pT = _d(T)
+    M = T.size
+    out = np.zeros(2 * r * M)
+    info = PortInfo()
+    lib().osqp_port_solve_axis(r, M, pp, pbs, pbe, pT, ctypes.byref(settings) if settings is not None else None,
+                               out.ctypes.data_as(_dp), ctypes.byref(info))
+    return out, info
+
+
+def osqp_solve_batch(r, seg_offsets, waypoints, times, bc, settings=None, threads=1):
+    """Batch in the C-ABI layout: 3 x (setup + solve + cleanup) per trajectory.  Returns (coef, status, iters)."""
+    so, pso = _i(seg_offsets)
+    wp, pwp = _d(waypoints)
+    tt, ptt = _d(times)
+    bcv, pbc = _d(bc)
+    n_traj = so.size - 1
+    out = np.zeros(3 * 2 * r * int(so[-1]))
+    status = np.zeros(n_traj, dtype=np.int32)
+    iters = np.zeros(n_traj, dtype=np.int32)
+    rc = lib().osqp_port_solve_batch(r, n_traj, pso, pwp, ptt, pbc,
+                                     ctypes.byref(settings) if settings is not None else None,
+                                     out.ctypes.data_as(_dp), status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip),
+                                     int(threads))
+    if rc != 0:
+        raise RuntimeError(f"osqp_port_solve_batch rc={rc}")
+    return out, status, iters

@@ -1,0 +1,58 @@
+// Mirror of the reference's src/planner/test/src/test_qpsolve.cpp:4-21 (minus ROS init/spin) against the
+// drop-in MinimumControl, plus what the reference test lacks: an expected answer.
+// Also exercises the TrajOptimizer batch facade on the same input.  Exit code 0 = parity.
+#include <traj_optimization/minimum_control.h>
+
+#include <cmath>
+#include <cstdio>
+
+#include "../../uav_motion_planning_amd/cpp/traj_optimizer.h"
+
+int main(int argc, char** argv) {
+  traj_optimization::MinimumControl::Ptr min_jerk_ptr = std::make_shared<traj_optimization::MinimumControl>();
+
+  Eigen::VectorXd pos_1d(4);
+  pos_1d << 1.0, 2.0, 3.0, 4.0;
+  Eigen::Vector2d bound_vel;
+  bound_vel << 0.0, 0.0;
+  Eigen::Vector2d bound_acc;
+  bound_acc << 0.0, 0.0;
+  Eigen::VectorXd time_vec(3);
+  time_vec << 1.0, 1.0, 1.0;
+  if (!min_jerk_ptr->solve(pos_1d, bound_vel, bound_acc, time_vec)) { std::printf("solve() returned false\n"); return 1; }
+
+  const double exp[18] = {1, 0, 0, 190.0 / 51, -65.0 / 17, 56.0 / 51, 2, 70.0 / 51, -40.0 / 51, -10.0 / 17, 5.0 / 3, -2.0 / 3,
+                          3, 70.0 / 51, 40.0 / 51, -10.0 / 17, -5.0 / 3, 56.0 / 51};
+  Eigen::VectorXd c = min_jerk_ptr->getCoef1d();
+  if (c.size() != 18) { std::printf("wrong size %ld\n", (long)c.size()); return 2; }
+  double worst = 0;
+  for (int i = 0; i < 18; ++i) worst = std::fmax(worst, std::fabs(c[i] - exp[i]));
+  std::printf("MinimumControl KAT max abs err %.3e\n", worst);
+  if (!(worst < 1e-12)) return 3;
+
+  // malformed call: clean failure, previous coefficients kept (minimum_control.cpp:173-184 semantics)
+  Eigen::VectorXd bad_t(2);
+  bad_t << 1.0, 1.0;
+  if (min_jerk_ptr->solve(pos_1d, bound_vel, bound_acc, bad_t)) return 4;
+  if (std::fabs(min_jerk_ptr->getCoef1d()[3] - exp[3]) > 1e-12) return 5;
+  min_jerk_ptr->reset();
+  if (min_jerk_ptr->getCoef1d()[3] != 0.0) return 6;
+
+  // batch facade, min-jerk order, same trajectory on x; y = 2x, z = -x
+  traj_optimization::TrajOptimizer opt(3);
+  double xyz[12];
+  for (int k = 0; k < 4; ++k) { xyz[3 * k] = k + 1.0; xyz[3 * k + 1] = 2.0 * (k + 1); xyz[3 * k + 2] = -(k + 1.0); }
+  const int32_t off[2] = {0, 4};
+  const double T[3] = {1.0, 1.0, 1.0};
+  opt.setWaypoints(xyz, off, 1);
+  opt.setTimeAllocation(T);
+  if (!opt.solve()) return 7;
+  worst = 0;
+  for (int i = 0; i < 18; ++i) {
+    worst = std::fmax(worst, std::fabs(opt.getPolyCoeff(0, 0)[i] - exp[i]));
+    worst = std::fmax(worst, std::fabs(opt.getPolyCoeff(0, 1)[i] - 2 * exp[i]));
+    worst = std::fmax(worst, std::fabs(opt.getPolyCoeff(0, 2)[i] + exp[i]));
+  }
+  std::printf("TrajOptimizer KAT max abs err %.3e\n", worst);
+  return worst < 1e-11 ? 0 : 8;
+}

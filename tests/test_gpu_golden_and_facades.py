@@ -1,0 +1,107 @@
+"""-m gpu: committed exact-rational fixtures through the C ABI, the host-side mirrors of the reference
+interface (Python MinimumControl / TrajOptimizer, C++ MinimumControl / TrajOptimizer), device-pointer
+entry point with torch buffers and an explicit stream."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import uav_motion_planning_amd as U
+from uav_motion_planning_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "kkt_exact.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_golden_fixture_through_c_abi(gpu_ctx, case, variant):
+    """Tolerance: 1e-10 relative to max|coef| per axis (float64 direct solve vs exact rationals);
+    the north star's budget is 1e-5."""
+    r, M = case["r"], case["M"]
+    gpu_ctx.set_variant(variant)
+    # replicate into a small batch so that partial tiles and both lanes of a pair are exercised
+    n = 5
+    wp = np.tile(np.array(case["waypoints"])[None], (n, 1, 1))
+    T = np.tile(np.array(case["times"])[None], (n, 1))
+    bc = np.tile(np.array(case["bc"])[None], (n, 1, 1, 1))
+    got, st = gpu_ctx.solve_batch_host(r, None, wp, T, bc, uniform_segments=M)
+    gpu_ctx.set_variant(0)
+    assert np.all(st == U.UAVQP_SOLVED)
+    got = got.reshape(n, 3, 2 * r * M)
+    ref = np.array(case["coef"])
+    for b in range(n):
+        for ax in range(3):
+            assert np.max(np.abs(got[b, ax] - ref[ax])) <= 1e-10 * max(1.0, np.max(np.abs(ref[ax])))
+
+
+def test_python_minimum_control_mirror(oracle):
+    """Same call sequence as test_minimum_jerk.cpp:75-78,100-103,125-128,171-172: three axis solves on one object."""
+    opt = U.MinimumControl()
+    b = W.uniform_batch(2, 1, 6, 3, time_mode="distance")
+    wp, T, bc = b["waypoints"][0], b["times"][0], b["bc"][0]
+    for ax in range(3):
+        assert opt.solve(wp[:, ax], [bc[0, 0, ax], bc[1, 0, ax]], [bc[0, 1, ax], bc[1, 1, ax]], T) is True
+        c = opt.getCoef1d()
+        ref = oracle.solve_exact(3, wp[:, ax], bc[0, :, ax], bc[1, :, ax], T)
+        assert c.shape == (36,) and np.max(np.abs(c - ref)) < 1e-9 * np.max(np.abs(ref))
+    prev = opt.getCoef1d()
+    assert opt.solve(wp[:, 0], [0, 0], [0, 0], T[:-1]) is False          # size mismatch -> false, result kept
+    assert np.array_equal(opt.getCoef1d(), prev)
+    assert opt.solve(wp[:, 0], [0, 0], [0, 0], -T) is False               # invalid time allocation -> "solve failed"
+    opt.reset()
+    assert np.all(opt.getCoef1d() == 0)
+
+
+def test_python_traj_optimizer_batch_facade(oracle):
+    b = W.ragged_batch(4, 40, 4, m_lo=2, m_hi=12)
+    so = b["seg_offsets"]
+    opt = U.TrajOptimizer(order=4)
+    opt.setWaypoints(b["waypoints"], wp_offsets=so + np.arange(so.size))
+    opt.setTimeAllocation(b["times"])
+    opt.setBoundary(b["bc"])
+    assert opt.solve() is True
+    ref, _ = oracle.solve_exact_batch(4, so, b["waypoints"], b["times"], b["bc"])
+    got = opt.getPolyCoeff()
+    assert np.max(np.abs(got - ref)) < 1e-8 * np.max(np.abs(ref))
+    k = 7
+    per = opt.getPolyCoeff(k)
+    assert per.shape == (3, so[k + 1] - so[k], 8)
+    assert np.array_equal(per.ravel(), got[24 * so[k]:24 * so[k + 1]])
+
+
+def test_cpp_facades_mirror_of_test_qpsolve():
+    """Compiles tests/cpp/test_qpsolve_mirror.cpp (the reference's test_qpsolve.cpp body + expected values)
+    against the drop-in header and runs it on the GPU."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_qpsolve_mirror")
+    pkg = os.path.join(ROOT, "uav_motion_planning_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", f"-I{pkg}/cpp", f"-I{pkg}/cpp/eigen_shim",
+                           os.path.join(ROOT, "tests", "cpp", "test_qpsolve_mirror.cpp"), f"{pkg}/cpp/minimum_control.cpp",
+                           f"-L{pkg}", "-luavqp", f"-Wl,-rpath,{pkg}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "MinimumControl KAT" in out.stdout and "TrajOptimizer KAT" in out.stdout
+
+
+def test_device_pointer_entry_with_torch_stream(oracle):
+    import torch
+    b = W.uniform_batch(2, 300, 8, 4, time_mode="distance")
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(device=dev)
+    with U.Context(0) as ctx, torch.cuda.stream(s):
+        ctx.set_stream(s.cuda_stream)
+        d_wp = torch.from_numpy(b["waypoints"]).to(dev)
+        d_T = torch.from_numpy(b["times"]).to(dev)
+        d_bc = torch.from_numpy(b["bc"]).to(dev)
+        d_out = torch.zeros(300 * 192, dtype=torch.float64, device=dev)
+        d_st = torch.zeros(300, dtype=torch.int32, device=dev)
+        s.synchronize()
+        ctx.solve_batch_device(4, 300, 8, 8, None, d_wp, d_T, d_bc, d_out, d_st)
+        ctx.synchronize()
+        got = d_out.cpu().numpy()
+        assert bool((d_st == U.UAVQP_SOLVED).all())
+    ref, _ = oracle.solve_exact_batch(4, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+    assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))

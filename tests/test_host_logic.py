@@ -1,0 +1,61 @@
+"""CPU: host-side logic that needs no device -- workload generators, facade bookkeeping, sharding."""
+import numpy as np
+
+from uav_motion_planning_amd import TrajOptimizer
+from uav_motion_planning_amd import distributed as D
+from uav_motion_planning_amd import workloads as W
+
+
+def test_algorithmic_bytes_match_survey_8d():
+    assert W.algorithmic_bytes(4, 8) == 1960      # config 2: 424 in + 1536 out
+    assert W.algorithmic_bytes(4, 7) == 392 + 1344  # config 1 (SURVEY quotes 376 in: arithmetic slip, 8*(24+7+18) = 392)
+    assert W.algorithmic_bytes(3, 16) == 632 + 2304
+
+
+def test_uniform_batch_is_seeded_and_inside_the_map():
+    a = W.uniform_batch(2, 64, 8, 4, time_mode="distance")
+    b = W.uniform_batch(2, 64, 8, 4, time_mode="distance")
+    assert np.array_equal(a["waypoints"], b["waypoints"]) and np.array_equal(a["times"], b["times"])
+    wp = a["waypoints"]
+    assert wp.shape == (64, 9, 3) and a["bc"].shape == (64, 2, 3, 3)
+    assert np.all(wp >= W.BOX_LO - 1e-9) and np.all(wp <= W.BOX_HI + 1e-9)
+    step = np.linalg.norm(np.diff(wp, axis=1), axis=2)
+    assert step.max() <= 2.0 + 1e-9
+    assert np.all(a["times"] >= 0.3) and np.all(W.uniform_batch(2, 4, 8, 4)["times"] == 1.0)  # reference: 1.0 s
+    assert np.all(a["bc"][:, 1] == 0) and np.all(a["bc"][:, 0, 1:] == 0)
+
+
+def test_ragged_batch_layout():
+    b = W.ragged_batch(4, 50, 4)
+    so = b["seg_offsets"]
+    Ms = np.diff(so)
+    assert Ms.min() >= 4 and Ms.max() <= 24 and so[0] == 0
+    assert b["waypoints"].shape == (so[-1] + 50, 3) and b["times"].shape == (so[-1],)
+    for k in range(50):
+        t = b["times"][so[k]:so[k + 1]]
+        assert np.allclose(t[:-1], 0.3) and 0.5 <= t[-1] <= 2.0
+
+
+def test_traj_optimizer_offset_bookkeeping():
+    opt = TrajOptimizer(order=4)
+    xyz = np.zeros((9 + 5 + 3, 3))
+    opt.setWaypoints(xyz, wp_offsets=[0, 9, 14, 17])
+    assert list(opt._so) == [0, 8, 12, 14]
+    opt.setWaypoints(np.zeros((18, 3)), n_waypoints=9)
+    assert list(opt._so) == [0, 8, 16]
+    assert opt.solve() is False            # no time allocation yet: refuses before touching the device
+    opt.setTimeAllocation(np.ones(5))
+    assert opt.solve() is False            # wrong length
+
+
+def test_shard_bounds():
+    assert D.shard_bounds(4096, 8) == [512 * g for g in range(9)]
+    assert D.shard_bounds(10, 4) == [0, 2, 5, 7, 10]
+    b = W.ragged_batch(4, 200, 4)
+    bounds = D.shard_bounds_ragged(b["seg_offsets"], 8)
+    assert bounds[0] == 0 and bounds[-1] == 200 and all(x <= y for x, y in zip(bounds, bounds[1:]))
+    work = [b["seg_offsets"][hi] - b["seg_offsets"][lo] for lo, hi in zip(bounds, bounds[1:])]
+    assert max(work) - min(work) <= 2 * 24
+    sl = D.local_slice(b, bounds[2], bounds[3])
+    assert sl["seg_offsets"][0] == 0 and sl["times"].size == sl["seg_offsets"][-1]
+    assert sl["waypoints"].shape[0] == sl["seg_offsets"][-1] + (bounds[3] - bounds[2])

@@ -120,7 +120,8 @@ class MinimumControl:
     def __init__(self, order=3, device=0):
         assert order in (3, 4)
         self._r = order
-        self._ctx = Context(device)
+        self._device = device
+        self._ctx = None  # created on first solve (the reference builds its OSQP workspace in solve(), too)
         self._coef_1d = np.zeros(0)
 
     def solve(self, pos_1d, bound_vel, bound_acc, time_vec, bound_jerk=None):
@@ -130,6 +131,8 @@ class MinimumControl:
         if pos.ndim != 1 or tv.ndim != 1 or tv.size < 1 or pos.size != tv.size + 1:
             print("solver init failed!")
             return False
+        if self._ctx is None:
+            self._ctx = Context(self._device)  # raises UavqpError without libuavqp.so / without a GPU
         rc, st, coef = self._ctx.solve_axis_host(self._r, pos, bound_vel, bound_acc, tv, bound_jerk)
         if rc != _lib.UAVQP_OK:
             print("solver init failed!")
@@ -162,7 +165,8 @@ class TrajOptimizer:
     def __init__(self, order=4, device=0):
         assert order in (3, 4)
         self._r = order
-        self._ctx = Context(device)
+        self._device = device
+        self._ctx = None
         self._wp = self._T = self._bc = self._so = None
         self._coef = np.zeros(0)
         self.status = np.zeros(0, dtype=np.int32)
@@ -191,11 +195,9 @@ class TrajOptimizer:
         if self._T.size != int(self._so[-1]):
             return False
         bc = self._bc if self._bc is not None else np.zeros((n_traj, 2, self._r - 1, 3))
-        try:
-            self._coef, self.status = self._ctx.solve_batch_host(self._r, self._so, self._wp, self._T, bc)
-        except _lib.UavqpError as e:
-            print(f"solver init failed! ({e})")
-            return False
+        if self._ctx is None:
+            self._ctx = Context(self._device)  # raises UavqpError without libuavqp.so / without a GPU
+        self._coef, self.status = self._ctx.solve_batch_host(self._r, self._so, self._wp, self._T, bc)
         return bool(np.all(self.status == _lib.UAVQP_SOLVED))
 
     def getPolyCoeff(self, traj=None):
