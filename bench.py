@@ -41,28 +41,75 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="trajectories in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child run under rocprofv3: kernels only
     ap.add_argument("--data", default="astar", choices=["astar", "uniform"],
                     help="astar: configs[1] generator; uniform: iid waypoints/times (tuning aid)")
     return ap.parse_args()
 
 
 def cpu_baseline(batch, r, n_sample):
-    """OSQP-faithful CPU restatement (oracle/osqp_port.c) timed on this host: one full
-    setup+solve+cleanup per axis, exactly the reference's call pattern (test_minimum_jerk.cpp:75,100,125)."""
+    """OSQP-faithful CPU restatement (oracle/osqp_port.c) timed on this host's cores: one full
+    setup+solve+cleanup per axis, exactly the reference's call pattern (test_minimum_jerk.cpp:75,100,125;
+    minimum_control.cpp:164-190), reference settings, stdout dumps excluded.  The reference itself cannot
+    be built (OSQP / osqp-eigen / Eigen / ROS absent), hence kind = "port"."""
     from oracle import oracle
     oracle.build()
-    if not hasattr(oracle, "osqp_solve_batch"):
-        return None
     n = min(n_sample, batch["waypoints"].shape[0])
     M = batch["M"]
     so = batch["seg_offsets"][: n + 1]
+    args = (r, so, batch["waypoints"][:n], batch["times"][:n], batch["bc"][:n])
     t0 = time.perf_counter()
-    oracle.osqp_solve_batch(r, so, batch["waypoints"][:n], batch["times"][:n], batch["bc"][:n], threads=1)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} trajectories of the same batch (M={M}, r={r}), OSQP-port with the reference's "
-                      f"settings, 3 setup+solve per trajectory, {dt:.2f} s of CPU work",
-            "host_cores_available": os.cpu_count()}
+    _, st, iters = oracle.osqp_solve_batch(*args, threads=1)
+    dt1 = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    oracle.osqp_solve_batch(*args, threads=cores)
+    dtn = time.perf_counter() - t0
+    return {"value": n / dt1, "unit": "trajectories/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} trajectories of the same batch (M={M}, r={r}); OSQP-port, reference settings "
+                      f"(eps 1e-3, max_iter 1000), 3 x (setup+solve+cleanup) per trajectory; {dt1:.2f} s on 1 core; "
+                      f"median {int(np.median(iters))} ADMM iterations, {int((st == 1).sum())}/{n} reported solved",
+            "all_cores": {"value": n / dtn, "cores": cores}}
+
+
+def measure_traffic(args):
+    """HBM bytes per launch of the solve kernel from the PMC counters, as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes (TCC has 4 slots: 3 + 2 do not fit), kernel-trace
+    only; both report KiB; on gfx950 FETCH_SIZE counts exactly half of a 16-B-per-lane coalesced read stream
+    (128-B requests tallied as 64 B) -> doubled; WRITE_SIZE calibrated 1.000 on a known 1.61 GB write
+    (tools/ubench/write_patterns).  Returns None when rocprofv3 is unavailable or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="uavqp_pmc_", dir="/tmp")
+            cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--inner", "--steps", "10", "--warmup", "2",
+                   "--batch", str(args.batch), "--segments", str(args.segments), "--order", str(args.order),
+                   "--time-mode", args.time_mode, "--variant", str(args.variant)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "uavqp::solve" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            shutil.rmtree(d, ignore_errors=True)
+            if not vals:
+                return None
+            out[ctr] = float(np.mean(vals)) * 1024.0
+        return {"bytes": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "fetch_bytes_corrected": 2.0 * out["FETCH_SIZE"],
+                "write_bytes": out["WRITE_SIZE"]}
+    except Exception:
+        return None
 
 
 def main():
@@ -160,11 +207,14 @@ def main():
                   "own_shard_intact": ok,
                   "value_with_gather": world * B / (dt / args.steps + g_ms * 1e-3)}
 
+    if args.inner:
+        return
     if rank == 0:
         bytes_per_traj = W.algorithmic_bytes(r, M)
         achieved = B * bytes_per_traj / (kernel_ms * 1e-3) / 1e9
         n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 4096
         cpu = cpu_baseline(batch, r, n_cpu) if (n_cpu > 0 and world == 1) else None
+        traffic = measure_traffic(args) if (world == 1 and not args.no_traffic) else None
         out = {
             "metric": "trajectories/sec (8-seg 7th-order min-snap, 3-axis)",
             "value": world * B * args.steps / dt,
@@ -184,7 +234,8 @@ def main():
                        "batch_per_gpu": B, "segments": M, "r": r, "variant": args.variant,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_detail": traffic, "algorithmic_bytes_per_launch": B * bytes_per_traj,
                          "kernel_ms": kernel_ms, "per_launch_event_ms": per_launch_ms,
                          "region_ms_per_step": region_ms / args.steps,
                          "algorithmic_bytes_per_trajectory": bytes_per_traj},
