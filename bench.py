@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--time-mode", default="distance", choices=["reference", "distance", "wide"])
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="trajectories in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="independent HIP streams the steps are issued on round-robin (0 = auto = 1; 2 pipelines consecutive steps: "
+                         "+40 % trajectories/s at the 4096 batch, but each kernel then shares the GPU and its own duration grows)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child run under rocprofv3: kernels only
@@ -94,7 +97,7 @@ def measure_traffic(args):
             cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--inner", "--steps", "10", "--warmup", "2",
                    "--batch", str(args.batch), "--segments", str(args.segments), "--order", str(args.order),
-                   "--time-mode", args.time_mode, "--variant", str(args.variant)]
+                   "--time-mode", args.time_mode, "--variant", str(args.variant), "--streams", str(args.streams)]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             vals = []
@@ -142,17 +145,24 @@ def main():
     d_wp = torch.from_numpy(batch["waypoints"]).to(dev)
     d_T = torch.from_numpy(batch["times"]).to(dev)
     d_bc = torch.from_numpy(batch["bc"]).to(dev)
-    d_out = torch.zeros(B * 3 * M * 2 * r, dtype=torch.float64, device=dev)
     d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    S = args.streams if args.streams > 0 else 1
+    # one ctx + stream + output buffer per pipeline slot: step i runs on slot i % S.  Steps are independent
+    # batches, so consecutive steps may overlap on the GPU (kernel boundary of one hides under the next).
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    ctxs, d_outs = [], []
+    for st_ in streams:
+        c = U.Context(local_rank)
+        c.set_stream(st_.cuda_stream)
+        c.set_variant(args.variant)
+        ctxs.append(c)
+        d_outs.append(torch.zeros(B * 3 * M * 2 * r, dtype=torch.float64, device=dev))
+    d_out = d_outs[0]
+    stream = streams[0]
 
-    ctx = U.Context(local_rank)
-    stream = torch.cuda.Stream(device=dev)  # explicit side stream: its handle is non-null, events see the kernels
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.set_variant(args.variant)
-
-    def step():
-        ctx.solve_batch_device(r, B, M, M, None, d_wp, d_T, d_bc, d_out, d_st)
+    def step(i=0):
+        k = i % S
+        ctxs[k].solve_batch_device(r, B, M, M, None, d_wp, d_T, d_bc, d_outs[k], d_st)
 
     def fence():
         torch.cuda.synchronize()
@@ -160,34 +170,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
     t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
+    for k in range(S):
+        ev0[k].record(streams[k])
+    for i in range(args.steps):
+        step(i)
+    for k in range(S):
+        ev1[k].record(streams[k])
     fence()
     dt = time.perf_counter() - t0
-    region_ms = ev0.elapsed_time(ev1)
+    # average time one launch occupies its stream (kernel + boundary), from the events of the timed region
+    region_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) / max(1, len(range(k, args.steps, S))) for k in range(S)]))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert int((d_st == U.UAVQP_SOLVED).sum().item()) == B, "some trajectories were not solved"
 
-    # per-launch kernel duration: HIP events bracketing each launch on the launch stream (post-pass)
+    # per-launch kernel duration: HIP events bracketing each launch on its launch stream (post-pass, same
+    # round-robin issue pattern as the timed region)
     n_ev = min(args.steps, 200)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    for a, b in evs:
-        a.record(stream)
-        step()
-        b.record(stream)
+    for i, (a, b) in enumerate(evs):
+        a.record(streams[i % S])
+        step(i)
+        b.record(streams[i % S])
     torch.cuda.synchronize()
     per_launch_ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
-    kernel_ms = min(per_launch_ms, region_ms / args.steps)
+    kernel_ms = min(per_launch_ms, region_ms)
 
     gather = None
     if world > 1 and not args.no_allgather:
@@ -231,13 +246,13 @@ def main():
             "config": {"workload": f"configs[1]: batch of {B} independent {M}-segment order-{2 * r - 1} "
                                    f"(r={r}) 3-axis trajectories per GPU, synthetic A*-like waypoints, "
                                    f"time allocation '{args.time_mode}'",
-                       "batch_per_gpu": B, "segments": M, "r": r, "variant": args.variant,
+                       "batch_per_gpu": B, "segments": M, "r": r, "variant": args.variant, "streams": S,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
                          "traffic_detail": traffic, "algorithmic_bytes_per_launch": B * bytes_per_traj,
                          "kernel_ms": kernel_ms, "per_launch_event_ms": per_launch_ms,
-                         "region_ms_per_step": region_ms / args.steps,
+                         "stream_ms_per_launch": region_ms,
                          "algorithmic_bytes_per_trajectory": bytes_per_traj},
             "cpu_baseline": cpu,
         }

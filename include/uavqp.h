@@ -78,7 +78,9 @@ int uavqp_set_stream(uavqp_ctx* ctx, void* hip_stream);
 int uavqp_synchronize(uavqp_ctx* ctx);
 
 /* Kernel variant selection: 0 = auto, 1 = generic lane-per-trajectory kernel, 2 = register-resident
- * specialised kernel (uniform batches only).  For benchmarking/tests; results are identical. */
+ * specialised kernel (uniform batches only, tile shape chosen by batch size); 8 / 16 / 32 = specialised
+ * kernel with that many trajectories per wave (8: one lane pair per axis, latency shape; 16 / 32: one
+ * lane pair per trajectory).  For benchmarking/tests; results agree to rounding. */
 int uavqp_set_variant(uavqp_ctx* ctx, int variant);
 
 /* Batched solve, DEVICE pointers, asynchronous on the ctx stream.
@@ -105,6 +107,30 @@ int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
 int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const double* pos_1d, const double* bound_vel,
                           const double* bound_acc, const double* bound_jerk, const double* time_vec,
                           double* coef_1d, int32_t* status_out);
+
+/* Batched evaluation of solved trajectories on a uniform time grid.
+ * Replaces, for a whole batch, PolyTraj::evaluatePos / evaluateVel / evaluateAcc
+ * (src/planner/traj_utils/include/traj_utils/poly_traj.hpp:74-168) as driven by poly_traj_server's
+ * 100 Hz timer (traj_server/src/poly_traj_server.cpp:33-37) and PolyTraj::getTraj (poly_traj.hpp:175-187),
+ * and the caller-side sampling loop of test_minimum_jerk.cpp:79-92.
+ *   t_s = t0 + s*dt, s = 0..n_samples-1, is trajectory-global time; the segment is found with the
+ *   reference's rule (walk while t > T_idx + 1e-4, subtracting; past the end clamp to the last segment's
+ *   end, poly_traj.hpp:77-88).
+ *   what: bit 0 position, bit 1 velocity, bit 2 acceleration; K = popcount(what) outputs per sample.
+ *   d_out [n_traj][n_samples][K][3] float64 (pos, vel, acc order; xyz interleaved = Eigen::Vector3d).
+ * d_coeff / d_times / d_seg_offsets: the arrays of uavqp_solve_batch_device.  Asynchronous on the ctx stream. */
+int uavqp_eval_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                            const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
+                            int what, double* d_out);
+
+/* hipGraph capture of a launch-bound inner loop: everything enqueued on the ctx stream between
+ * uavqp_capture_begin and uavqp_capture_end (any number of uavqp_solve_batch_device calls with their
+ * workspaces already sized by one eager call) becomes one executable graph; uavqp_graph_launch replays
+ * it on the ctx stream.  No reference counterpart (the reference has no device queue). */
+int uavqp_capture_begin(uavqp_ctx* ctx);
+int uavqp_capture_end(uavqp_ctx* ctx, void** out_graph_exec);
+int uavqp_graph_launch(uavqp_ctx* ctx, void* graph_exec);
+int uavqp_graph_destroy(uavqp_ctx* ctx, void* graph_exec);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ _ip = ctypes.POINTER(ctypes.c_int)
 
 def build(force=False):
     """Compile the oracle with gcc (seconds).  Never touches /root/reference."""
-    srcs = [os.path.join(_HERE, f) for f in ("qp_oracle.c", "osqp_port.c") if os.path.exists(os.path.join(_HERE, f))]
+    srcs = [os.path.join(_HERE, f) for f in ("qp_oracle.c", "osqp_port.c", "poly_eval.c") if os.path.exists(os.path.join(_HERE, f))]
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
@@ -179,3 +179,13 @@ def osqp_solve_batch(r, seg_offsets, waypoints, times, bc, settings=None, thread
     if rc != 0:
         raise RuntimeError(f"osqp_port_solve_batch rc={rc}")
     return out, status, iters
+
+
+def poly_eval(nc, times, coef_traj, t, what=7):
+    """Reference PolyTraj::evaluate{Pos,Vel,Acc}(t) for one trajectory ([axis][seg][nc] coefficients)."""
+    T, pT = _d(times)
+    c, pc = _d(coef_traj)
+    K = bin(what & 7).count("1")
+    out = np.zeros(3 * K)
+    lib().oracle_poly_eval(nc, T.size, pT, pc, ctypes.c_double(t), what, out.ctypes.data_as(_dp))
+    return out.reshape(K, 3)

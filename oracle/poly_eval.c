@@ -1,0 +1,35 @@
+/*
+ * poly_eval.c -- CPU restatement of the reference's trajectory evaluator.  TEST INFRASTRUCTURE ONLY.
+ * Follows src/planner/traj_utils/include/traj_utils/poly_traj.hpp:
+ *   segment search   :77-88 (same loop in evaluateVel :109-120, evaluateAcc :141-152)
+ *   evaluatePos      :90-103   p = sum_i c_i t^i
+ *   evaluateVel      :122-135  v = sum_i (i+1) c_{i+1} t^i
+ *   evaluateAcc      :154-167  a = sum_i (i+2)(i+1) c_{i+2} t^i
+ * with the power vector built by repeated multiplication (tv[i] = tv[i-1]*t) and a plain dot product,
+ * as the reference does.  PARITY UNPINNED: the reference has no recorded outputs for it either; the
+ * header needs Eigen (absent), so it is restated, not compiled.
+ */
+#include <stddef.h>
+
+/* coef: one trajectory in the C-ABI layout [axis][segment][nc]; out[3*K]: (pos, vel, acc selected by what) x xyz */
+void oracle_poly_eval(int nc, int M, const double* times, const double* coef, double t, int what, double* out) {
+    int idx = 0;
+    while (idx < M && t > times[idx] + 1e-4) { t -= times[idx]; idx++; }   /* :77-81 (bounds check first: no OOB read) */
+    if (idx == M) { idx--; t = times[idx]; }                                /* :83-87 */
+    int k = 0;
+    for (int d = 0; d < 3; ++d) {
+        if (!((what >> d) & 1)) continue;
+        for (int ax = 0; ax < 3; ++ax) {
+            const double* c = coef + ((size_t)ax * M + idx) * nc;
+            double tv = 1.0, acc = 0.0;
+            for (int i = 0; i < nc - d; ++i) {
+                double f = 1.0;
+                for (int q = 0; q < d; ++q) f *= (double)(i + d - q);
+                if (i > 0) tv *= t;
+                acc += tv * (f * c[i + d]);
+            }
+            out[3 * k + ax] = acc;
+        }
+        ++k;
+    }
+}

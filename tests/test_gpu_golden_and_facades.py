@@ -17,11 +17,13 @@ CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "kkt_exact.json")))
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 8])
 def test_golden_fixture_through_c_abi(gpu_ctx, case, variant):
     """Tolerance: 1e-10 relative to max|coef| per axis (float64 direct solve vs exact rationals);
     the north star's budget is 1e-5."""
     r, M = case["r"], case["M"]
+    if variant >= 8 and (M < 2 or (r == 4 and M > 12) or M == 11):
+        pytest.skip("no specialised instantiation for this M")
     gpu_ctx.set_variant(variant)
     # replicate into a small batch so that partial tiles and both lanes of a pair are exercised
     n = 5
@@ -105,3 +107,34 @@ def test_device_pointer_entry_with_torch_stream(oracle):
         assert bool((d_st == U.UAVQP_SOLVED).all())
     ref, _ = oracle.solve_exact_batch(4, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
     assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("r,ragged", [(3, False), (4, False), (4, True)])
+def test_batched_evaluation_matches_polytraj_restatement(oracle, r, ragged):
+    """N1: uavqp_eval_batch_device vs the restated PolyTraj::evaluatePos/Vel/Acc (poly_traj.hpp:74-168) on the
+    100 Hz-style grid of poly_traj_server.cpp:33-37, including samples past the end (clamped) and the 1e-4
+    segment-switch slack.  Tolerance 1e-12 relative: same float64 polynomial, Horner vs power-vector order."""
+    import torch
+    n, ns, dt = 37, 173, 0.05
+    b = W.ragged_batch(4, n, r, m_lo=1, m_hi=9) if ragged else W.uniform_batch(5, n, 6, r, time_mode="distance")
+    so = b["seg_offsets"]
+    dev = torch.device("cuda", 0)
+    with U.Context(0) as ctx:
+        coef, st = ctx.solve_batch_host(r, so, np.asarray(b["waypoints"]).reshape(-1, 3), np.asarray(b["times"]).reshape(-1), b["bc"])
+        assert np.all(st == U.UAVQP_SOLVED)
+        d_coef = torch.from_numpy(coef).to(dev)
+        d_T = torch.from_numpy(np.asarray(b["times"]).reshape(-1).copy()).to(dev)
+        d_so = torch.from_numpy(so).to(dev)
+        for what in (7, 1, 5):
+            K = bin(what).count("1")
+            d_out = torch.full((n, ns, K, 3), float("nan"), dtype=torch.float64, device=dev)
+            ctx.eval_batch_device(r, n, 0 if ragged else 6, d_so if ragged else None, d_T, d_coef, ns, 0.0, dt, what, d_out)
+            ctx.synchronize()
+            got = d_out.cpu().numpy()
+            T = np.asarray(b["times"]).reshape(-1)
+            for k in range(n):
+                tk = T[so[k]:so[k + 1]]
+                ck = coef[3 * 2 * r * so[k]:3 * 2 * r * so[k + 1]]
+                for s in range(0, ns, 7):
+                    ref = oracle.poly_eval(2 * r, tk, ck, s * dt, what)
+                    assert np.max(np.abs(got[k, s] - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))

@@ -1,5 +1,6 @@
 // Times uavqp_solve_batch_device through the C ABI with plain hipMalloc buffers (no torch in the process).
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -30,6 +31,32 @@ int main(int argc, char** argv) {
     for (int i = 0; i < K; ++i) uavqp_solve_batch_device(ctx, r, B, M, M, nullptr, dwp, dT, dbc, dout, dst);
     hipEventRecord(e1, s); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (getenv("STREAMS")) {
+        const int NS = atoi(getenv("STREAMS"));
+        std::vector<uavqp_ctx*> cs(NS); std::vector<hipStream_t> ss(NS); std::vector<double*> outs(NS);
+        for (int i = 0; i < NS; ++i) { uavqp_create(&cs[i], 0); hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking); uavqp_set_stream(cs[i], ss[i]); hipMalloc(&outs[i], (size_t)B * 192 * 8); }
+        for (int i = 0; i < 4 * NS; ++i) uavqp_solve_batch_device(cs[i % NS], r, B, M, M, nullptr, dwp, dT, dbc, outs[i % NS], dst);
+        hipDeviceSynchronize();
+        hipEvent_t ev[16]; for (int i = 0; i < NS; ++i) hipEventCreate(&ev[i]);
+        auto t0 = std::chrono::high_resolution_clock::now();
+        for (int i = 0; i < K; ++i) uavqp_solve_batch_device(cs[i % NS], r, B, M, M, nullptr, dwp, dT, dbc, outs[i % NS], dst);
+        hipDeviceSynchronize();
+        auto t1 = std::chrono::high_resolution_clock::now();
+        ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+        printf("[%d streams, wall clock] ", NS);
+    }
+    if (getenv("GRAPH")) {
+        void* g = nullptr;
+        uavqp_capture_begin(ctx);
+        for (int i = 0; i < K; ++i) uavqp_solve_batch_device(ctx, r, B, M, M, nullptr, dwp, dT, dbc, dout, dst);
+        if (uavqp_capture_end(ctx, &g) != 0) { printf("capture failed: %s\n", uavqp_last_error()); return 1; }
+        uavqp_graph_launch(ctx, g); hipStreamSynchronize(s);
+        hipEventRecord(e0, s);
+        uavqp_graph_launch(ctx, g);
+        hipEventRecord(e1, s); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("[graph of %d steps] ", K);
+    }
     printf("C ABI B=%d: %.2f us/step  %.3e traj/s  %.2f TB/s algorithmic\n", B, ms * 1e3 / K, B / (ms / K * 1e-3), B * 1960.0 / (ms / K * 1e-3) / 1e12);
     uavqp_destroy(ctx);
     return 0;

@@ -5,6 +5,9 @@
 #ifndef TILE_
 #define TILE_ 32
 #endif
+#ifndef LPT_
+#define LPT_ 2
+#endif
 #include "../../uav_motion_planning_amd/csrc/uavqp.hip"
 #include <vector>
 #include <random>
@@ -34,14 +37,14 @@ int main(int argc, char** argv) {
     hipStream_t s; if (getenv("NB")) hipStreamCreateWithFlags(&s, hipStreamNonBlocking); else hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL((uavqp::solve_twisted_kernel<4, 8, TILE_>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((uavqp::solve_twisted_kernel<4, 8, TILE_, LPT_>), dim3(grid), dim3(64), 0, s, a);
         hipStreamSynchronize(s);
         long long st[8]; hipMemcpy(st, dstamps, 64, hipMemcpyDeviceToHost);
         printf("wave0 cycles: load %lld | chain %lld | meet %lld | emit %lld | total %lld\n", st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[4] - st[0]);
     }
     const int K = 200;
     hipEventRecord(e0, s);
-    for (int i = 0; i < K; ++i) hipLaunchKernelGGL((uavqp::solve_twisted_kernel<4, 8, TILE_>), dim3(grid), dim3(64), 0, s, a);
+    for (int i = 0; i < K; ++i) hipLaunchKernelGGL((uavqp::solve_twisted_kernel<4, 8, TILE_, LPT_>), dim3(grid), dim3(64), 0, s, a);
     hipEventRecord(e1, s); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("twisted<4,8> B=%d: %.2f us/launch back-to-back\n", B, ms * 1e3 / K);

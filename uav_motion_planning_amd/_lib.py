@@ -32,6 +32,11 @@ SYMBOLS = (
     "uavqp_solve_batch_device",
     "uavqp_solve_batch_host",
     "uavqp_solve_axis_host",
+    "uavqp_eval_batch_device",
+    "uavqp_capture_begin",
+    "uavqp_capture_end",
+    "uavqp_graph_launch",
+    "uavqp_graph_destroy",
 )
 
 
@@ -60,6 +65,14 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The uavqp product path has no CPU fallback."
         )
+    # torch wheels bundle their own libamdhip64 / libhsa-runtime64 (no SONAME).  Loaded first, the dynamic
+    # loader resolves libuavqp.so's HIP dependency to that same copy (one HIP runtime per process, torch
+    # streams and tensors are directly usable); loaded second, torch brings up a second HSA runtime and
+    # fails with "No HIP GPUs are available".  So: torch first, whenever torch is present.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, dp, ip = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p
     L.uavqp_version.restype = ctypes.c_char_p
@@ -72,6 +85,11 @@ def lib():
     L.uavqp_solve_batch_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
     L.uavqp_solve_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
     L.uavqp_solve_axis_host.argtypes = [vp, i32, i32, dp, dp, dp, dp, dp, dp, ctypes.POINTER(ctypes.c_int32)]
+    L.uavqp_eval_batch_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, i32, dp]
+    L.uavqp_capture_begin.argtypes = [vp]
+    L.uavqp_capture_end.argtypes = [vp, ctypes.POINTER(vp)]
+    L.uavqp_graph_launch.argtypes = [vp, vp]
+    L.uavqp_graph_destroy.argtypes = [vp, vp]
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError here = the library does not match the header
     _lib = L

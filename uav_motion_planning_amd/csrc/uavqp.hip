@@ -223,6 +223,68 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// N1: batched evaluation on a uniform time grid.  One lane per (trajectory, sample); consecutive lanes are
+// consecutive samples of one trajectory, so coefficient reads hit the same few cache lines and the
+// output (the dominant traffic: 24 B x K per sample) is fully coalesced.
+// ---------------------------------------------------------------------------------------------------
+struct EvalArgs {
+    int n_traj, uniform, n_samples, what;
+    const int32_t* seg_offsets;
+    const double* times;
+    const double* coeff;
+    double t0, dt;
+    double* out;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
+    constexpr int NC = 2 * R;
+    const long long total = (long long)a.n_traj * a.n_samples;
+    const int K = __popc(a.what & 7);
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(g / a.n_samples), s = (int)(g - (long long)b * a.n_samples);
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        double* o = a.out + (size_t)g * K * 3;
+        if (M < 1) {
+            for (int k = 0; k < 3 * K; ++k) o[k] = 0.0;
+            continue;
+        }
+        const double* __restrict__ T = a.times + s0;
+        // segment search exactly as PolyTraj::evaluatePos (poly_traj.hpp:77-88)
+        double t = a.t0 + s * a.dt;
+        int idx = 0;
+        while (idx < M && t > T[idx] + 1e-4) {
+            t -= T[idx];
+            ++idx;
+        }
+        if (idx == M) {
+            --idx;
+            t = T[idx];
+        }
+        const double* __restrict__ c = a.coeff + (size_t)3 * NC * s0 + (size_t)idx * NC;
+        int k = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (!((a.what >> d) & 1)) continue;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double* ca = c + (size_t)ax * NC * M;
+                double acc = 0.0;
+#pragma unroll
+                for (int j = NC - 1; j >= d; --j) {  // Horner on the d-th derivative
+                    double f = 1.0;
+                    for (int q = 0; q < d; ++q) f *= (double)(j - q);
+                    acc = fma(acc, t, f * ca[j]);
+                }
+                o[k * 3 + ax] = acc;
+            }
+            ++k;
+        }
+    }
+}
+
 }  // namespace uavqp
 
 #include "qp_twisted.h"
@@ -232,6 +294,7 @@ namespace uavqp {
 typedef void (*twisted_fn)(BatchArgs);
 template <int R, int M>
 static twisted_fn twisted_ptr(int tile) {
+    if (tile == 8) return &solve_twisted_kernel<R, M, 8, 8>;  // one lane pair per axis (latency shape)
     return tile == 16 ? &solve_twisted_kernel<R, M, 16> : &solve_twisted_kernel<R, M, 32>;
 }
 static twisted_fn find_twisted(int r, int M, int tile) {
@@ -314,7 +377,7 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
     }
     if (const char* e = std::getenv("UAVQP_TILE")) {
         const int t = std::atoi(e);
-        if (t == 16 || t == 32) ctx->tile_override = t;
+        if (t == 8 || t == 16 || t == 32) ctx->tile_override = t;
     }
     *out_ctx = ctx;
     return UAVQP_OK;
@@ -345,8 +408,15 @@ extern "C" int uavqp_synchronize(uavqp_ctx* ctx) {
 }
 
 extern "C" int uavqp_set_variant(uavqp_ctx* ctx, int variant) {
-    if (!ctx || variant < 0 || variant > 2) return UAVQP_ERR_INVALID_ARG;
+    if (!ctx) return UAVQP_ERR_INVALID_ARG;
+    if (variant == 8 || variant == 16 || variant == 32) {  // specialised kernel with a fixed tile shape
+        ctx->variant = 2;
+        ctx->tile_override = variant;
+        return UAVQP_OK;
+    }
+    if (variant < 0 || variant > 2) return UAVQP_ERR_INVALID_ARG;
     ctx->variant = variant;
+    ctx->tile_override = 0;
     return UAVQP_OK;
 }
 
@@ -387,7 +457,7 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     if (uniform_segments > 0 && ctx->variant != 1) {
         // small batches: half-wave tiles (16 trajectories) spread the launch over twice as many CUs --
         // one CU moves only ~10 B/clk, so a 4096-trajectory batch needs all 256 of them
-        int tile = (n_traj <= 16 * ctx->num_cus) ? 16 : 32;
+        int tile = (n_traj <= 16 * ctx->num_cus) ? 8 : 32;
         if (ctx->tile_override) tile = ctx->tile_override;
         uavqp::twisted_fn fn = uavqp::find_twisted(r, uniform_segments, tile);
         if (fn) {
@@ -513,4 +583,62 @@ extern "C" int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const dou
     delete[] wp;
     delete[] out;
     return rc;
+}
+
+extern "C" int uavqp_capture_begin(uavqp_ctx* ctx) {
+    if (!ctx) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    UAVQP_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_capture_end(uavqp_ctx* ctx, void** out_graph_exec) {
+    if (!ctx || !out_graph_exec) return UAVQP_ERR_INVALID_ARG;
+    *out_graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    UAVQP_HIP(hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+        return UAVQP_ERR_HIP;
+    }
+    *out_graph_exec = (void*)exec;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_graph_launch(uavqp_ctx* ctx, void* graph_exec) {
+    if (!ctx || !graph_exec) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_graph_destroy(uavqp_ctx* ctx, void* graph_exec) {
+    if (!ctx) return UAVQP_ERR_INVALID_ARG;
+    if (graph_exec) UAVQP_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_eval_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                       const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
+                                       int what, double* d_out) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || n_samples < 0 || uniform_segments < 0 || (what & 7) == 0)
+        return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0 || n_samples == 0) return UAVQP_OK;
+    if (!d_times || !d_coeff || !d_out || (uniform_segments == 0 && !d_seg_offsets)) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    uavqp::EvalArgs a;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.n_samples = n_samples; a.what = what & 7;
+    a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.t0 = t0; a.dt = dt; a.out = d_out;
+    const long long total = (long long)n_traj * n_samples;
+    long long grid = (total + 255) / 256;
+    const long long cap = (long long)ctx->num_cus * 16;
+    if (grid > cap) grid = cap;
+    if (r == 3)
+        hipLaunchKernelGGL(uavqp::eval_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(uavqp::eval_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+    UAVQP_HIP(hipGetLastError());
+    return UAVQP_OK;
 }

@@ -61,6 +61,29 @@ class Context:
     def synchronize(self):
         _lib.check(_lib.lib().uavqp_synchronize(self._h), "uavqp_synchronize")
 
+    def eval_batch_device(self, r, n_traj, uniform_segments, seg_offsets, times, coeff, n_samples, t0, dt, what, out):
+        """Batched PolyTraj::evaluatePos/Vel/Acc on the grid t0 + s*dt (device buffers, asynchronous)."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_eval_batch_device(self._h, r, n_traj, uniform_segments, p(seg_offsets), p(times), p(coeff),
+                                                n_samples, float(t0), float(dt), int(what), p(out))
+        _lib.check(rc, "uavqp_eval_batch_device")
+
+    def capture_begin(self):
+        """Start hipGraph capture of everything subsequently enqueued on the ctx stream."""
+        _lib.check(_lib.lib().uavqp_capture_begin(self._h), "uavqp_capture_begin")
+
+    def capture_end(self):
+        g = ctypes.c_void_p()
+        _lib.check(_lib.lib().uavqp_capture_end(self._h, ctypes.byref(g)), "uavqp_capture_end")
+        return g
+
+    def graph_launch(self, graph):
+        _lib.check(_lib.lib().uavqp_graph_launch(self._h, graph), "uavqp_graph_launch")
+
+    def graph_destroy(self, graph):
+        _lib.check(_lib.lib().uavqp_graph_destroy(self._h, graph), "uavqp_graph_destroy")
+
     def solve_batch_device(self, r, n_traj, uniform_segments, max_segments, seg_offsets, waypoints, times, bc,
                            coeff_out, status_out=None):
         """All array arguments are device buffers (torch CUDA tensors or raw integer addresses). Asynchronous."""
