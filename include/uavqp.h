@@ -60,6 +60,7 @@ enum {
 /* per-trajectory status (positive = OSQP's OSQP_SOLVED value, which the reference's solve() maps to true) */
 enum {
     UAVQP_SOLVED = 1,
+    UAVQP_MAX_ITER_REACHED = -2, /* corridor solve only (OSQP's OSQP_MAX_ITER_REACHED value): feasible, not proven optimal */
     UAVQP_INVALID_INPUT = -10, /* M < 1, M > max_segments, T <= 0 or non-finite input */
     UAVQP_NON_FINITE = -11     /* solution overflowed / NaN (pathological time allocation) */
 };
@@ -107,6 +108,26 @@ int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
 int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const double* pos_1d, const double* bound_vel,
                           const double* bound_acc, const double* bound_jerk, const double* time_vec,
                           double* coef_1d, int32_t* status_out);
+
+/* Corridor-constrained batched solve (north-star extension, BASELINE configs 3 and 5; no reference
+ * counterpart: every row of the reference QP is an equality, minimum_control.cpp:98-125,146-147).
+ * The interior-waypoint rows p_i(T_i) = w_{i+1} (minimum_control.cpp:34-42,118-124) become
+ * corr_lo <= p_i(T_i) <= corr_hi per axis; everything else is unchanged.
+ *   d_corr_lo / d_corr_hi  [sum_b (M_b+1)][3], same indexing as waypoints; the entries of the first and last
+ *                          waypoint of a trajectory are ignored (start/end positions stay equalities);
+ *                          lo == hi pins that waypoint (so lo = hi = waypoints reproduces uavqp_solve_batch_device).
+ *   d_waypoints            start/end positions, and the initial guess (clipped into the box) elsewhere.
+ *   d_iters_out            [n_traj] active-set iterations (max over axes), may be NULL.
+ * Exact primal active-set solve in the Hermite variables; status UAVQP_MAX_ITER_REACHED
+ * (max_iter = 8 M + 20 iterations) leaves a feasible, smooth, possibly sub-optimal trajectory. */
+int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                      const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                      const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
+                                      double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out);
+int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                    const int32_t* seg_offsets, const double* waypoints, const double* times,
+                                    const double* bc, const double* corr_lo, const double* corr_hi,
+                                    double* coeff_out, int32_t* status_out, int32_t* iters_out);
 
 /* Batched evaluation of solved trajectories on a uniform time grid.
  * Replaces, for a whole batch, PolyTraj::evaluatePos / evaluateVel / evaluateAcc

@@ -162,8 +162,9 @@ def osqp_solve_axis(r, pos, bc_start, bc_end, T, settings=None):
     return out, info
 
 
-def osqp_solve_batch(r, seg_offsets, waypoints, times, bc, settings=None, threads=1):
-    """Batch in the C-ABI layout: 3 x (setup + solve + cleanup) per trajectory.  Returns (coef, status, iters)."""
+def osqp_solve_batch(r, seg_offsets, waypoints, times, bc, settings=None, threads=1, corr_lo=None, corr_hi=None):
+    """Batch in the C-ABI layout: 3 x (setup + solve + cleanup) per trajectory.  Returns (coef, status, iters).
+    corr_lo / corr_hi (waypoint layout): interior waypoint rows become l <= p <= u (corridor extension)."""
     so, pso = _i(seg_offsets)
     wp, pwp = _d(waypoints)
     tt, ptt = _d(times)
@@ -172,7 +173,11 @@ def osqp_solve_batch(r, seg_offsets, waypoints, times, bc, settings=None, thread
     out = np.zeros(3 * 2 * r * int(so[-1]))
     status = np.zeros(n_traj, dtype=np.int32)
     iters = np.zeros(n_traj, dtype=np.int32)
-    rc = lib().osqp_port_solve_batch(r, n_traj, pso, pwp, ptt, pbc,
+    plo = phi = None
+    if corr_lo is not None:
+        clo, plo = _d(corr_lo)
+        chi, phi = _d(corr_hi)
+    rc = lib().osqp_port_solve_batch_corridor(r, n_traj, pso, pwp, ptt, pbc, plo, phi,
                                      ctypes.byref(settings) if settings is not None else None,
                                      out.ctypes.data_as(_dp), status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip),
                                      int(threads))

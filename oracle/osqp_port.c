@@ -93,7 +93,7 @@ static double falling(int k, int d) { double f = 1; for (int j = 0; j < d; ++j) 
 /* Problem data exactly as minimum_control.cpp:5-125 builds it (r=3), same pattern for r=4.
  * P: upper triangle only (osqp-eigen hands OSQP the upper-triangular view).  A keeps the structural zeros. */
 static void build_problem(int r, int M, const double* T, const double* pos, const double* bcs, const double* bce,
-                          csc* P, csc* A, double* l, double* u) {
+                          const double* corr_lo, const double* corr_hi, csc* P, csc* A, double* l, double* u) {
     const int R = 2 * r, n = R * M, m = 2 * r + (r + 1) * (M - 1);
     trip* tp = (trip*)malloc(sizeof(trip) * (size_t)(r * (r + 1) / 2 * M));
     int np = 0;
@@ -135,6 +135,10 @@ static void build_problem(int r, int M, const double* T, const double* pos, cons
     for (int d = 1; d < r; ++d) l[r + (r + 1) * (M - 1) + d] = bce[d - 1];
     for (int i = 0; i < M - 1; ++i) l[r + (r + 1) * i] = pos[i + 1];
     for (int j = 0; j < m; ++j) u[j] = l[j];
+    /* North-star extension (SURVEY.md section 8-a'): corridor = the interior waypoint equality p_i(T_i) = w_{i+1}
+     * becomes l <= p_i(T_i) <= u -- the only rows with l < u, and the reason OSQP's ADMM is needed at all. */
+    if (corr_lo && corr_hi)
+        for (int i = 0; i < M - 1; ++i) { l[r + (r + 1) * i] = corr_lo[i]; u[r + (r + 1) * i] = corr_hi[i]; }
 }
 
 /* ------------------------------------------------------------------ scaling (Ruiz) */
@@ -345,8 +349,19 @@ static void sym_triu_vec(const csc* P, const double* x, double* y) { /* y = P x,
 typedef struct { int iters; int status; int rho_updates; double pri_res, dua_res, rho; } port_info;
 
 /* One axis: setup + solve + cleanup, as MinimumControl::solve does per call (minimum_control.cpp:164-190). */
+int osqp_port_solve_axis_corridor(int r, int M, const double* pos, const double* bcs, const double* bce, const double* T,
+                                  const double* corr_lo, const double* corr_hi,
+                                  const port_settings* user, double* coef, port_info* info);
+
 int osqp_port_solve_axis(int r, int M, const double* pos, const double* bcs, const double* bce, const double* T,
                          const port_settings* user, double* coef, port_info* info) {
+    return osqp_port_solve_axis_corridor(r, M, pos, bcs, bce, T, NULL, NULL, user, coef, info);
+}
+
+/* corr_lo / corr_hi: M-1 bounds for the interior waypoints 1..M-1 of this axis (NULL: equalities at pos). */
+int osqp_port_solve_axis_corridor(int r, int M, const double* pos, const double* bcs, const double* bce, const double* T,
+                                  const double* corr_lo, const double* corr_hi,
+                                  const port_settings* user, double* coef, port_info* info) {
     if ((r != 3 && r != 4) || M < 1) return -2;
     port_settings st;
     if (user) st = *user; else osqp_port_default_settings(&st);
@@ -354,7 +369,7 @@ int osqp_port_solve_axis(int r, int M, const double* pos, const double* bcs, con
     csc P, A;
     double* q = (double*)calloc((size_t)n, sizeof(double));                 /* getGradient: q = 0, :21-24 */
     double* l = (double*)malloc(sizeof(double) * m); double* u = (double*)malloc(sizeof(double) * m);
-    build_problem(r, M, T, pos, bcs, bce, &P, &A, l, u);
+    build_problem(r, M, T, pos, bcs, bce, corr_lo, corr_hi, &P, &A, l, u);
 
     /* ---- osqp_setup ---- */
     scaling_t sc;
@@ -459,6 +474,7 @@ int osqp_port_solve_axis(int r, int M, const double* pos, const double* bcs, con
 typedef struct {
     int r, b0, b1; const int* so; const double* wp; const double* times; const double* bc;
     const port_settings* st; double* out; int* status; int* iters;
+    const double* clo; const double* chi;  /* optional corridor bounds, waypoint layout [sum(M_b+1)][3] */
 } job_t;
 
 static void* job_run(void* arg) {
@@ -478,7 +494,13 @@ static void* job_run(void* arg) {
                 be[d] = j->bc[(((size_t)b * 2 + 1) * (r - 1) + d) * 3 + ax];
             }
             port_info info;
-            osqp_port_solve_axis(r, M, pos, bs, be, j->times + s0, j->st, j->out + (size_t)3 * 2 * r * s0 + (size_t)ax * 2 * r * M, &info);
+            double *lo = NULL, *hi = NULL;
+            if (j->clo && j->chi && M > 1) {
+                lo = (double*)malloc(sizeof(double) * (M - 1)); hi = (double*)malloc(sizeof(double) * (M - 1));
+                for (int i = 1; i < M; ++i) { lo[i - 1] = j->clo[3 * (size_t)(s0 + b + i) + ax]; hi[i - 1] = j->chi[3 * (size_t)(s0 + b + i) + ax]; }
+            }
+            osqp_port_solve_axis_corridor(r, M, pos, bs, be, j->times + s0, lo, hi, j->st, j->out + (size_t)3 * 2 * r * s0 + (size_t)ax * 2 * r * M, &info);
+            free(lo); free(hi);
             if (info.status != PORT_SOLVED) worst = info.status;
             if (info.iters > it_max) it_max = info.iters;
         }
@@ -489,9 +511,19 @@ static void* job_run(void* arg) {
     return NULL;
 }
 
+int osqp_port_solve_batch_corridor(int r, int n_traj, const int* seg_offsets, const double* waypoints, const double* times,
+                                   const double* bc, const double* corr_lo, const double* corr_hi, const port_settings* st,
+                                   double* coef_out, int* status_out, int* iters_out, int n_threads);
+
 int osqp_port_solve_batch(int r, int n_traj, const int* seg_offsets, const double* waypoints, const double* times,
                           const double* bc, const port_settings* st, double* coef_out, int* status_out, int* iters_out,
                           int n_threads) {
+    return osqp_port_solve_batch_corridor(r, n_traj, seg_offsets, waypoints, times, bc, NULL, NULL, st, coef_out, status_out, iters_out, n_threads);
+}
+
+int osqp_port_solve_batch_corridor(int r, int n_traj, const int* seg_offsets, const double* waypoints, const double* times,
+                                   const double* bc, const double* corr_lo, const double* corr_hi, const port_settings* st,
+                                   double* coef_out, int* status_out, int* iters_out, int n_threads) {
     if (r != 3 && r != 4) return -2;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n_traj) n_threads = n_traj > 0 ? n_traj : 1;
@@ -499,7 +531,7 @@ int osqp_port_solve_batch(int r, int n_traj, const int* seg_offsets, const doubl
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
     for (int t = 0; t < n_threads; ++t) {
         job_t j = { r, (int)((long long)n_traj * t / n_threads), (int)((long long)n_traj * (t + 1) / n_threads),
-                    seg_offsets, waypoints, times, bc, st, coef_out, status_out, iters_out };
+                    seg_offsets, waypoints, times, bc, st, coef_out, status_out, iters_out, corr_lo, corr_hi };
         jobs[t] = j;
     }
     if (n_threads == 1) job_run(&jobs[0]);

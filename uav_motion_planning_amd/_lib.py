@@ -17,6 +17,7 @@ UAVQP_ERR_NO_DEVICE = -3
 UAVQP_ERR_ALLOC = -4
 
 UAVQP_SOLVED = 1
+UAVQP_MAX_ITER_REACHED = -2
 UAVQP_INVALID_INPUT = -10
 UAVQP_NON_FINITE = -11
 
@@ -32,6 +33,8 @@ SYMBOLS = (
     "uavqp_solve_batch_device",
     "uavqp_solve_batch_host",
     "uavqp_solve_axis_host",
+    "uavqp_solve_corridor_batch_device",
+    "uavqp_solve_corridor_batch_host",
     "uavqp_eval_batch_device",
     "uavqp_capture_begin",
     "uavqp_capture_end",
@@ -85,6 +88,8 @@ def lib():
     L.uavqp_solve_batch_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
     L.uavqp_solve_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
     L.uavqp_solve_axis_host.argtypes = [vp, i32, i32, dp, dp, dp, dp, dp, dp, ctypes.POINTER(ctypes.c_int32)]
+    L.uavqp_solve_corridor_batch_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip]
+    L.uavqp_solve_corridor_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip]
     L.uavqp_eval_batch_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, i32, dp]
     L.uavqp_capture_begin.argtypes = [vp]
     L.uavqp_capture_end.argtypes = [vp, ctypes.POINTER(vp)]

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
 }  // namespace uavqp
 
 #include "qp_twisted.h"
+#include "qp_corridor.h"
 
 namespace uavqp {
 // Specialised (R, M) instantiations of the register-resident kernel; everything else takes the generic one.
@@ -640,5 +641,98 @@ extern "C" int uavqp_eval_batch_device(uavqp_ctx* ctx, int r, int n_traj, int un
     else
         hipLaunchKernelGGL(uavqp::eval_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
     UAVQP_HIP(hipGetLastError());
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                                 const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                                 const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
+                                                 double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!d_waypoints || !d_times || !d_bc || !d_corr_lo || !d_corr_hi || !d_coeff_out || !d_status_out) return UAVQP_ERR_INVALID_ARG;
+    if (uniform_segments == 0 && (!d_seg_offsets || max_segments < 1)) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    const int Mmax = uniform_segments > 0 ? uniform_segments : max_segments;
+    uavqp::CorridorArgs a;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax; a.max_iter = 8 * Mmax + 20;
+    a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
+    a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.coeff = d_coeff_out; a.status = d_status_out; a.iters = d_iters_out;
+    const int block = 64;
+    long long lanes = 3LL * n_traj;
+    long long grid = (lanes + block - 1) / block;
+    const long long max_grid = (long long)ctx->num_cus * 8;
+    if (grid > max_grid) grid = max_grid;
+    const int F = r * r + 2 * r + 1;
+    const size_t ws_bytes = sizeof(double) * (size_t)(Mmax > 1 ? Mmax - 1 : 1) * F * (size_t)grid * block;
+    int rc = ensure_ws(ctx, ws_bytes);
+    if (rc != UAVQP_OK) return rc;
+    a.ws = ctx->ws;
+    hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
+    if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
+    if (r == 3)
+        hipLaunchKernelGGL(uavqp::solve_corridor_kernel<3>, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(uavqp::solve_corridor_kernel<4>, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+    UAVQP_HIP(hipGetLastError());
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                               const int32_t* seg_offsets, const double* waypoints, const double* times,
+                                               const double* bc, const double* corr_lo, const double* corr_hi,
+                                               double* coeff_out, int32_t* status_out, int32_t* iters_out) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!waypoints || !times || !bc || !corr_lo || !corr_hi || !coeff_out) return UAVQP_ERR_INVALID_ARG;
+    if (uniform_segments == 0 && !seg_offsets) return UAVQP_ERR_INVALID_ARG;
+    long long total_seg = 0;
+    int Mmax = uniform_segments;
+    if (uniform_segments > 0) total_seg = (long long)uniform_segments * n_traj;
+    else {
+        if (seg_offsets[0] != 0) return UAVQP_ERR_INVALID_ARG;
+        for (int b = 0; b < n_traj; ++b) {
+            const int M = seg_offsets[b + 1] - seg_offsets[b];
+            if (M < 0) return UAVQP_ERR_INVALID_ARG;
+            if (M > Mmax) Mmax = M;
+        }
+        total_seg = seg_offsets[n_traj];
+        if (max_segments > 0 && max_segments < Mmax) Mmax = max_segments;
+        if (Mmax < 1) Mmax = 1;
+    }
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    const size_t n_wp = 3 * (size_t)(total_seg + n_traj);
+    const size_t b_off = uniform_segments > 0 ? 0 : align256(sizeof(int32_t) * (size_t)(n_traj + 1));
+    const size_t b_wp = align256(sizeof(double) * n_wp);
+    const size_t b_t = align256(sizeof(double) * (size_t)total_seg);
+    const size_t b_bc = align256(sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3);
+    const size_t b_out = align256(sizeof(double) * 3 * 2 * r * (size_t)total_seg);
+    const size_t b_st = align256(sizeof(int32_t) * (size_t)n_traj);
+    int rc = ensure_stage(ctx, b_off + 3 * b_wp + b_t + b_bc + b_out + 2 * b_st);
+    if (rc != UAVQP_OK) return rc;
+    char* p = (char*)ctx->d_stage;
+    int32_t* d_off = uniform_segments > 0 ? nullptr : (int32_t*)p; p += b_off;
+    double* d_wp = (double*)p; p += b_wp;
+    double* d_lo = (double*)p; p += b_wp;
+    double* d_hi = (double*)p; p += b_wp;
+    double* d_t = (double*)p; p += b_t;
+    double* d_bc = (double*)p; p += b_bc;
+    double* d_out = (double*)p; p += b_out;
+    int32_t* d_st = (int32_t*)p; p += b_st;
+    int32_t* d_it = (int32_t*)p;
+    hipStream_t s = ctx->stream;
+    if (d_off) UAVQP_HIP(hipMemcpyAsync(d_off, seg_offsets, sizeof(int32_t) * (size_t)(n_traj + 1), hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_wp, waypoints, sizeof(double) * n_wp, hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_lo, corr_lo, sizeof(double) * n_wp, hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_hi, corr_hi, sizeof(double) * n_wp, hipMemcpyHostToDevice, s));
+    if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(d_t, times, sizeof(double) * (size_t)total_seg, hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_bc, bc, sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3, hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * 3 * 2 * r * (size_t)total_seg, s));
+    rc = uavqp_solve_corridor_batch_device(ctx, r, n_traj, uniform_segments, Mmax, d_off, d_wp, d_t, d_bc, d_lo, d_hi, d_out, d_st, d_it);
+    if (rc != UAVQP_OK) return rc;
+    if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(coeff_out, d_out, sizeof(double) * 3 * 2 * r * (size_t)total_seg, hipMemcpyDeviceToHost, s));
+    if (status_out) UAVQP_HIP(hipMemcpyAsync(status_out, d_st, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
+    if (iters_out) UAVQP_HIP(hipMemcpyAsync(iters_out, d_it, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
+    UAVQP_HIP(hipStreamSynchronize(s));
     return UAVQP_OK;
 }

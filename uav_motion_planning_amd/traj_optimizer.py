@@ -117,6 +117,31 @@ class Context:
         _lib.check(rc, "uavqp_solve_batch_host")
         return coeff, status
 
+    def solve_corridor_batch_host(self, r, seg_offsets, waypoints, times, bc, corr_lo, corr_hi, uniform_segments=0):
+        """Corridor-constrained solve, numpy in / numpy out.  Returns (coeff_flat, status, iters)."""
+        waypoints = np.ascontiguousarray(waypoints, dtype=np.float64)
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        bc = np.ascontiguousarray(bc, dtype=np.float64)
+        lo = np.ascontiguousarray(corr_lo, dtype=np.float64)
+        hi = np.ascontiguousarray(corr_hi, dtype=np.float64)
+        if uniform_segments > 0:
+            n_traj = times.size // uniform_segments
+            so, total, mmax = None, n_traj * uniform_segments, uniform_segments
+        else:
+            so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+            n_traj = so.size - 1
+            total = int(so[-1]) if n_traj > 0 else 0
+            mmax = int(np.max(np.diff(so))) if n_traj > 0 else 1
+        assert waypoints.size == 3 * (total + n_traj) == lo.size == hi.size
+        coeff = np.zeros(3 * 2 * r * total, dtype=np.float64)
+        status = np.zeros(n_traj, dtype=np.int32)
+        iters = np.zeros(n_traj, dtype=np.int32)
+        rc = _lib.lib().uavqp_solve_corridor_batch_host(self._h, r, n_traj, uniform_segments, max(mmax, 1), _ptr(so),
+                                                        _ptr(waypoints), _ptr(times), _ptr(bc), _ptr(lo), _ptr(hi),
+                                                        _ptr(coeff), _ptr(status), _ptr(iters))
+        _lib.check(rc, "uavqp_solve_corridor_batch_host")
+        return coeff, status, iters
+
     def solve_axis_host(self, r, pos_1d, bound_vel, bound_acc, time_vec, bound_jerk=None):
         pos = np.ascontiguousarray(pos_1d, dtype=np.float64)
         bv = np.ascontiguousarray(bound_vel, dtype=np.float64)

@@ -95,3 +95,21 @@ def ragged_batch(config_index, n_traj, r, m_lo=4, m_hi=24, seed=None):
 def algorithmic_bytes(r, n_seg):
     """float64, 3 axes, equality-only: in = 8[3(M+1)+M+3*2*(r-1)], out = 8*3*2r*M."""
     return 8 * (3 * (n_seg + 1) + n_seg + 3 * 2 * (r - 1)) + 8 * 3 * 2 * r * n_seg
+
+
+def corridor_boxes(batch, config_index=3, h_lo=0.3, h_hi=0.8, seed=None):
+    """Config-3 style corridors: axis-aligned box of half-width h ~ U(0.3, 0.8) m around
+    each interior waypoint (cf. pillar radii 0.5-0.7 and inflation 0.099, simulator.xml:26-27), replacing the
+    waypoint equality.  Returns (lo, hi) in the waypoint layout; first/last waypoint rows are lo = hi = waypoint."""
+    rng = np.random.default_rng(SEED0 + 100 + config_index if seed is None else seed)
+    wp = np.asarray(batch["waypoints"], dtype=np.float64)
+    flat = wp.reshape(-1, 3)
+    h = rng.uniform(h_lo, h_hi, size=(flat.shape[0], 1))
+    lo, hi = flat - h, flat + h
+    so = np.asarray(batch["seg_offsets"], dtype=np.int64)
+    first = so[:-1] + np.arange(so.size - 1)
+    last = so[1:] + np.arange(so.size - 1)
+    for idx in (first, last):
+        lo[idx] = flat[idx]
+        hi[idx] = flat[idx]
+    return lo.reshape(wp.shape), hi.reshape(wp.shape)
