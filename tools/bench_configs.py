@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Device-resident timings of BASELINE.json's other configs (parity-test shapes, not bench.py lines):
+config 3 (65536 x 16-segment min-jerk + corridors), config 4 (32768 ragged min-snap, M in [4, 24]),
+evaluation (N1).  Prints one JSON line per measurement.  Run on the GPU box: python tools/bench_configs.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timeit(fn, stream, n=20, warm=3):
+    import torch
+    for _ in range(warm):
+        fn()
+    stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(n):
+        fn()
+    e1.record(stream)
+    stream.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    import torch
+    import uav_motion_planning_amd as U
+    from uav_motion_planning_amd import workloads as W
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(s)
+    ctx = U.Context(0)
+    ctx.set_stream(s.cuda_stream)
+
+    def up(x, dt=torch.float64):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+    # ---- config 3: 65536 x (M=16, r=3), equality-only and with corridors
+    r, M, n = 3, 16, 65536
+    b = W.uniform_batch(3, n, M, r, time_mode="distance")
+    lo, hi = W.corridor_boxes(b)
+    d = {k: up(b[k]) for k in ("waypoints", "times", "bc")}
+    d_lo, d_hi = up(lo), up(hi)
+    out = torch.zeros(n * 3 * M * 2 * r, dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev)
+    ms = timeit(lambda: ctx.solve_batch_device(r, n, M, M, None, d["waypoints"], d["times"], d["bc"], out, st), s)
+    print(json.dumps({"config": "3-equality", "n": n, "M": M, "r": r, "ms": ms, "traj_per_s": n / ms * 1e3,
+                      "GB_per_s": n * W.algorithmic_bytes(r, M) / ms / 1e6}))
+    lib = U.lib()
+    import ctypes
+
+    def corridor():
+        rc = lib.uavqp_solve_corridor_batch_device(ctx._h, r, n, M, M, None, d["waypoints"].data_ptr(), d["times"].data_ptr(),
+                                                   d["bc"].data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), out.data_ptr(),
+                                                   st.data_ptr(), it.data_ptr())
+        assert rc == 0
+    ms = timeit(corridor, s, n=5, warm=1)
+    bytes_c = W.algorithmic_bytes(r, M) + 8 * 2 * 3 * (M - 1)
+    print(json.dumps({"config": "3-corridor", "n": n, "M": M, "r": r, "ms": ms, "traj_per_s": n / ms * 1e3,
+                      "GB_per_s": n * bytes_c / ms / 1e6, "solved": int((st == 1).sum()), "iters_mean": float(it.float().mean()),
+                      "iters_max": int(it.max())}))
+
+    # ---- config 4: 32768 ragged (M in [4, 24]), r=4
+    r, n = 4, 32768
+    b = W.ragged_batch(4, n, r)
+    so = b["seg_offsets"]
+    d_so = torch.from_numpy(so).to(dev)
+    d = {k: up(b[k]) for k in ("waypoints", "times", "bc")}
+    out = torch.zeros(int(so[-1]) * 3 * 2 * r, dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    ms = timeit(lambda: ctx.solve_batch_device(r, n, 0, 24, d_so, d["waypoints"], d["times"], d["bc"], out, st), s)
+    byts = 8 * (3 * (so[-1] + n) + so[-1] + 18 * n) + 8 * 24 * so[-1] + 4 * n
+    print(json.dumps({"config": "4-ragged", "n": n, "sum_M": int(so[-1]), "r": r, "ms": ms, "traj_per_s": n / ms * 1e3,
+                      "GB_per_s": float(byts) / ms / 1e6, "solved": int((st == 1).sum())}))
+
+    # ---- N1: evaluation of config-2 trajectories at 100 samples (pos, vel, acc)
+    r, M, n, ns = 4, 8, 4096, 100
+    b = W.uniform_batch(2, n, M, r, time_mode="distance")
+    d = {k: up(b[k]) for k in ("waypoints", "times", "bc")}
+    out = torch.zeros(n * 3 * M * 2 * r, dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx.solve_batch_device(r, n, M, M, None, d["waypoints"], d["times"], d["bc"], out, st)
+    ev = torch.zeros(n * ns * 9, dtype=torch.float64, device=dev)
+    ms = timeit(lambda: ctx.eval_batch_device(r, n, M, None, d["times"], out, ns, 0.0, 0.05, 7, ev), s)
+    print(json.dumps({"config": "N1-eval", "n": n, "samples": ns, "ms": ms, "samples_per_s": n * ns / ms * 1e3,
+                      "GB_per_s": (n * ns * 72 + n * 1536) / ms / 1e6}))
+
+
+if __name__ == "__main__":
+    main()

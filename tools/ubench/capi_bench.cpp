@@ -8,15 +8,15 @@
 #include "../../include/uavqp.h"
 
 int main(int argc, char** argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 4096, M = 8, r = 4, K = argc > 2 ? atoi(argv[2]) : 200;
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, K = argc > 2 ? atoi(argv[2]) : 200, r = argc > 3 ? atoi(argv[3]) : 4, M = argc > 4 ? atoi(argv[4]) : 8;
     std::mt19937_64 g(1);
     std::uniform_real_distribution<double> u(-2, 2), ut(0.5, 2.0);
-    std::vector<double> wp((size_t)B * (M + 1) * 3), T((size_t)B * M), bc((size_t)B * 18, 0.0);
+    std::vector<double> wp((size_t)B * (M + 1) * 3), T((size_t)B * M), bc((size_t)B * 6 * (r - 1), 0.0);
     for (auto& x : wp) x = u(g);
     for (auto& x : T) x = ut(g);
     double *dwp, *dT, *dbc, *dout; int* dst;
     hipMalloc(&dwp, wp.size() * 8); hipMalloc(&dT, T.size() * 8); hipMalloc(&dbc, bc.size() * 8);
-    hipMalloc(&dout, (size_t)B * 192 * 8); hipMalloc(&dst, (size_t)B * 4);
+    hipMalloc(&dout, (size_t)B * 3 * 2 * r * M * 8); hipMalloc(&dst, (size_t)B * 4);
     hipMemcpy(dwp, wp.data(), wp.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dT, T.data(), T.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(dbc, bc.data(), bc.size() * 8, hipMemcpyHostToDevice);
@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     if (getenv("STREAMS")) {
         const int NS = atoi(getenv("STREAMS"));
         std::vector<uavqp_ctx*> cs(NS); std::vector<hipStream_t> ss(NS); std::vector<double*> outs(NS);
-        for (int i = 0; i < NS; ++i) { uavqp_create(&cs[i], 0); hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking); uavqp_set_stream(cs[i], ss[i]); hipMalloc(&outs[i], (size_t)B * 192 * 8); }
+        for (int i = 0; i < NS; ++i) { uavqp_create(&cs[i], 0); hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking); uavqp_set_stream(cs[i], ss[i]); hipMalloc(&outs[i], (size_t)B * 3 * 2 * r * M * 8); }
         for (int i = 0; i < 4 * NS; ++i) uavqp_solve_batch_device(cs[i % NS], r, B, M, M, nullptr, dwp, dT, dbc, outs[i % NS], dst);
         hipDeviceSynchronize();
         hipEvent_t ev[16]; for (int i = 0; i < NS; ++i) hipEventCreate(&ev[i]);
@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
         hipEventElapsedTime(&ms, e0, e1);
         printf("[graph of %d steps] ", K);
     }
-    printf("C ABI B=%d: %.2f us/step  %.3e traj/s  %.2f TB/s algorithmic\n", B, ms * 1e3 / K, B / (ms / K * 1e-3), B * 1960.0 / (ms / K * 1e-3) / 1e12);
+    printf("C ABI B=%d: %.2f us/step  %.3e traj/s  %.2f TB/s algorithmic\n", B, ms * 1e3 / K, B / (ms / K * 1e-3), B * (8.0 * (3 * (M + 1) + M + 6 * (r - 1)) + 8.0 * 3 * 2 * r * M) / (ms / K * 1e-3) / 1e12);
     uavqp_destroy(ctx);
     return 0;
 }

@@ -65,6 +65,32 @@ __global__ __launch_bounds__(64) void wr(double* out, int n_tiles) {
                         const int seg = r ? 15 - jj : jj;
                         if (q < 3) *reinterpret_cast<double2*>(base + ((t * 3 + ax) * 16 + seg) * 6 + 2 * q) = v;
                     }
+        } else if (P == 6) {
+            // min-jerk M=16 pair mode, axis-major: 48-B chunks, two adjacent chunks (96 B) back-to-back; tile = 32 traj x 288 doubles
+            double* b6 = out + (size_t)tile * 32 * 288;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+                for (int pp = 3; pp >= 0; --pp)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int pl = ii * 16 + (lane >> 2), q = lane & 3, t = pl >> 1, r = pl & 1;
+                            const int j1 = 2 * pp + 1, j0 = 2 * pp;
+                            const int seg = (r ? 15 - j1 : j0) + hh;
+                            if (q < 3) *reinterpret_cast<double2*>(b6 + ((t * 3 + ax) * 16 + seg) * 6 + 2 * q) = v;
+                        }
+        } else if (P == 7) {
+            // min-jerk M=16 row mode: per axis the 32 rows of 768 B are written linearly (48 pieces of 16 B per row)
+            double* b7 = out + (size_t)tile * 32 * 288;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+                for (int it = 0; it < 24; ++it) {
+                    const int g = it * 64 + lane, row = g / 48, col = g % 48;
+                    *reinterpret_cast<double2*>(b7 + ((row * 3 + ax) * 16) * 6 + 2 * col) = v;
+                }
         } else {
 #pragma unroll
             for (int k = 0; k < 48; ++k) {
@@ -84,7 +110,7 @@ void run(double* out, int n_tiles, int grid) {
     for (int i = 0; i < K; ++i) hipLaunchKernelGGL(wr<P>, dim3(grid), dim3(64), 0, 0, out, n_tiles);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    const double bytes = (double)n_tiles * 32 * 192 * 8;
+    const double bytes = (double)n_tiles * 32 * (P >= 6 ? 288 : 192) * 8;
     printf("pattern %d grid %5d: %.1f us  %.2f TB/s\n", P, grid, ms * 1e3 / K, bytes / (ms / K * 1e-3) / 1e12);
 }
 
@@ -92,7 +118,7 @@ int main(int argc, char** argv) {
     const int n_traj = 1 << 20, n_tiles = n_traj / 32;
     double* out; hipMalloc(&out, (size_t)n_traj * 192 * 8);
     for (int grid : {1024, 4096}) {
-        run<0>(out, n_tiles, grid); run<1>(out, n_tiles, grid); run<2>(out, n_tiles, grid); run<4>(out, n_tiles, grid); run<5>(out, n_tiles, grid);
+        run<0>(out, n_tiles, grid); run<1>(out, n_tiles, grid); run<2>(out, n_tiles, grid); run<4>(out, n_tiles, grid); run<5>(out, n_tiles, grid); run<6>(out, n_tiles * 2 / 3, grid); run<7>(out, n_tiles * 2 / 3, grid);
     }
     return 0;
 }

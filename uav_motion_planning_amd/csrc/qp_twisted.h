@@ -34,22 +34,25 @@ struct TwistedCfg {
     static constexpr int BC_D = TILE * 2 * ND * 3;
     static constexpr int T_OFF = WP_D, BC_OFF = WP_D + T_D;
     static constexpr int IN_D = WP_D + T_D + BC_D;
-    // staged chunk row per producing lane: 3 axes x 2r doubles, padded so that the row stride in dwords
-    // is 4 (mod 8): conflict-free ds_write_b128 within its 8-lane groups
-    static constexpr int OUT_STRIDE = (3 * NC + 2) % 4 == 0 ? 3 * NC + 4 : 3 * NC + 2;
     static constexpr int PQ = NC / 2;  // 16-byte pieces per chunk
     // LPT = lanes per trajectory.  2: one (L, R) lane pair carries all three axes (throughput shape).
     // 8: one lane pair per axis (+ one idle pair) -- the matrix elimination is repeated by the three pairs,
     // right-hand sides, back-substitution and coefficient emission are split by axis (latency shape for
     // small batches: ~2x shorter critical path per wave, 8 trajectories per wave).
     static constexpr int NAX = LPT == 2 ? 3 : 1;
-    // Pair mode: both halves have an even number of segments, so own segments are emitted two at a time and
-    // the two 2r-coefficient chunks of a (trajectory, axis, segment pair) are stored by back-to-back
-    // instructions -- for r = 4 that is one whole 128-B line, which L2 then writes out as a full line
-    // (measured: 5.3 TB/s vs 3.5 TB/s when the halves of a line arrive a segment apart).
-    static constexpr bool PAIRS = (mL == mR) && (mL % 2 == 0);
-    static constexpr int PAIR_STRIDE = (2 * NC + 2) % 4 == 0 ? 2 * NC + 4 : 2 * NC + 2;  // one axis, two segments
-    static constexpr int OUT_D = 64 * (PAIRS ? PAIR_STRIDE : OUT_STRIDE);
+    // Emission chunk: CH own segments of one axis per unit (r = 4: 2 segments = one 128-B line; r = 3: 4
+    // segments = 192 B).  Staging = 64 lane rows of CH*NC doubles, row stride 4 (mod 8) dwords for
+    // conflict-free ds_write_b128.  If double-buffered input + staging exceed the LDS budget of 4 waves
+    // per CU (40448 B each), the staging rows alias the current input buffer instead.
+    static constexpr int CH = (NC * 8) % 64 == 0 ? 2 : 4;
+    static constexpr int STAGE_STRIDE0 = CH * NC + 2;
+    static constexpr int STAGE_STRIDE = (STAGE_STRIDE0 * 2) % 8 == 4 ? STAGE_STRIDE0 : STAGE_STRIDE0 + 2;
+    static constexpr int STAGE_D = 64 * STAGE_STRIDE;
+    // (measured, 1 M batch: aliasing wins for r = 3 -- (3,16) 3.85 vs 3.71, (3,12) 3.97 vs 3.43 TB/s -- but the
+    // register cost of the pre-loaded positions spills for r = 4, M = 12: 3.46 vs 3.92 TB/s with 3 waves/CU)
+    static constexpr bool ALIAS = LPT == 2 && R == 3 && (2 * IN_D + STAGE_D) * 8 > 40448;
+    static constexpr int OUT_D = (LPT == 2 && !ALIAS) ? STAGE_D : 2;
+    static_assert(!ALIAS || STAGE_D <= IN_D, "aliased staging rows must fit the input buffer");
     static_assert(WP_D % 2 == 0 && T_D % 2 == 0 && BC_D % 2 == 0, "tile arrays must be whole 16-B pairs");
 };
 
@@ -60,6 +63,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);  // also keep arithmetic of the next unit below: bounds register pressure
 }
 
 // s_waitcnt vmcnt(0) through the builtin (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15) so that the
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
 
     __shared__ __attribute__((aligned(16))) double s_in[2][C::IN_D];
     __shared__ __attribute__((aligned(16))) double s_out[LPT == 2 ? C::OUT_D : 2];
+    (void)s_out;
 
     const int lane = threadIdx.x;
     const int isR = lane & 1;
@@ -364,164 +369,95 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                     for (int i = 0; i < ND; ++i) ynext[i][0] = y[i];
                 }
             }
-        } else if constexpr (C::PAIRS) {
+        } else {
+            // ---------------- chunk mode (LPT == 2): CH own segments x one axis per emission unit ----------------
+            // Every lane writes the 2r*CH coefficients of its chunk, in ORIGINAL segment order, to its own LDS
+            // row; the wave then copies the 64 rows out linearly, 16 B per lane: a lane row is one contiguous
+            // run in HBM (r = 4, CH = 2: exactly one 128-B line; r = 3, CH = 4: 192 B, and when CH covers the
+            // whole half the L and R rows of a trajectory are adjacent, i.e. whole (trajectory, axis) rows).
+            // Units are axis-major so that the fragments of a line shared by two chunks are written close
+            // together.  Measured on the store pattern alone (tools/ubench/write_patterns.hip): 5.3-5.5 TB/s
+            // for line-complete runs vs 3.0-3.5 TB/s when half lines / 48-B chunks arrive a segment apart.
+            constexpr int CH = C::CH, NQ = (mL + CH - 1) / CH, RS = C::STAGE_STRIDE, PPL = CH * NC / 2;
+            // in-place back-substitution: h[j] <- y_j for the own interior knots j = m-1 .. 1
 #pragma unroll
-            for (int pp = mL / 2 - 1; pp >= 0; --pp) {
-                constexpr int NII = TILE / 8;
-                const int j1 = 2 * pp + 1, j0 = 2 * pp;  // own segments of this pair (halves are equal: no lag)
-                double y1[ND][NAX], y0[ND][NAX];
-#pragma unroll
-                for (int i = 0; i < ND; ++i)
-#pragma unroll
-                    for (int ax = 0; ax < NAX; ++ax) y1[i][ax] = h[j1][i][ax];
-#pragma unroll
-                for (int i = 0; i < ND; ++i)
-#pragma unroll
-                    for (int c = 0; c < ND; ++c)
-#pragma unroll
-                        for (int ax = 0; ax < NAX; ++ax) y1[i][ax] -= E[j1][i][c] * ynext[c][ax];
-#pragma unroll
-                for (int i = 0; i < ND; ++i)
-#pragma unroll
-                    for (int ax = 0; ax < NAX; ++ax) y0[i][ax] = h[j0][i][ax];
-                if (j0 > 0) {
+            for (int j = mL - 1; j >= 1; --j) {
+                if (j < m) {
 #pragma unroll
                     for (int i = 0; i < ND; ++i)
 #pragma unroll
                         for (int c = 0; c < ND; ++c)
 #pragma unroll
-                            for (int ax = 0; ax < NAX; ++ax) y0[i][ax] -= E[j0][i][c] * y1[c][ax];
+                            for (int ax = 0; ax < NAX; ++ax) {
+                                const double src = (j == mL - 1 || j == m - 1) ? ynext[c][ax] : h[j + 1 < mL ? j + 1 : j][c][ax];
+                                h[j][i][ax] -= E[j][i][c] * src;
+                            }
                 }
-                const double T1 = Tof(j1), T0 = Tof(j0);
-                const double it1 = fast_rcp(T1), it0 = fast_rcp(T0);
-                // LDS row of this lane: [lower original segment | higher original segment]
-                double* so = &s_out[lane * C::PAIR_STRIDE];
-                double* so1 = so + (isR ? 0 : NC);  // own j1: the higher original segment for L, the lower for R
-                double* so0 = so + (isR ? NC : 0);
+            }
+            double* stage = C::ALIAS ? s_in[buf] : s_out;
+            // When the staging rows alias the current input buffer, everything emission still needs from it
+            // is pulled into registers first.
+            double P_[C::ALIAS ? mL + 1 : 1][3], T_[C::ALIAS ? mL : 1];
+            if constexpr (C::ALIAS) {
 #pragma unroll
-                for (int ax = 0; ax < NAX; ++ax) {
-                    const double p0 = pos(j0, ax), p1 = pos(j1, ax), p2 = pos(j1 + 1, ax);
-                    double ys[ND], ye[ND], ca[NC], cb[NC];
+                for (int j = 0; j <= mL; ++j)
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) {
-                        const double fs = ((d & 1) == 0) ? -1.0 : 1.0;
-                        ys[d] = isR ? fs * ynext[d][ax] : y1[d][ax];
-                        ye[d] = isR ? fs * y1[d][ax] : ynext[d][ax];
-                    }
-                    segment_coeffs<R>(isR ? p2 : p1, ys, isR ? p1 : p2, ye, T1, it1, ca);
+                    for (int ax = 0; ax < 3; ++ax) P_[j][ax] = pos(j <= m ? j : m, ax);
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) {
-                        const double fs = ((d & 1) == 0) ? -1.0 : 1.0;
-                        ys[d] = isR ? fs * y1[d][ax] : y0[d][ax];
-                        ye[d] = isR ? fs * y0[d][ax] : y1[d][ax];
-                    }
-                    segment_coeffs<R>(isR ? p1 : p0, ys, isR ? p0 : p1, ye, T0, it0, cb);
-                    finite = finite && (fabs(ca[NC - 1]) < INFINITY) && (fabs(ca[R]) < INFINITY) &&
-                             (fabs(cb[NC - 1]) < INFINITY) && (fabs(cb[R]) < INFINITY);
+                for (int j = 0; j < mL; ++j) T_[j] = Tof(j < m ? j : m - 1);
+                wave_lds_sync();
+            }
 #pragma unroll
-                    for (int k = 0; k < NC; k += 2) {
-                        *reinterpret_cast<double2*>(so1 + k) = make_double2(ca[k], ca[k + 1]);
-                        *reinterpret_cast<double2*>(so0 + k) = make_double2(cb[k], cb[k + 1]);
+            for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+                for (int q = NQ - 1; q >= 0; --q) {
+                    const int cnt = max(0, min((q + 1) * CH, m) - q * CH);  // own segments in this chunk (lane-dependent for odd M)
+                    double* row = stage + lane * RS;
+#pragma unroll
+                    for (int s = 0; s < CH; ++s) {
+                        const int j = q * CH + s;  // own segment
+                        if (j < mL) {
+                            const int jc = j < m ? j : (m > 0 ? m - 1 : 0);
+                            double ys[ND], ye[ND], c8[NC];
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) {
+                                const double fs = ((d & 1) == 0) ? -1.0 : 1.0;
+                                const double yj = h[j][d][ax];
+                                const double yj1 = (j + 1 >= mL || j + 1 == m) ? ynext[d][ax] : h[j + 1 < mL ? j + 1 : j][d][ax];
+                                ys[d] = isR ? fs * yj1 : yj;
+                                ye[d] = isR ? fs * yj : yj1;
+                            }
+                            double pa, pb, Tj;
+                            if constexpr (C::ALIAS) { pa = P_[j][ax]; pb = P_[j + 1][ax]; Tj = T_[j]; }
+                            else { pa = pos(jc, ax); pb = pos(jc + 1, ax); Tj = Tof(jc); }
+                            segment_coeffs<R>(isR ? pb : pa, ys, isR ? pa : pb, ye, Tj, fast_rcp(Tj), c8);
+                            if (j < m) finite = finite && (fabs(c8[NC - 1]) < INFINITY) && (fabs(c8[R]) < INFINITY);
+                            // slot in original order: L ascending, R descending within the chunk
+                            const int slot = isR ? (cnt - 1 - s) : s;
+                            if (s < cnt) {
+                                double* so = row + slot * NC;
+#pragma unroll
+                                for (int k = 0; k < NC; k += 2) *reinterpret_cast<double2*>(so + k) = make_double2(c8[k], c8[k + 1]);
+                            }
+                        }
                     }
                     wave_lds_sync();
-                    double2 v[NII][2];
 #pragma unroll
-                    for (int ii = 0; ii < NII; ++ii)
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const int pl = ii * 16 + (lane >> 2), q = lane & 3;
-                            v[ii][hh] = *reinterpret_cast<const double2*>(&s_out[pl * C::PAIR_STRIDE + hh * NC + 2 * (q < C::PQ ? q : 0)]);
-                        }
-#pragma unroll
-                    for (int ii = 0; ii < NII; ++ii)
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const int pl = ii * 16 + (lane >> 2), q = lane & 3;
-                            const int ctl = pl >> 1, cR = pl & 1;
-                            const int seg = (cR ? (M - 1 - j1) : j0) + hh;
-                            const bool keep = (q < C::PQ) && ((okmask >> (2 * ctl)) & 1ull);
-                            double* dst = keep ? out + (((size_t)ctl * 3 + ax) * M + seg) * NC + 2 * q : a.dummy + 2 * lane;
-                            store_pair(dst, v[ii][hh]);
-                        }
-                    wave_lds_sync();  // the row is rewritten by the next axis: keep the reads above it
-                }
-#pragma unroll
-                for (int i = 0; i < ND; ++i)
-#pragma unroll
-                    for (int ax = 0; ax < NAX; ++ax) ynext[i][ax] = y0[i][ax];
-            }
-        } else {
-#pragma unroll
-        for (int jj = mL - 1; jj >= 0; --jj) {
-            // the lane with the shorter half (R, odd M) runs one index behind
-            const int j = (mL == mR || !isR) ? jj : jj - 1;
-            const bool act = (j >= 0);
-            double y[ND][NAX];
-#pragma unroll
-            for (int i = 0; i < ND; ++i)
-#pragma unroll
-                for (int ax = 0; ax < NAX; ++ax) y[i][ax] = (mL == mR || !isR) ? h[jj][i][ax] : h[jj > 0 ? jj - 1 : 0][i][ax];
-            if (jj > 0 || mL != mR) {  // E_0 = 0: nothing to subtract at the boundary knot
-#pragma unroll
-                for (int i = 0; i < ND; ++i)
-#pragma unroll
-                    for (int c = 0; c < ND; ++c) {
-                        const double e = (mL == mR || !isR) ? E[jj][i][c] : E[jj > 0 ? jj - 1 : 0][i][c];
-#pragma unroll
-                        for (int ax = 0; ax < NAX; ++ax) y[i][ax] -= e * ynext[c][ax];
+                    for (int it = 0; it < PPL; ++it) {
+                        const int g = it * 64 + lane;
+                        const int pl = g / PPL, col = g - pl * PPL;
+                        const int ctl = pl >> 1, cR = pl & 1;
+                        const int cm = cR ? mR : mL;
+                        const int ccnt = max(0, min((q + 1) * CH, cm) - q * CH);
+                        const int first = cR ? (M - q * CH - ccnt) : q * CH;
+                        const double2 v = *reinterpret_cast<const double2*>(stage + pl * RS + 2 * col);
+                        const bool keep = (2 * col < ccnt * NC) && (ctl < TILE) && ((okmask >> (2 * (ctl < TILE ? ctl : 0))) & 1ull);
+                        double* dst = keep ? out + (((size_t)ctl * 3 + ax) * M + first) * NC + 2 * col : a.dummy + 2 * lane;
+                        store_pair(dst, v);
                     }
-            }
-            const int jc = act ? j : 0;
-            const double Tj = Tof(jc);
-            const double itj = fast_rcp(Tj);
-            double* so = &s_out[lane * C::OUT_STRIDE];
-#pragma unroll
-            for (int ax = 0; ax < NAX; ++ax) {
-                const double pj = pos(jc, ax), pj1 = pos(jc + 1, ax);
-                double ys[ND], ye[ND], c8[NC];
-#pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    // original orientation: L: start = knot j, end = knot j+1;  R: start = F knot j+1, end = F knot j
-                    const double fs = ((d & 1) == 0) ? -1.0 : 1.0;
-                    ys[d] = isR ? fs * ynext[d][ax] : y[d][ax];
-                    ye[d] = isR ? fs * y[d][ax] : ynext[d][ax];
+                    wave_lds_sync();  // rows are rewritten by the next unit: keep the reads above it
                 }
-                segment_coeffs<R>(isR ? pj1 : pj, ys, isR ? pj : pj1, ye, Tj, itj, c8);
-                if (act) finite = finite && (fabs(c8[NC - 1]) < INFINITY) && (fabs(c8[R]) < INFINITY);
-#pragma unroll
-                for (int k = 0; k < NC; k += 2) *reinterpret_cast<double2*>(so + ax * NC + k) = make_double2(c8[k], c8[k + 1]);
             }
-            wave_lds_sync();
-            // transpose out: store instruction (ax, ii): lane -> 16-B piece q of the chunk produced by lane pl
-            constexpr int NII = TILE / 8;  // producing lanes / 16
-            double2 v[3][NII];
-#pragma unroll
-            for (int ax = 0; ax < NAX; ++ax)
-#pragma unroll
-                for (int ii = 0; ii < NII; ++ii) {
-                    const int pl = ii * 16 + (lane >> 2), q = lane & 3;
-                    v[ax][ii] = *reinterpret_cast<const double2*>(&s_out[pl * C::OUT_STRIDE + ax * NC + 2 * (q < C::PQ ? q : 0)]);
-                }
-#pragma unroll
-            for (int ax = 0; ax < NAX; ++ax)
-#pragma unroll
-                for (int ii = 0; ii < NII; ++ii) {
-                    const int pl = ii * 16 + (lane >> 2), q = lane & 3;
-                    const int ctl = pl >> 1, cR = pl & 1;
-                    const int cj = (mL == mR || !cR) ? jj : jj - 1;  // own-frame segment of the producing lane
-                    const int seg = cR ? (M - 1 - cj) : cj;
-                    // branch-free: pieces of invalid / padding trajectories go to a scratch line instead
-                    const bool keep = (q < C::PQ) && (cj >= 0) && ((okmask >> (2 * ctl)) & 1ull);
-                    double* dst = keep ? out + (((size_t)ctl * 3 + ax) * M + seg) * NC + 2 * q : a.dummy + 2 * lane;
-                    store_pair(dst, v[ax][ii]);
-                }
-            if (act) {
-#pragma unroll
-                for (int i = 0; i < ND; ++i)
-#pragma unroll
-                    for (int ax = 0; ax < NAX; ++ax) ynext[i][ax] = y[i][ax];
-            }
-        }
         }
         {
             const int f = finite ? 1 : 0;
