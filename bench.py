@@ -45,6 +45,8 @@ def parse():
                          "+40 % trajectories/s at the 4096 batch, but each kernel then shares the GPU and its own duration grows)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl) and run the barrier / all-reduce / all-gather code even at world size 1 (self-test)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child run under rocprofv3: kernels only
     ap.add_argument("--data", default="astar", choices=["astar", "uniform"],
                     help="astar: configs[1] generator; uniform: iid waypoints/times (tuning aid)")
@@ -126,8 +128,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
@@ -166,7 +173,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -186,7 +193,7 @@ def main():
     dt = time.perf_counter() - t0
     # average time one launch occupies its stream (kernel + boundary), from the events of the timed region
     region_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) / max(1, len(range(k, args.steps, S))) for k in range(S)]))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -205,7 +212,7 @@ def main():
     kernel_ms = min(per_launch_ms, region_ms)
 
     gather = None
-    if world > 1 and not args.no_allgather:
+    if use_dist and not args.no_allgather:
         # RCCL all-gather of the solved coefficient shards over xGMI (equal shards)
         full = torch.empty(world * d_out.numel(), dtype=torch.float64, device=dev)
         for _ in range(3):
@@ -224,6 +231,7 @@ def main():
 
     if args.inner:
         return
+    out = None
     if rank == 0:
         bytes_per_traj = W.algorithmic_bytes(r, M)
         achieved = B * bytes_per_traj / (kernel_ms * 1e-3) / 1e9
@@ -258,9 +266,18 @@ def main():
         }
         if gather:
             out["allgather"] = gather
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    if use_dist:
+        dist.destroy_process_group()  # RCCL prints its version banner here: keep the JSON line last
+    if rank == 0:
+        # RCCL (NCCL_DEBUG=VERSION on the GPU boxes) leaves its banner in the C stdio buffer; flush it so that
+        # the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
