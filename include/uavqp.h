@@ -129,6 +129,20 @@ int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj, int unifo
                                     const double* bc, const double* corr_lo, const double* corr_hi,
                                     double* coeff_out, int32_t* status_out, int32_t* iters_out);
 
+/* Time re-allocation step of the outer loop of BASELINE config 5 (north-star extension; the reference uses a
+ * constant 1.0 s per segment, test_minimum_jerk.cpp:65-71, and has no such loop -- nothing to mirror, parity is
+ * per inner solve).  The 3-axis speed |v| and acceleration |a| of the solved polynomials are sampled at
+ * samples_per_seg + 1 uniform points per segment; with rho = max(|v|_peak / v_max, sqrt(|a|_peak / a_max)) over the
+ * whole trajectory, if rho > 1.01 EVERY duration of that trajectory is scaled by min(max_stretch, 1.02 rho)
+ * (never shrunk).  Scaling is per trajectory, not per segment: stretching one segment next to short ones makes
+ * it overshoot more (it inherits their knot acceleration) and diverges; uniform scaling T -> sT lowers speeds
+ * ~1/s and accelerations ~1/s^2.
+ * d_times is updated in place; d_changed_out[b] (may be NULL) receives the number of stretched segments of
+ * trajectory b, so the caller can stop when it is all zero.  Typical loop: solve, reallocate, solve, ... (<= 5x). */
+int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                 double* d_times, const double* d_coeff, double v_max, double a_max,
+                                 int samples_per_seg, double max_stretch, int32_t* d_changed_out);
+
 /* Batched evaluation of solved trajectories on a uniform time grid.
  * Replaces, for a whole batch, PolyTraj::evaluatePos / evaluateVel / evaluateAcc
  * (src/planner/traj_utils/include/traj_utils/poly_traj.hpp:74-168) as driven by poly_traj_server's

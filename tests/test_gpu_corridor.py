@@ -115,3 +115,60 @@ def test_corridor_invalid_box_is_flagged(gpu_ctx):
     lo[2, 2, 1], hi[2, 2, 1] = 1.0, -1.0
     got, st, it = gpu_ctx.solve_corridor_batch_host(3, None, b["waypoints"], b["times"], b["bc"], lo, hi, uniform_segments=4)
     assert st[2] == U.UAVQP_INVALID_INPUT and np.all(np.delete(st, 2) == U.UAVQP_SOLVED)
+
+
+def test_config5_shape_corridor_plus_time_reallocation_outer_loop(oracle):
+    """BASELINE config 5 in miniature: ragged batch + corridors + <= 5 outer time re-allocations, all on device
+    buffers.  No reference behaviour exists for the outer loop (SURVEY.md section 8-a'); checked properties:
+    durations only grow, the loop stops, peak speed / acceleration end within the limits (5 % sampling slack), and
+    the final inner solve is the corridor QP's minimiser for the final time allocation (KKT certificate)."""
+    import torch
+    r, n, v_max, a_max = 4, 96, 7.0, 10.0   # max_velocity / max_accelration of test_kino_astar_searching.launch:49-50
+    b = W.ragged_batch(5, n, r, m_lo=3, m_hi=12)
+    so = b["seg_offsets"]
+    lo, hi = W.corridor_boxes(b, config_index=5)
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_so, d_wp, d_T, d_bc, d_lo, d_hi = up(so), up(b["waypoints"]), up(b["times"]), up(b["bc"]), up(lo), up(hi)
+    d_out = torch.zeros(int(so[-1]) * 24, dtype=torch.float64, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_it = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ch = torch.zeros(n, dtype=torch.int32, device=dev)
+    lib = U.lib()
+    with U.Context(0) as ctx:
+        T_prev = b["times"].copy()
+        outer = 0
+        for outer in range(1, 7):
+            rc = lib.uavqp_solve_corridor_batch_device(ctx._h, r, n, 0, 12, d_so.data_ptr(), d_wp.data_ptr(), d_T.data_ptr(), d_bc.data_ptr(),
+                                                       d_lo.data_ptr(), d_hi.data_ptr(), d_out.data_ptr(), d_st.data_ptr(), d_it.data_ptr())
+            assert rc == 0
+            ctx.time_reallocate_device(r, n, 0, d_so, d_T, d_out, v_max, a_max, samples_per_seg=16, max_stretch=2.0, changed=d_ch)
+            ctx.synchronize()
+            assert bool((d_st == U.UAVQP_SOLVED).all())
+            T_now = d_T.cpu().numpy()
+            assert np.all(T_now >= T_prev * (1 - 1e-15))
+            T_prev = T_now
+            if int(d_ch.sum().item()) == 0:
+                break
+        assert outer <= 6 and int(d_ch.sum().item()) == 0, "time re-allocation did not settle"
+        coef = d_out.cpu().numpy()
+        # limits hold on a finer grid than the one used for the update
+        n_s = 400
+        tot = np.array([T_prev[so[k]:so[k + 1]].sum() for k in range(n)])
+        d_ev = torch.zeros(n * n_s * 6, dtype=torch.float64, device=dev)
+        for k_dt in (tot.max() / (n_s - 1),):
+            ctx.eval_batch_device(r, n, 0, d_so, d_T, d_out, n_s, 0.0, float(k_dt), 6, d_ev)
+            ctx.synchronize()
+            ev = d_ev.cpu().numpy().reshape(n, n_s, 2, 3)
+            assert np.max(np.linalg.norm(ev[:, :, 0], axis=2)) <= 1.05 * v_max
+            assert np.max(np.linalg.norm(ev[:, :, 1], axis=2)) <= 1.05 * a_max
+    # final inner solve is optimal for the final allocation
+    wp = np.asarray(b["waypoints"])
+    for k in range(0, n, 11):
+        M = so[k + 1] - so[k]
+        for ax in range(3):
+            c = coef[24 * so[k]:24 * so[k + 1]].reshape(3, 8 * M)[ax]
+            prim, stat, comp = kkt_certificate(oracle, r, M, T_prev[so[k]:so[k + 1]], c, wp[so[k] + k:so[k + 1] + k + 1, ax],
+                                               b["bc"][k, 0, :, ax], b["bc"][k, 1, :, ax],
+                                               lo[so[k] + k + 1:so[k + 1] + k, ax], hi[so[k] + k + 1:so[k + 1] + k, ax])
+            assert prim < 1e-9 and stat < 1e-7 and comp < 1e-6

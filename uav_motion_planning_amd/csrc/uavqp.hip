@@ -285,6 +285,61 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Time re-allocation: one lane per segment; peak |v|, |a| by sampling, stretch-only update of T.
+// ---------------------------------------------------------------------------------------------------
+struct ReallocArgs {
+    int n_traj, uniform, total_seg, samples;
+    const int32_t* seg_offsets;
+    double* times;
+    const double* coeff;
+    double v_max, a_max, max_stretch;
+    int32_t* changed;
+};
+
+template <int R>
+__global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
+    // One lane per trajectory: the whole trajectory is scaled by ONE factor.  (Stretching single segments
+    // diverges: a long segment next to short ones inherits their knot acceleration and overshoots more the
+    // longer it gets; under uniform scaling T -> sT speeds drop ~1/s and accelerations ~1/s^2.)
+    constexpr int NC = 2 * R;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.n_traj; b += gridDim.x * blockDim.x) {
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        double v2 = 0.0, a2 = 0.0;
+        for (int i = 0; i < M; ++i) {
+            const double T = a.times[s0 + i];
+            const double* __restrict__ c = a.coeff + (size_t)3 * NC * s0 + (size_t)i * NC;
+            for (int s = 0; s <= a.samples; ++s) {
+                const double t = T * (double)s / (double)a.samples;
+                double vs = 0.0, as = 0.0;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double* ca = c + (size_t)ax * NC * M;
+                    double v = 0.0, ac = 0.0;
+#pragma unroll
+                    for (int j = NC - 1; j >= 1; --j) v = fma(v, t, (double)j * ca[j]);
+#pragma unroll
+                    for (int j = NC - 1; j >= 2; --j) ac = fma(ac, t, (double)(j * (j - 1)) * ca[j]);
+                    vs += v * v;
+                    as += ac * ac;
+                }
+                v2 = fmax(v2, vs);
+                a2 = fmax(a2, as);
+            }
+        }
+        const double ratio = fmax(sqrt(v2) / a.v_max, sqrt(sqrt(a2) / a.a_max));
+        int ch = 0;
+        // 1 % dead band and 2 % overshoot so that the loop settles instead of creeping towards the limit
+        if (ratio > 1.01 && ratio < INFINITY) {
+            const double s = fmin(1.02 * ratio, a.max_stretch);
+            for (int i = 0; i < M; ++i) a.times[s0 + i] *= s;
+            ch = M;
+        }
+        if (a.changed) a.changed[b] = ch;
+    }
+}
+
 }  // namespace uavqp
 
 #include "qp_twisted.h"
@@ -734,5 +789,29 @@ extern "C" int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj
     if (status_out) UAVQP_HIP(hipMemcpyAsync(status_out, d_st, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
     if (iters_out) UAVQP_HIP(hipMemcpyAsync(iters_out, d_it, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
     UAVQP_HIP(hipStreamSynchronize(s));
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                            double* d_times, const double* d_coeff, double v_max, double a_max,
+                                            int samples_per_seg, double max_stretch, int32_t* d_changed_out) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0 || !(v_max > 0.0) || !(a_max > 0.0) ||
+        samples_per_seg < 1 || !(max_stretch > 1.0))
+        return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!d_times || !d_coeff || (uniform_segments == 0 && !d_seg_offsets)) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    const int total_seg = 0;  // (unused: one lane per trajectory)
+    uavqp::ReallocArgs a;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.total_seg = total_seg; a.samples = samples_per_seg;
+    a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.v_max = v_max; a.a_max = a_max;
+    a.max_stretch = max_stretch; a.changed = d_changed_out;
+    int grid = (n_traj + 63) / 64;
+    if (grid > ctx->num_cus * 16) grid = ctx->num_cus * 16;
+    if (r == 3)
+        hipLaunchKernelGGL(uavqp::realloc_kernel<3>, dim3(grid), dim3(64), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(uavqp::realloc_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
+    UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }

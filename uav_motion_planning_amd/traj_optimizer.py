@@ -69,6 +69,15 @@ class Context:
                                                 n_samples, float(t0), float(dt), int(what), p(out))
         _lib.check(rc, "uavqp_eval_batch_device")
 
+    def time_reallocate_device(self, r, n_traj, uniform_segments, seg_offsets, times, coeff, v_max, a_max,
+                               samples_per_seg=16, max_stretch=1.5, changed=None):
+        """One stretch-only time re-allocation step (device buffers, `times` updated in place)."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_time_reallocate_device(self._h, r, n_traj, uniform_segments, p(seg_offsets), p(times), p(coeff),
+                                                     float(v_max), float(a_max), int(samples_per_seg), float(max_stretch), p(changed))
+        _lib.check(rc, "uavqp_time_reallocate_device")
+
     def capture_begin(self):
         """Start hipGraph capture of everything subsequently enqueued on the ctx stream."""
         _lib.check(_lib.lib().uavqp_capture_begin(self._h), "uavqp_capture_begin")
