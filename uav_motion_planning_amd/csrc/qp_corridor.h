@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64) void solve_corridor_kernel(CorridorArgs a) {
         pin = eqmask;
 
         int it = 0;
+        int pdas_left = 3;  // PDAS_ITERS (measured on config 3: 3 rounds 13.8 mean iterations, 0 rounds 17.5, 10 rounds 15.7)
         bool converged = (M == 1);
         bool final_pass = false;  // max_iter hit: one last solve with every position pinned at the feasible iterate
         while (!converged) {
@@ -227,6 +228,71 @@ __global__ __launch_bounds__(64) void solve_corridor_kernel(CorridorArgs a) {
                 }
             }
             if (final_pass) break;
+
+            // ================= block-pivoting warm-up (primal-dual active set) =================
+            // The first iterations change the whole working set at once: every free position outside its box is
+            // pinned at the violated bound, every pinned one whose multiplier has the wrong sign is released.
+            // It usually identifies the active set in 2-3 solves (vs one change per solve) but is not monotone, so
+            // after PDAS_ITERS rounds the safe single-pivot method below takes over from the clipped (feasible) point.
+            if (pdas_left > 0) {
+                unsigned long long npin = eqmask, nupper = 0ull;
+                {
+                    FullBlocks<R> sa;
+                    sa.build(T[0]);
+                    for (int k = 1; k < M; ++k) {
+                        FullBlocks<R> sb;
+                        sb.build(T[k]);
+                        const double l = lo[3 * k], h = hi[3 * k];
+                        if ((eqmask >> k) & 1ull) {
+                        } else if ((pin >> k) & 1ull) {
+                            double lam = 0.0, mag = 0.0;
+#pragma unroll
+                            for (int c = 0; c < R; ++c) {
+                                const double xp = (k == 1) ? x0[c] : W(k - 1, F_X + c);
+                                const double xk = W(k, F_X + c);
+                                const double xq = (k == M - 1) ? xM[c] : W(k + 1, F_X + c);
+                                const double t1 = sa.B01[c][0] * xp, t2 = (sa.B11[0][c] + sb.B00(0, c)) * xk, t3 = sb.B01[0][c] * xq;
+                                lam += t1 + t2 + t3;
+                                mag += fabs(t1) + fabs(t2) + fabs(t3);
+                            }
+                            const bool up = (upper >> k) & 1ull;
+                            const double viol = up ? lam : -lam;
+                            if (!(viol > 1e-11 * mag)) {  // multiplier has the right sign: stays active
+                                npin |= 1ull << k;
+                                if (up) nupper |= 1ull << k;
+                            }
+                        } else {
+                            const double ph = W(k, F_X);
+                            if (ph < l - 1e-12 * (1.0 + fabs(l))) npin |= 1ull << k;
+                            else if (ph > h + 1e-12 * (1.0 + fabs(h))) { npin |= 1ull << k; nupper |= 1ull << k; }
+                        }
+                        sa = sb;
+                    }
+                }
+                ++it;
+                if (npin == pin && nupper == upper) {
+                    // KKT point: free positions feasible, all multipliers right
+                    for (int k = 1; k < M; ++k)
+                        if (!((pin >> k) & 1ull)) W(k, F_Z) = W(k, F_X);
+                    converged = true;
+                    continue;
+                }
+                --pdas_left;
+                for (int k = 1; k < M; ++k) {
+                    const double l = lo[3 * k], h = hi[3 * k];
+                    if ((npin >> k) & 1ull) {
+                        if (!((eqmask >> k) & 1ull)) W(k, F_Z) = ((nupper >> k) & 1ull) ? h : l;
+                    } else {
+                        // keep a feasible iterate for the safe phase: clip the subspace minimiser
+                        double z = W(k, F_X);
+                        W(k, F_Z) = z < l ? l : (z > h ? h : z);
+                    }
+                }
+                pin = npin;
+                upper = nupper;
+                if (it >= a.max_iter) { pin = ~0ull; final_pass = true; }
+                continue;
+            }
 
             // ================= ratio test on the free positions =================
             double alpha = 1.0;
