@@ -59,3 +59,28 @@ def test_shard_bounds():
     sl = D.local_slice(b, bounds[2], bounds[3])
     assert sl["seg_offsets"][0] == 0 and sl["times"].size == sl["seg_offsets"][-1]
     assert sl["waypoints"].shape[0] == sl["seg_offsets"][-1] + (bounds[3] - bounds[2])
+
+
+def test_adapters_flatten_paths_and_empty_rrt_star_path():
+    from uav_motion_planning_amd import adapters as A
+    paths = [np.arange(12.0).reshape(4, 3), np.zeros((0, 3)), np.ones((1, 3)), np.arange(6.0).reshape(2, 3)]
+    f = A.flatten_paths(paths)                      # H8: empty / single-point paths are skipped, not solved
+    assert list(f["kept"]) == [0, 3] and list(f["seg_offsets"]) == [0, 3, 4]
+    assert f["waypoints"].shape == (6, 3) and np.all(f["times"] == 1.0)
+    g = A.flatten_paths(paths[:1], durations=[[0.3, 0.3, 1.2]])
+    assert list(g["times"]) == [0.3, 0.3, 1.2]
+    bc = A.boundary_from_odometry(2, 4, start_velocity=[[1, 2, 3], [4, 5, 6]])
+    assert bc.shape == (2, 2, 3, 3) and np.all(bc[:, 1] == 0) and list(bc[1, 0, 0]) == [4, 5, 6]
+
+
+def test_polynomial_trajectory_packer_round_trip():
+    from uav_motion_planning_amd import adapters as A
+    r, m = 3, 4
+    c = np.arange(3 * m * 2 * r, dtype=np.float64)
+    msg = A.pack_polynomial_trajectory(c, [1.0, 2.0, 0.5, 1.5], r, trajectory_id=7)
+    assert (msg["num_order"], msg["num_segment"], msg["action"], msg["trajectory_id"]) == (5, 4, 1, 7)
+    segs = A.unpack_like_traj_server(msg)           # poly_traj_server.cpp:66-78 indexing
+    cc = c.reshape(3, m, 2 * r)
+    for i, (cx, cy, cz, t) in enumerate(segs):
+        assert np.array_equal(cx, cc[0, i]) and np.array_equal(cy, cc[1, i]) and np.array_equal(cz, cc[2, i])
+    assert [s[3] for s in segs] == [1.0, 2.0, 0.5, 1.5]
