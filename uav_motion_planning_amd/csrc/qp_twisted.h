@@ -330,23 +330,24 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
         if constexpr (LPT == 8) {
             // one axis per lane pair: coefficients go straight from registers to HBM (4 x 16 B per segment);
             // at the batch sizes this shape is used for, store efficiency is irrelevant, latency is not.
+            // Back-substitution first (in place, h[j] <- y_j), so that the mL segment evaluations below are
+            // independent of each other and the scheduler can overlap their dependent FP64 chains.
 #pragma unroll
-            for (int jj = mL - 1; jj >= 0; --jj) {
-                const int j = (mL == mR || !isR) ? jj : jj - 1;
-                const bool act = (j >= 0);
-                double y[ND];
-#pragma unroll
-                for (int i = 0; i < ND; ++i) y[i] = (mL == mR || !isR) ? h[jj][i][0] : h[jj > 0 ? jj - 1 : 0][i][0];
-                if (jj > 0 || mL != mR) {
+            for (int j = mL - 1; j >= 1; --j) {
+                if (j < m) {
 #pragma unroll
                     for (int i = 0; i < ND; ++i)
 #pragma unroll
                         for (int c = 0; c < ND; ++c) {
-                            const double e = (mL == mR || !isR) ? E[jj][i][c] : E[jj > 0 ? jj - 1 : 0][i][c];
-                            y[i] -= e * ynext[c][0];
+                            const double src = (j == mL - 1 || j == m - 1) ? ynext[c][0] : h[j + 1 < mL ? j + 1 : j][c][0];
+                            h[j][i][0] -= E[j][i][c] * src;
                         }
                 }
-                const int jc = act ? j : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < mL; ++j) {
+                const bool act = (j < m);
+                const int jc = act ? j : (m > 0 ? m - 1 : 0);
                 const double Tj = Tof(jc);
                 const double itj = fast_rcp(Tj);
                 const double pj = pos(jc, 0), pj1 = pos(jc + 1, 0);
@@ -354,8 +355,10 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
                     const double fs = ((d & 1) == 0) ? -1.0 : 1.0;
-                    ys[d] = isR ? fs * ynext[d][0] : y[d];
-                    ye[d] = isR ? fs * y[d] : ynext[d][0];
+                    const double yj = h[j][d][0];
+                    const double yj1 = (j + 1 >= mL || j + 1 == m) ? ynext[d][0] : h[j + 1 < mL ? j + 1 : j][d][0];
+                    ys[d] = isR ? fs * yj1 : yj;
+                    ye[d] = isR ? fs * yj : yj1;
                 }
                 segment_coeffs<R>(isR ? pj1 : pj, ys, isR ? pj : pj1, ye, Tj, itj, c8);
                 if (act) finite = finite && (fabs(c8[NC - 1]) < INFINITY) && (fabs(c8[R]) < INFINITY);
@@ -364,10 +367,6 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                     double* dst = out + (((size_t)tlc * 3 + ax0) * M + seg) * NC;
 #pragma unroll
                     for (int k = 0; k < NC; k += 2) store_pair(dst + k, make_double2(c8[k], c8[k + 1]));
-                }
-                if (act) {
-#pragma unroll
-                    for (int i = 0; i < ND; ++i) ynext[i][0] = y[i];
                 }
             }
         } else {
