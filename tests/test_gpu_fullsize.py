@@ -114,3 +114,56 @@ def test_empty_batch_and_single_segment(gpu_ctx, oracle):
     got, st = gpu_ctx.solve_batch_host(4, None, b["waypoints"], b["times"], b["bc"], uniform_segments=1)
     ref, _ = oracle.solve_exact_batch(4, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
     assert np.all(st == U.UAVQP_SOLVED) and np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
+
+
+def test_quarter_million_batch_throughput_shape_agrees_with_generic(gpu_ctx):
+    """262 144 trajectories (64 x the benchmark batch) through the throughput shape (32 trajectories / wave,
+    persistent tiles, LDS-DMA prefetch across tiles): continuity / interpolation everywhere and agreement with
+    the generic lane-per-trajectory kernel on the whole batch."""
+    r, M, n = 4, 8, 262144
+    b = W.uniform_batch(2, n, M, r, time_mode="distance", seed=4242)
+    gpu_ctx.set_variant(32)
+    coef, st = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    gpu_ctx.set_variant(1)
+    coef1, st1 = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    gpu_ctx.set_variant(0)
+    assert np.all(st == U.UAVQP_SOLVED) and np.all(st1 == U.UAVQP_SOLVED)
+    check_continuity_and_interpolation(coef, b, r, M, 1e-9)
+    c = coef.reshape(n, -1)
+    c1 = coef1.reshape(n, -1)
+    rel = np.max(np.abs(c - c1), axis=1) / np.max(np.abs(c1), axis=1)
+    assert rel.max() < 1e-10
+
+
+@pytest.mark.parametrize("variant", [0, 1, 8, 32])
+def test_non_finite_waypoints_and_extreme_allocations(gpu_ctx, variant):
+    """NaN / inf waypoints give UAVQP_NON_FINITE for that trajectory only; time ratios of 1:200 inside one
+    trajectory still solve (they arise in re-allocation loops)."""
+    r, M, n = 4, 8, 40
+    b = W.uniform_batch(9, n, M, r, time_mode="distance")
+    wp = b["waypoints"].copy()
+    wp[3, 4, 1] = np.nan
+    wp[17, 0, 2] = np.inf
+    T = b["times"].copy()
+    T[5] = [0.3, 0.3, 0.3, 60.0, 0.3, 0.3, 60.0, 0.3]
+    gpu_ctx.set_variant(variant)
+    coef, st = gpu_ctx.solve_batch_host(r, None, wp, T, b["bc"], uniform_segments=M)
+    gpu_ctx.set_variant(0)
+    assert st[3] == U.UAVQP_NON_FINITE and st[17] == U.UAVQP_NON_FINITE
+    good = np.ones(n, dtype=bool)
+    good[[3, 17]] = False
+    assert np.all(st[good] == U.UAVQP_SOLVED)
+    c = coef.reshape(n, -1)
+    assert np.all(np.isfinite(c[good]))
+    sub = dict(waypoints=wp[good], times=T[good], bc=b["bc"][good])
+    check_continuity_and_interpolation(c[good].ravel(), sub, r, M, 1e-8)
+
+
+def test_long_trajectories_generic_path(gpu_ctx, oracle):
+    """M = 40 and 63 segments (beyond every specialised instantiation; SURVEY section 5 'long dimension')."""
+    for M in (40, 63):
+        b = W.uniform_batch(11, 6, M, 3, time_mode="distance")
+        got, st = gpu_ctx.solve_batch_host(3, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+        ref, _ = oracle.solve_exact_batch(3, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+        assert np.all(st == U.UAVQP_SOLVED)
+        assert np.max(np.abs(got - ref)) < 1e-8 * np.max(np.abs(ref))
