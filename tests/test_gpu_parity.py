@@ -74,3 +74,28 @@ def test_invalid_inputs_are_flagged_not_fatal(gpu_ctx, variant):
     assert list(st[[2, 5, 6]]) == [UAVQP_INVALID_INPUT] * 3
     assert np.all(np.delete(st, [2, 5, 6]) == UAVQP_SOLVED)
     assert np.all(np.isfinite(got))
+
+
+def test_randomised_shapes_and_variants_vs_oracle(gpu_ctx, oracle):
+    """Seeded fuzz over (r, M, batch size, time allocation, kernel variant, ragged or uniform): 30 draws."""
+    rng = np.random.default_rng(20260925)
+    for draw in range(30):
+        r = int(rng.choice([3, 4]))
+        ragged = bool(rng.integers(0, 2))
+        n = int(rng.integers(1, 70))
+        if ragged:
+            b = W.ragged_batch(draw, n, r, m_lo=1, m_hi=int(rng.integers(2, 20)), seed=1000 + draw)
+            b["times"] = b["times"] * rng.uniform(0.5, 3.0, size=b["times"].shape)
+            got, st = gpu_ctx.solve_batch_host(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+        else:
+            M = int(rng.integers(1, 18))
+            b = W.uniform_batch(draw, n, M, r, time_mode=str(rng.choice(["reference", "distance", "wide"])), seed=2000 + draw)
+            b["bc"] = rng.uniform(-2.0, 2.0, size=b["bc"].shape)       # all boundary derivatives non-zero
+            gpu_ctx.set_variant(int(rng.choice([0, 1, 2, 8, 16, 32])) if (2 <= M <= 12 and M != 11) else int(rng.choice([0, 1])))
+            got, st = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+            gpu_ctx.set_variant(0)
+        ref, _ = oracle.solve_exact_batch(r, b["seg_offsets"], np.asarray(b["waypoints"]).reshape(-1, 3),
+                                          np.asarray(b["times"]).reshape(-1), b["bc"])
+        assert np.all(st == UAVQP_SOLVED), (draw, st)
+        err = rel_err_per_traj(got, ref, b["seg_offsets"], r)
+        assert err.max() < 1e-7, (draw, r, ragged, err.max())

@@ -511,9 +511,11 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     a.dummy = ctx->dummy;
 
     if (uniform_segments > 0 && ctx->variant != 1) {
-        // small batches: half-wave tiles (16 trajectories) spread the launch over twice as many CUs --
-        // one CU moves only ~10 B/clk, so a 4096-trajectory batch needs all 256 of them
-        int tile = (n_traj <= 16 * ctx->num_cus) ? 8 : 32;
+        // Tile shape by batch size (measured on MI355X, 8-segment snap, us per launch for tiles 8 / 16 / 32:
+        // 4096: 6.0 / 7.5 / 8.2   8192: 8.7 / 8.5 / 9.4   16384: 14.1 / 9.7 / 10.0   32768: 23.8 / 17.5 / 12.6).
+        // One CU moves only ~10 B/clk, so a small batch is spread over all 256 CUs with fewer trajectories per
+        // wave; a large one wants the full-wave shape that does the least redundant work.
+        int tile = (n_traj <= 28 * ctx->num_cus) ? 8 : (n_traj <= 72 * ctx->num_cus ? 16 : 32);
         if (ctx->tile_override) tile = ctx->tile_override;
         uavqp::twisted_fn fn = uavqp::find_twisted(r, uniform_segments, tile);
         if (fn) {
