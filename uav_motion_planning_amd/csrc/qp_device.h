@@ -134,6 +134,49 @@ struct SmallLDL {
     }
 };
 
+// Explicit inverse of a small SPD matrix by cofactors (only the lower triangle of S is read): ONE reciprocal
+// (of the determinant) instead of N dependent pivots -- a much shorter dependency chain than LDL', which is
+// what matters when a single wave per SIMD runs the elimination (latency shape).  Cofactor expansion is
+// invariant under symmetric diagonal scaling, so the badly scaled T^-5..T^-1 entries do not hurt; the
+// blocks themselves are well conditioned after scaling (checked by the parity tests at 1e-9).
+template <int N>
+struct SymInv;
+template <>
+struct SymInv<2> {
+    double i00, i10, i11;
+    __device__ __forceinline__ void factor(const double (&S)[2][2]) {
+        const double det = S[0][0] * S[1][1] - S[1][0] * S[1][0];
+        const double r = fast_rcp(det);
+        i00 = S[1][1] * r;
+        i10 = -S[1][0] * r;
+        i11 = S[0][0] * r;
+    }
+    __device__ __forceinline__ void solve(double (&x)[2]) const {
+        const double a = x[0], b = x[1];
+        x[0] = i00 * a + i10 * b;
+        x[1] = i10 * a + i11 * b;
+    }
+};
+template <>
+struct SymInv<3> {
+    double i00, i10, i11, i20, i21, i22;
+    __device__ __forceinline__ void factor(const double (&S)[3][3]) {
+        const double a = S[0][0], b = S[1][0], c = S[2][0], d = S[1][1], e = S[2][1], f = S[2][2];
+        const double c00 = d * f - e * e, c10 = c * e - b * f, c20 = b * e - c * d;
+        const double c11 = a * f - c * c, c21 = b * c - a * e, c22 = a * d - b * b;
+        const double det = a * c00 + b * c10 + c * c20;
+        const double r = fast_rcp(det);
+        i00 = c00 * r; i10 = c10 * r; i20 = c20 * r;
+        i11 = c11 * r; i21 = c21 * r; i22 = c22 * r;
+    }
+    __device__ __forceinline__ void solve(double (&x)[3]) const {
+        const double a = x[0], b = x[1], c = x[2];
+        x[0] = i00 * a + i10 * b + i20 * c;
+        x[1] = i10 * a + i11 * b + i21 * c;
+        x[2] = i20 * a + i21 * b + i22 * c;
+    }
+};
+
 // Monomial coefficients (ascending powers, segment-local time: the reference's coef_1d_ layout,
 // minimum_control.cpp:186) of one segment of one axis from its Hermite data.
 //   ys / ye : derivatives 1..R-1 at the segment start / end;  p0 / p1 : positions.

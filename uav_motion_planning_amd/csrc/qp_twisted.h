@@ -15,6 +15,8 @@
 //     global_store_dwordx4 writes whole 2r-coefficient chunks from adjacent lanes.
 // HBM traffic is therefore exactly the algorithmic bytes.
 #pragma once
+#include <type_traits>
+
 #include "qp_device.h"
 
 #ifdef UAVQP_PHASE_TIMING
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
 #pragma unroll
                         for (int ax = 0; ax < NAX; ++ax) z[i][ax] -= sa.A01[q][i] * h[j - 1][q][ax];
                     }
-                SmallLDL<ND> ldl;
+                typename std::conditional<LPT == 8, SymInv<ND>, SmallLDL<ND>>::type ldl;
                 ldl.factor(S);
 #pragma unroll
                 for (int ax = 0; ax < NAX; ++ax) {
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
 #pragma unroll
                 for (int c = i + 1; c < ND; ++c) S[i][c] = 0.0;  // upper triangle is never read
             }
-            SmallLDL<ND> ldl;
+            typename std::conditional<LPT == 8, SymInv<ND>, SmallLDL<ND>>::type ldl;
             ldl.factor(S);
 #pragma unroll
             for (int ax = 0; ax < NAX; ++ax) {
