@@ -17,7 +17,7 @@ CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "kkt_exact.json")))
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-@pytest.mark.parametrize("variant", [0, 1, 8])
+@pytest.mark.parametrize("variant", [0, 1, 8, 64])
 def test_golden_fixture_through_c_abi(gpu_ctx, case, variant):
     """Tolerance: 1e-10 relative to max|coef| per axis (float64 direct solve vs exact rationals);
     the north star's budget is 1e-5."""

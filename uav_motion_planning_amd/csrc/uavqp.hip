@@ -343,6 +343,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 }  // namespace uavqp
 
 #include "qp_twisted.h"
+#include "qp_phased.h"
 #include "qp_corridor.h"
 
 namespace uavqp {
@@ -360,6 +361,12 @@ static twisted_fn find_twisted(int r, int M, int tile) {
     UAVQP_CASE(3, 2) UAVQP_CASE(3, 3) UAVQP_CASE(3, 4) UAVQP_CASE(3, 5) UAVQP_CASE(3, 6) UAVQP_CASE(3, 7)
     UAVQP_CASE(3, 8) UAVQP_CASE(3, 10) UAVQP_CASE(3, 12) UAVQP_CASE(3, 16)
 #undef UAVQP_CASE
+    return nullptr;
+}
+static twisted_fn find_phased(int r, int M) {
+#define UAVQP_PCASE(RR, MM) if (r == RR && M == MM) return &solve_phased_kernel<RR, MM>;
+    UAVQP_PCASE(4, 4) UAVQP_PCASE(4, 8) UAVQP_PCASE(3, 4) UAVQP_PCASE(3, 8) UAVQP_PCASE(3, 16)
+#undef UAVQP_PCASE
     return nullptr;
 }
 }  // namespace uavqp
@@ -433,7 +440,7 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
     }
     if (const char* e = std::getenv("UAVQP_TILE")) {
         const int t = std::atoi(e);
-        if (t == 8 || t == 16 || t == 32) ctx->tile_override = t;
+        if (t == 8 || t == 16 || t == 32 || t == 64) ctx->tile_override = t;
     }
     *out_ctx = ctx;
     return UAVQP_OK;
@@ -465,7 +472,7 @@ extern "C" int uavqp_synchronize(uavqp_ctx* ctx) {
 
 extern "C" int uavqp_set_variant(uavqp_ctx* ctx, int variant) {
     if (!ctx) return UAVQP_ERR_INVALID_ARG;
-    if (variant == 8 || variant == 16 || variant == 32) {  // specialised kernel with a fixed tile shape
+    if (variant == 8 || variant == 16 || variant == 32 || variant == 64) {  // specialised kernel with a fixed tile shape
         ctx->variant = 2;
         ctx->tile_override = variant;
         return UAVQP_OK;
@@ -517,6 +524,18 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
         // wave; a large one wants the full-wave shape that does the least redundant work.
         int tile = (n_traj <= 28 * ctx->num_cus) ? 8 : (n_traj <= 72 * ctx->num_cus ? 16 : 32);
         if (ctx->tile_override) tile = ctx->tile_override;
+        if (tile == 64) {  // phase-split workgroup kernel (16 trajectories per 256-thread workgroup)
+            uavqp::twisted_fn pf = uavqp::find_phased(r, uniform_segments);
+            if (pf) {
+                a.ws = nullptr;
+                const int n_tiles = (n_traj + 15) / 16;
+                const int g = n_tiles < ctx->num_cus * 4 ? n_tiles : ctx->num_cus * 4;
+                hipLaunchKernelGGL(pf, dim3(g), dim3(256), 0, ctx->stream, a);
+                UAVQP_HIP(hipGetLastError());
+                return UAVQP_OK;
+            }
+            tile = 8;
+        }
         uavqp::twisted_fn fn = uavqp::find_twisted(r, uniform_segments, tile);
         if (fn) {
             a.ws = nullptr;
