@@ -67,6 +67,10 @@ def test_adapters_flatten_paths_and_empty_rrt_star_path():
     f = A.flatten_paths(paths)                      # H8: empty / single-point paths are skipped, not solved
     assert list(f["kept"]) == [0, 3] and list(f["seg_offsets"]) == [0, 3, 4]
     assert f["waypoints"].shape == (6, 3) and np.all(f["times"] == 1.0)
+    s = A.flatten_paths(paths, sort_by_segments=True)
+    assert list(s["kept"]) == [0, 3] and list(s["seg_offsets"]) == [0, 3, 4]
+    s2 = A.flatten_paths([paths[3], paths[0]], sort_by_segments=True)
+    assert list(s2["kept"]) == [1, 0] and list(s2["seg_offsets"]) == [0, 3, 4]
     g = A.flatten_paths(paths[:1], durations=[[0.3, 0.3, 1.2]])
     assert list(g["times"]) == [0.3, 0.3, 1.2]
     bc = A.boundary_from_odometry(2, 4, start_velocity=[[1, 2, 3], [4, 5, 6]])

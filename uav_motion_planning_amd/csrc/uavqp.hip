@@ -87,13 +87,27 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
             dpa[ax] = pb[ax] - wp[ax];
         }
         double Eprev[ND][ND], hprev[ND][3];
+        // software prefetch: the loads of step k+1 are issued before the arithmetic of step k (one lane per
+        // trajectory has nothing else to hide an HBM round trip per knot behind)
+        double Tn = M > 1 ? T[1] : 1.0, pn[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) pn[ax] = M > 1 ? wp[6 + ax] : 0.0;
         for (int k = 1; k < M; ++k) {
+            const double Tk_ = Tn;
+            double pcur[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) pcur[ax] = pn[ax];
+            if (k + 1 < M) {
+                Tn = T[k + 1];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) pn[ax] = wp[3 * (k + 2) + ax];
+            }
             SegBlocks<R> sb;
-            sb.build(T[k]);
+            sb.build(Tk_);
             double dpb[3];
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-                const double pc = wp[3 * (k + 1) + ax];
+                const double pc = pcur[ax];
                 dpb[ax] = pc - pb[ax];
                 pb[ax] = pc;
             }
@@ -173,7 +187,33 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
 #pragma unroll
             for (int d = 0; d < ND; ++d) ynext[d][ax] = yM[d][ax];
         }
+        // software prefetch of the sweep state of knot k-1 (and of T, waypoint) while knot k is processed
+        double wn[F], Tkn = T[M - 1], pkn[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) pkn[ax] = wp[3 * (M - 1) + ax];
+        if (M >= 2) {
+            const double* w = ws + (size_t)(M - 2) * F * wstride;
+#pragma unroll
+            for (int f = 0; f < F; ++f) wn[f] = w[(size_t)f * wstride];
+        }
         for (int k = M - 1; k >= 0; --k) {
+            double wc[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) wc[f] = wn[f];
+            const double Tk = Tkn;
+            double pkc[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) pkc[ax] = pkn[ax];
+            if (k >= 1) {
+                Tkn = T[k - 1];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) pkn[ax] = wp[3 * (k - 1) + ax];
+                if (k >= 2) {
+                    const double* w = ws + (size_t)(k - 2) * F * wstride;
+#pragma unroll
+                    for (int f = 0; f < F; ++f) wn[f] = w[(size_t)f * wstride];
+                }
+            }
             double y[ND][3];
             if (k == 0) {
 #pragma unroll
@@ -181,26 +221,25 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
 #pragma unroll
                     for (int ax = 0; ax < 3; ++ax) y[d][ax] = y0[d][ax];
             } else {
-                const double* w = ws + (size_t)(k - 1) * F * wstride;
 #pragma unroll
                 for (int i = 0; i < ND; ++i)
 #pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) y[i][ax] = w[(size_t)(ND * ND + i * 3 + ax) * wstride];
+                    for (int ax = 0; ax < 3; ++ax) y[i][ax] = wc[ND * ND + i * 3 + ax];
                 if (k < M - 1) {
 #pragma unroll
                     for (int i = 0; i < ND; ++i)
 #pragma unroll
                         for (int c = 0; c < ND; ++c) {
-                            const double e = w[(size_t)(i * ND + c) * wstride];
+                            const double e = wc[i * ND + c];
 #pragma unroll
                             for (int ax = 0; ax < 3; ++ax) y[i][ax] -= e * ynext[c][ax];
                         }
                 }
             }
-            const double Tk = T[k], itk = 1.0 / Tk;
+            const double itk = 1.0 / Tk;
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-                const double pk = wp[3 * k + ax];
+                const double pk = pkc[ax];
                 double ys[ND], ye[ND], c[NC];
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
