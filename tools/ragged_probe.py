@@ -7,13 +7,16 @@ dev = torch.device("cuda", 0); s = torch.cuda.Stream(device=dev); torch.cuda.set
 ctx = U.Context(0); ctx.set_stream(s.cuda_stream)
 up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 r, n = 4, 32768
-# uniform M = 14 through the generic kernel
+# uniform M = 14 (and 24) through the generic kernel
 b = W.uniform_batch(4, n, 14, r, time_mode="distance")
 d = {k: up(b[k]) for k in ("waypoints", "times", "bc")}
 out = torch.zeros(n * 3 * 14 * 8, dtype=torch.float64, device=dev); st = torch.zeros(n, dtype=torch.int32, device=dev)
 ctx.set_variant(1)
 ms = timeit(lambda: ctx.solve_batch_device(r, n, 14, 14, None, d["waypoints"], d["times"], d["bc"], out, st), s)
 print("uniform M=14 generic: %.1f us" % (ms * 1e3))
+b24 = W.uniform_batch(4, n, 24, r, time_mode="distance"); d24 = {k: up(b24[k]) for k in ("waypoints", "times", "bc")}; out24 = torch.zeros(n * 3 * 24 * 8, dtype=torch.float64, device=dev)
+ms = timeit(lambda: ctx.solve_batch_device(r, n, 24, 24, None, d24["waypoints"], d24["times"], d24["bc"], out24, st), s)
+print("uniform M=24 generic: %.1f us" % (ms * 1e3))
 # ragged, as is, and pre-sorted by M on the host
 b = W.ragged_batch(4, n, r); so = b["seg_offsets"]; Ms = np.diff(so)
 def run(bb, tag):

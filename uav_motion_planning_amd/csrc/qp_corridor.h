@@ -209,16 +209,27 @@ __global__ __launch_bounds__(64) void solve_corridor_kernel(CorridorArgs a) {
                     }
                     sa = sb;
                 }
-                double xn[R];
+                // backward sweep; the state of knot k-1 is fetched while knot k is processed (one lane per
+                // (trajectory, axis) has nothing else to hide an HBM round trip per knot behind)
+                double xn[R], nx[R + R * R];
+#pragma unroll
+                for (int f = 0; f < R + R * R; ++f) nx[f] = W(M - 1, f < R ? F_H + f : F_E + (f - R));
                 for (int k = M - 1; k >= 1; --k) {
+                    double cur[R + R * R];
+#pragma unroll
+                    for (int f = 0; f < R + R * R; ++f) cur[f] = nx[f];
+                    if (k >= 2) {
+#pragma unroll
+                        for (int f = 0; f < R + R * R; ++f) nx[f] = W(k - 1, f < R ? F_H + f : F_E + (f - R));
+                    }
                     double x[R];
 #pragma unroll
-                    for (int i = 0; i < R; ++i) x[i] = W(k, F_H + i);
+                    for (int i = 0; i < R; ++i) x[i] = cur[i];
                     if (k < M - 1) {
 #pragma unroll
                         for (int i = 0; i < R; ++i)
 #pragma unroll
-                            for (int c = 0; c < R; ++c) x[i] -= W(k, F_E + i * R + c) * xn[c];
+                            for (int c = 0; c < R; ++c) x[i] -= cur[R + i * R + c] * xn[c];
                     }
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
