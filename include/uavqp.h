@@ -159,6 +159,21 @@ int uavqp_eval_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segme
                             const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
                             int what, double* d_out);
 
+/* Batched SE(3) ellipsoid collision check of solved trajectories against an obstacle point cloud
+ * (SURVEY.md section 8-f, N4).  Replaces, for every sample of every trajectory, KinoAstar::isCollisionFree(pt, acc)
+ * (src/planner/path_searching/src/kino_astar.cpp:721-758): body axis b3 = normalize(acc + 9.81 z),
+ * b2 = normalize(b3 x (1,0,0)), b1 = normalize(b2 x b3), E = Rot diag(robot_r, robot_r, robot_h) Rot', and a
+ * sample collides when some obstacle point o within robot_r + 0.1 of it has |E^-1 (o - p)| <= 1.  The kd-tree
+ * radius search of the reference is an exhaustive scan here (same candidate set).
+ *   samples: t_s = t0 + s*dt, position and acceleration from the polynomials (segment rule of uavqp_eval_batch_device)
+ *   d_obstacles [n_obs][3] float64
+ *   d_first_hit [n_traj] int32: index of the first colliding sample, n_samples if the trajectory is collision-free
+ *   d_flags     [n_traj][n_samples] uint8 (1 = collides), may be NULL */
+int uavqp_ellipsoid_check_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                 const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
+                                 const double* d_obstacles, int n_obs, double robot_r, double robot_h,
+                                 int32_t* d_first_hit, uint8_t* d_flags);
+
 /* hipGraph capture of a launch-bound inner loop: everything enqueued on the ctx stream between
  * uavqp_capture_begin and uavqp_capture_end (any number of uavqp_solve_batch_device calls with their
  * workspaces already sized by one eager call) becomes one executable graph; uavqp_graph_launch replays

@@ -19,7 +19,7 @@ _ip = ctypes.POINTER(ctypes.c_int)
 
 def build(force=False):
     """Compile the oracle with gcc (seconds).  Never touches /root/reference."""
-    srcs = [os.path.join(_HERE, f) for f in ("qp_oracle.c", "osqp_port.c", "poly_eval.c") if os.path.exists(os.path.join(_HERE, f))]
+    srcs = [os.path.join(_HERE, f) for f in ("qp_oracle.c", "osqp_port.c", "poly_eval.c", "ellipsoid.c") if os.path.exists(os.path.join(_HERE, f))]
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
@@ -194,3 +194,11 @@ def poly_eval(nc, times, coef_traj, t, what=7):
     out = np.zeros(3 * K)
     lib().oracle_poly_eval(nc, T.size, pT, pc, ctypes.c_double(t), what, out.ctypes.data_as(_dp))
     return out.reshape(K, 3)
+
+
+def is_collision_free(pt, acc, obstacles, robot_r, robot_h):
+    """Reference KinoAstar::isCollisionFree(pt, acc) (kino_astar.cpp:721-758) against an obstacle array [n,3]."""
+    p, pp = _d(pt)
+    a, pa = _d(acc)
+    o, po = _d(obstacles)
+    return bool(lib().oracle_is_collision_free(pp, pa, po, o.size // 3, ctypes.c_double(robot_r), ctypes.c_double(robot_h)))

@@ -138,3 +138,48 @@ def test_batched_evaluation_matches_polytraj_restatement(oracle, r, ragged):
                 for s in range(0, ns, 7):
                     ref = oracle.poly_eval(2 * r, tk, ck, s * dt, what)
                     assert np.max(np.abs(got[k, s] - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_batched_ellipsoid_collision_check_matches_kino_astar_restatement(oracle):
+    """N4: uavqp_ellipsoid_check_device vs the restated KinoAstar::isCollisionFree (kino_astar.cpp:721-758) with the
+    reference's robot ellipsoid r = 0.4, h = 0.1 (test_kino_astar_searching.launch:56-57).  Flags must agree
+    bit-exactly except for samples whose decisive point sits within 1e-9 of the ellipsoid surface."""
+    import torch
+    r, M, n, ns, dt = 4, 6, 24, 64, 0.08
+    robot_r, robot_h = 0.4, 0.1
+    b = W.uniform_batch(6, n, M, r, time_mode="distance")
+    rng = np.random.default_rng(77)
+    # obstacle cloud: random pillars' points near the paths so that a good fraction of samples collide
+    wp = b["waypoints"].reshape(-1, 3)
+    centres = wp[rng.integers(0, wp.shape[0], size=400)] + rng.normal(scale=0.5, size=(400, 3))
+    obs = (centres[:, None, :] + rng.normal(scale=0.08, size=(400, 6, 3))).reshape(-1, 3)
+    dev = torch.device("cuda", 0)
+    with U.Context(0) as ctx:
+        coef, st = ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+        assert np.all(st == U.UAVQP_SOLVED)
+        d_coef = torch.from_numpy(coef).to(dev)
+        d_T = torch.from_numpy(b["times"].reshape(-1).copy()).to(dev)
+        d_obs = torch.from_numpy(obs.copy()).to(dev)
+        d_first = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_flags = torch.zeros(n * ns, dtype=torch.uint8, device=dev)
+        d_ev = torch.zeros(n * ns * 6, dtype=torch.float64, device=dev)
+        ctx.ellipsoid_check_device(r, n, M, None, d_T, d_coef, ns, 0.0, dt, d_obs, obs.shape[0], robot_r, robot_h, d_first, d_flags)
+        ctx.eval_batch_device(r, n, M, None, d_T, d_coef, ns, 0.0, dt, 5, d_ev)   # pos + acc at the same samples
+        ctx.synchronize()
+        flags = d_flags.cpu().numpy().reshape(n, ns)
+        first = d_first.cpu().numpy()
+        ev = d_ev.cpu().numpy().reshape(n, ns, 2, 3)
+    n_hit = 0
+    for k in range(n):
+        exp_first = ns
+        for s in range(ns):
+            free = oracle.is_collision_free(ev[k, s, 0], ev[k, s, 1], obs, robot_r, robot_h)
+            if bool(flags[k, s]) == free:   # disagreement: only tolerated on the surface of the ellipsoid
+                free_in = oracle.is_collision_free(ev[k, s, 0], ev[k, s, 1], obs, robot_r * (1 - 1e-9), robot_h * (1 - 1e-9))
+                free_out = oracle.is_collision_free(ev[k, s, 0], ev[k, s, 1], obs, robot_r * (1 + 1e-9), robot_h * (1 + 1e-9))
+                assert free_in != free_out, (k, s)
+            if flags[k, s] and exp_first == ns:
+                exp_first = s
+            n_hit += int(flags[k, s])
+        assert first[k] == exp_first
+    assert 0.02 * n * ns < n_hit < 0.9 * n * ns     # the cloud really cuts through some of the paths

@@ -37,6 +37,7 @@ SYMBOLS = (
     "uavqp_solve_corridor_batch_host",
     "uavqp_time_reallocate_device",
     "uavqp_eval_batch_device",
+    "uavqp_ellipsoid_check_device",
     "uavqp_capture_begin",
     "uavqp_capture_end",
     "uavqp_graph_launch",
@@ -93,6 +94,8 @@ def lib():
     L.uavqp_solve_corridor_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip]
     L.uavqp_time_reallocate_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, ctypes.c_double, ctypes.c_double, i32, ctypes.c_double, ip]
     L.uavqp_eval_batch_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, i32, dp]
+    L.uavqp_ellipsoid_check_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, dp, i32,
+                                               ctypes.c_double, ctypes.c_double, ip, vp]
     L.uavqp_capture_begin.argtypes = [vp]
     L.uavqp_capture_end.argtypes = [vp, ctypes.POINTER(vp)]
     L.uavqp_graph_launch.argtypes = [vp, vp]

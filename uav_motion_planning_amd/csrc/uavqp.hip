@@ -325,6 +325,90 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// N4: SE(3) ellipsoid collision check.  One lane per (trajectory, sample); obstacle points stream through LDS
+// in tiles shared by the 256 samples of a block.
+// ---------------------------------------------------------------------------------------------------
+struct EllipsoidArgs {
+    int n_traj, uniform, n_samples, n_obs;
+    const int32_t* seg_offsets;
+    const double* times;
+    const double* coeff;
+    const double* obs;
+    double t0, dt, robot_r, robot_h;
+    int32_t* first_hit;
+    uint8_t* flags;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void ellipsoid_kernel(EllipsoidArgs a) {
+    constexpr int NC = 2 * R, TILE = 1024;
+    __shared__ double s_obs[TILE * 3];
+    const long long total = (long long)a.n_traj * a.n_samples;
+    const long long n_round = (total + 255) / 256 * 256;  // every thread of a block joins the LDS tile loads
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n_round; g += (long long)gridDim.x * 256) {
+        const bool live = g < total;
+        int b = 0, s = 0;
+        double p[3] = {0, 0, 0}, b1[3] = {1, 0, 0}, b2[3] = {0, 1, 0}, b3[3] = {0, 0, 1};
+        if (live) {
+            b = (int)(g / a.n_samples);
+            s = (int)(g - (long long)b * a.n_samples);
+            int s0, M;
+            if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+            const double* __restrict__ T = a.times + s0;
+            double t = a.t0 + s * a.dt;
+            int idx = 0;
+            while (idx < M && t > T[idx] + 1e-4) { t -= T[idx]; ++idx; }
+            if (idx == M) { --idx; t = T[idx]; }
+            double acc[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double* ca = a.coeff + (size_t)3 * NC * s0 + ((size_t)ax * M + idx) * NC;
+                double pv = 0.0, av = 0.0;
+#pragma unroll
+                for (int j = NC - 1; j >= 0; --j) pv = fma(pv, t, ca[j]);
+#pragma unroll
+                for (int j = NC - 1; j >= 2; --j) av = fma(av, t, (double)(j * (j - 1)) * ca[j]);
+                p[ax] = pv;
+                acc[ax] = av;
+            }
+            // kino_astar.cpp:724-727
+            double n3 = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + (acc[2] + 9.81) * (acc[2] + 9.81));
+            b3[0] = acc[0] / n3; b3[1] = acc[1] / n3; b3[2] = (acc[2] + 9.81) / n3;
+            double c2[3] = {0.0, b3[2], -b3[1]};  // b3 x (1,0,0)
+            double n2 = sqrt(c2[1] * c2[1] + c2[2] * c2[2]);
+            b2[0] = 0.0; b2[1] = c2[1] / n2; b2[2] = c2[2] / n2;
+            double c1[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
+            double n1 = sqrt(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+            b1[0] = c1[0] / n1; b1[1] = c1[1] / n1; b1[2] = c1[2] / n1;
+        }
+        const double rad2 = (a.robot_r + 1e-1) * (a.robot_r + 1e-1);
+        const double ir = 1.0 / a.robot_r, ih = 1.0 / a.robot_h;
+        bool hit = false;
+        for (int o0 = 0; o0 < a.n_obs; o0 += TILE) {
+            const int nt = min(TILE, a.n_obs - o0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nt * 3; i += 256) s_obs[i] = a.obs[(size_t)o0 * 3 + i];
+            __syncthreads();
+            if (live && !hit) {
+                for (int i = 0; i < nt; ++i) {
+                    const double dx = s_obs[3 * i] - p[0], dy = s_obs[3 * i + 1] - p[1], dz = s_obs[3 * i + 2] - p[2];
+                    if (dx * dx + dy * dy + dz * dz <= rad2) {  // the reference's radius search (r + 0.1)
+                        const double e1 = (b1[0] * dx + b1[1] * dy + b1[2] * dz) * ir;
+                        const double e2 = (b2[0] * dx + b2[1] * dy + b2[2] * dz) * ir;
+                        const double e3 = (b3[0] * dx + b3[1] * dy + b3[2] * dz) * ih;
+                        if (e1 * e1 + e2 * e2 + e3 * e3 <= 1.0) { hit = true; break; }  // |E^-1 d| <= 1
+                    }
+                }
+            }
+        }
+        if (live) {
+            if (a.flags) a.flags[g] = hit ? 1 : 0;
+            if (hit) atomicMin(&a.first_hit[b], s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Time re-allocation: one lane per segment; peak |v|, |a| by sampling, stretch-only update of T.
 // ---------------------------------------------------------------------------------------------------
 struct ReallocArgs {
@@ -872,6 +956,33 @@ extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, i
         hipLaunchKernelGGL(uavqp::realloc_kernel<3>, dim3(grid), dim3(64), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL(uavqp::realloc_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
+    UAVQP_HIP(hipGetLastError());
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_ellipsoid_check_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                            const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
+                                            const double* d_obstacles, int n_obs, double robot_r, double robot_h,
+                                            int32_t* d_first_hit, uint8_t* d_flags) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || n_samples < 0 || uniform_segments < 0 || n_obs < 0 || !(robot_r > 0.0) || !(robot_h > 0.0))
+        return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!d_times || !d_coeff || !d_first_hit || (n_obs > 0 && !d_obstacles) || (uniform_segments == 0 && !d_seg_offsets))
+        return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_first_hit, n_traj, (int32_t)n_samples);
+    if (n_samples == 0) return UAVQP_OK;
+    uavqp::EllipsoidArgs a;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.n_samples = n_samples; a.n_obs = n_obs;
+    a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.obs = d_obstacles;
+    a.t0 = t0; a.dt = dt; a.robot_r = robot_r; a.robot_h = robot_h; a.first_hit = d_first_hit; a.flags = d_flags;
+    const long long total = (long long)n_traj * n_samples;
+    long long grid = (total + 255) / 256;
+    if (grid > (long long)ctx->num_cus * 16) grid = (long long)ctx->num_cus * 16;
+    if (r == 3)
+        hipLaunchKernelGGL(uavqp::ellipsoid_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(uavqp::ellipsoid_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }

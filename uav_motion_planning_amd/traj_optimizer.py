@@ -78,6 +78,16 @@ class Context:
                                                      float(v_max), float(a_max), int(samples_per_seg), float(max_stretch), p(changed))
         _lib.check(rc, "uavqp_time_reallocate_device")
 
+    def ellipsoid_check_device(self, r, n_traj, uniform_segments, seg_offsets, times, coeff, n_samples, t0, dt,
+                               obstacles, n_obs, robot_r, robot_h, first_hit, flags=None):
+        """Batched KinoAstar::isCollisionFree over the samples of solved trajectories (device buffers)."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_ellipsoid_check_device(self._h, r, n_traj, uniform_segments, p(seg_offsets), p(times), p(coeff),
+                                                     n_samples, float(t0), float(dt), p(obstacles), int(n_obs),
+                                                     float(robot_r), float(robot_h), p(first_hit), p(flags))
+        _lib.check(rc, "uavqp_ellipsoid_check_device")
+
     def capture_begin(self):
         """Start hipGraph capture of everything subsequently enqueued on the ctx stream."""
         _lib.check(_lib.lib().uavqp_capture_begin(self._h), "uavqp_capture_begin")
