@@ -183,3 +183,30 @@ def test_batched_ellipsoid_collision_check_matches_kino_astar_restatement(oracle
             n_hit += int(flags[k, s])
         assert first[k] == exp_first
     assert 0.02 * n * ns < n_hit < 0.9 * n * ns     # the cloud really cuts through some of the paths
+
+
+def test_misaligned_device_views_take_the_generic_kernel(oracle):
+    """Arrays that start at an odd double (8-byte but not 16-byte aligned views) must still solve correctly: the
+    specialised kernels need 16-byte alignment for LDS-DMA / dwordx4 traffic, the library has to notice."""
+    import torch
+    r, M, n = 4, 8, 100
+    b = W.uniform_batch(2, n, M, r, time_mode="distance")
+    dev = torch.device("cuda", 0)
+
+    def odd(x):
+        buf = torch.zeros(x.size + 1, dtype=torch.float64, device=dev)
+        buf[1:] = torch.from_numpy(np.ascontiguousarray(x).reshape(-1)).to(dev)
+        return buf, buf[1:]
+    with U.Context(0) as ctx:
+        keep, d_wp = odd(b["waypoints"])
+        keep2, d_T = odd(b["times"])
+        keep3, d_bc = odd(b["bc"])
+        keep4, d_out = odd(np.zeros(n * 192))
+        d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        assert d_wp.data_ptr() % 16 == 8
+        ctx.solve_batch_device(r, n, M, M, None, d_wp, d_T, d_bc, d_out, d_st)
+        ctx.synchronize()
+        got = d_out.cpu().numpy()
+        assert bool((d_st == U.UAVQP_SOLVED).all())
+    ref, _ = oracle.solve_exact_batch(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+    assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))

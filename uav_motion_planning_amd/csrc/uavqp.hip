@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -640,7 +641,11 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     a.status = d_status_out;
     a.dummy = ctx->dummy;
 
-    if (uniform_segments > 0 && ctx->variant != 1) {
+    // the specialised kernels move 16 bytes per lane (LDS-DMA loads, dwordx4 stores): every array must be
+    // 16-byte aligned (allocations are; a view starting at an odd double is not) -- otherwise the generic
+    // kernel, which touches memory 8 bytes at a time, takes the batch
+    const bool aligned16 = ((((uintptr_t)d_waypoints) | ((uintptr_t)d_times) | ((uintptr_t)d_bc) | ((uintptr_t)d_coeff_out)) & 15u) == 0;
+    if (uniform_segments > 0 && ctx->variant != 1 && aligned16) {
         // Tile shape by batch size (measured on MI355X, 8-segment snap, us per launch for tiles 8 / 16 / 32:
         // 4096: 6.0 / 7.5 / 8.2   8192: 8.7 / 8.5 / 9.4   16384: 14.1 / 9.7 / 10.0   32768: 23.8 / 17.5 / 12.6).
         // One CU moves only ~10 B/clk, so a small batch is spread over all 256 CUs with fewer trajectories per
