@@ -60,10 +60,16 @@ __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     if (i < n) p[i] = v;
 }
 
+// r = 3 is held to 2 waves per SIMD (256 registers, ~100 B/lane scratch): the sweeps are chains of dependent
+// HBM round trips, a second wave hides them (measured on config 3: 4.30 ms at 1 wave, 3.25 ms at 2, 4.19 ms at 3).
 template <int R>
-__global__ __launch_bounds__(64) void solve_corridor_kernel(CorridorArgs a) {
+__global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(CorridorArgs a) {
     constexpr int ND = R - 1, NC = 2 * R;
-    constexpr int F_E = 0, F_H = R * R, F_Z = R * R + R, F_X = R * R + R + 1, F = R * R + 2 * R + 1;
+    // sweep state per interior knot: LDL' factors of S_k (strict lower triangle + inverse pivots), x_k (first h_k,
+    // overwritten by the solution in the backward sweep) and the current position iterate z_k.  E_k = S_k^-1 M_k is
+    // NOT stored: it is re-derived from the factors where needed (the kernel is bound by this HBM traffic).
+    constexpr int NL = R * (R - 1) / 2;
+    constexpr int F_L = 0, F_DI = NL, F_X = NL + R, F_Z = NL + 2 * R, F = NL + 2 * R + 1, F_H = F_X;
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_slots = gridDim.x * blockDim.x;
     double* __restrict__ ws = a.ws + slot;
@@ -121,7 +127,8 @@ __global__ __launch_bounds__(64) void solve_corridor_kernel(CorridorArgs a) {
             {
                 FullBlocks<R> sa;
                 sa.build(T[0]);
-                double Eprev[R][R], hprev[R];
+                SmallLDL<R> lprev;
+                double hprev[R];
                 for (int k = 1; k < M; ++k) {
                     FullBlocks<R> sb;
                     sb.build(T[k]);
@@ -166,76 +173,98 @@ __global__ __launch_bounds__(64) void solve_corridor_kernel(CorridorArgs a) {
                         D[0][0] = 1.0;
                         rhs[0] = zk;
                     }
-                    // masked coupling blocks: Mp between (k-1, k), Mn between (k, k+1)
-                    double Mp[R][R], Mn[R][R];
+                    if (k > 1) {
+                        // masked coupling block between (k-1, k) and E = S_{k-1}^-1 Mp from the previous factors
+                        double Mp[R][R], Ep[R][R];
 #pragma unroll
-                    for (int i = 0; i < R; ++i)
+                        for (int i = 0; i < R; ++i)
+#pragma unroll
+                            for (int c = 0; c < R; ++c) Mp[i][c] = ((pprev && i == 0) || (pk && c == 0)) ? 0.0 : sa.B01[i][c];
 #pragma unroll
                         for (int c = 0; c < R; ++c) {
-                            Mp[i][c] = ((pprev && i == 0) || (pk && c == 0)) ? 0.0 : sa.B01[i][c];
-                            Mn[i][c] = ((pk && i == 0) || (pnext && c == 0)) ? 0.0 : sb.B01[i][c];
+                            double col[R];
+#pragma unroll
+                            for (int i = 0; i < R; ++i) col[i] = Mp[i][c];
+                            lprev.solve(col);
+#pragma unroll
+                            for (int i = 0; i < R; ++i) Ep[i][c] = col[i];
                         }
-                    if (k > 1) {
 #pragma unroll
                         for (int i = 0; i < R; ++i)
 #pragma unroll
                             for (int q = 0; q < R; ++q) {
 #pragma unroll
-                                for (int c = 0; c <= i; ++c) D[i][c] -= Mp[q][i] * Eprev[q][c];
+                                for (int c = 0; c <= i; ++c) D[i][c] -= Mp[q][i] * Ep[q][c];
                                 rhs[i] -= Mp[q][i] * hprev[q];
                             }
                     }
                     SmallLDL<R> ldl;
                     ldl.factor(D);
                     ldl.solve(rhs);
+                    {
+                        int f = 0;
+#pragma unroll
+                        for (int i = 1; i < R; ++i)
+#pragma unroll
+                            for (int c = 0; c < i; ++c) W(k, F_L + (f++)) = ldl.l[i][c];
+                    }
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
+                        W(k, F_DI + i) = ldl.dinv[i];
                         hprev[i] = rhs[i];
-                        W(k, F_H + i) = rhs[i];
+                        W(k, F_X + i) = rhs[i];
                     }
-                    if (k < M - 1) {
-#pragma unroll
-                        for (int c = 0; c < R; ++c) {
-                            double col[R];
-#pragma unroll
-                            for (int i = 0; i < R; ++i) col[i] = Mn[i][c];
-                            ldl.solve(col);
-#pragma unroll
-                            for (int i = 0; i < R; ++i) {
-                                Eprev[i][c] = col[i];
-                                W(k, F_E + i * R + c) = col[i];
-                            }
-                        }
-                    }
+                    lprev = ldl;
                     sa = sb;
                 }
-                // backward sweep; the state of knot k-1 is fetched while knot k is processed (one lane per
-                // (trajectory, axis) has nothing else to hide an HBM round trip per knot behind)
-                double xn[R], nx[R + R * R];
+                // backward sweep: x_k = h_k - S_k^-1 (M_k x_{k+1}); the state of knot k-1 is fetched while knot k is
+                // processed (one lane per (trajectory, axis) has nothing else to hide an HBM round trip per knot behind)
+                constexpr int NB = NL + 2 * R;  // factors + h
+                double xn[R], nx[NB];
 #pragma unroll
-                for (int f = 0; f < R + R * R; ++f) nx[f] = W(M - 1, f < R ? F_H + f : F_E + (f - R));
+                for (int f = 0; f < NB; ++f) nx[f] = W(M - 1, f);
                 for (int k = M - 1; k >= 1; --k) {
-                    double cur[R + R * R];
+                    double cur[NB];
 #pragma unroll
-                    for (int f = 0; f < R + R * R; ++f) cur[f] = nx[f];
+                    for (int f = 0; f < NB; ++f) cur[f] = nx[f];
                     if (k >= 2) {
 #pragma unroll
-                        for (int f = 0; f < R + R * R; ++f) nx[f] = W(k - 1, f < R ? F_H + f : F_E + (f - R));
+                        for (int f = 0; f < NB; ++f) nx[f] = W(k - 1, f);
                     }
                     double x[R];
 #pragma unroll
-                    for (int i = 0; i < R; ++i) x[i] = cur[i];
+                    for (int i = 0; i < R; ++i) x[i] = cur[F_X + i];
                     if (k < M - 1) {
+                        FullBlocks<R> sb;
+                        sb.build(T[k]);
+                        const bool pk = (pin >> k) & 1ull;
+                        const bool pnext = (pin >> (k + 1)) & 1ull;
+                        double t[R];
 #pragma unroll
-                        for (int i = 0; i < R; ++i)
+                        for (int i = 0; i < R; ++i) {
+                            double acc = 0.0;
 #pragma unroll
-                            for (int c = 0; c < R; ++c) x[i] -= cur[R + i * R + c] * xn[c];
+                            for (int c = 0; c < R; ++c) acc += (((pk && i == 0) || (pnext && c == 0)) ? 0.0 : sb.B01[i][c]) * xn[c];
+                            t[i] = acc;
+                        }
+                        SmallLDL<R> ldl;
+                        {
+                            int f = 0;
+#pragma unroll
+                            for (int i = 1; i < R; ++i)
+#pragma unroll
+                                for (int c = 0; c < i; ++c) ldl.l[i][c] = cur[F_L + (f++)];
+                        }
+#pragma unroll
+                        for (int i = 0; i < R; ++i) ldl.dinv[i] = cur[F_DI + i];
+                        ldl.solve(t);
+#pragma unroll
+                        for (int i = 0; i < R; ++i) x[i] -= t[i];
+#pragma unroll
+                        for (int i = 0; i < R; ++i) W(k, F_X + i) = x[i];
                     }
 #pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        W(k, F_X + i) = x[i];
-                        xn[i] = x[i];
-                    }
+                    for (int i = 0; i < R; ++i) xn[i] = x[i];
                 }
             }
             if (final_pass) break;

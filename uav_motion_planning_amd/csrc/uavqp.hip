@@ -867,7 +867,7 @@ extern "C" int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_tr
     long long grid = (lanes + block - 1) / block;
     const long long max_grid = (long long)ctx->num_cus * 8;
     if (grid > max_grid) grid = max_grid;
-    const int F = r * r + 2 * r + 1;
+    const int F = r * (r - 1) / 2 + 2 * r + 1;  // must match solve_corridor_kernel's state layout
     const size_t ws_bytes = sizeof(double) * (size_t)(Mmax > 1 ? Mmax - 1 : 1) * F * (size_t)grid * block;
     int rc = ensure_ws(ctx, ws_bytes);
     if (rc != UAVQP_OK) return rc;
