@@ -174,6 +174,31 @@ int uavqp_ellipsoid_check_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_
                                  const double* d_obstacles, int n_obs, double robot_r, double robot_h,
                                  int32_t* d_first_hit, uint8_t* d_flags);
 
+/* Corridor boxes from an obstacle point cloud (SURVEY.md section 8-d config 5 "ellipsoid-derived corridor widths",
+ * 8-f N4).  No reference counterpart as a function: it turns the reference's SE(3) collision test
+ * KinoAstar::isCollisionFree(pt, acc) (src/planner/path_searching/src/kino_astar.cpp:721-758) into the box
+ * lo <= p <= hi that uavqp_solve_corridor_batch_device puts in place of the waypoint rows
+ * (minimum_control.cpp:34-42,118-124).  For every waypoint row w (n_rows = sum over trajectories of M_b + 1):
+ *   attitude: b3 = normalize(acc + 9.81 z), b2 = normalize(b3 x (1,0,0)), b1 = normalize(b2 x b3)
+ *             (kino_astar.cpp:724-727), E = Rot diag(robot_r, robot_r, robot_h) Rot' (:729-737), with acc the
+ *             acceleration of the solved polynomials d_coeff at that knot, or 0 (hover) when d_coeff is NULL;
+ *   clearance g = min over ALL obstacle points o of |E^-1 (o - w)|   (the reference's collision metric, :751-753;
+ *             +inf for an empty cloud; g <= 1 means the waypoint itself collides);
+ *   half-widths h_i = min(h_max, max(0, g - 1) / (3 |E^-1 e_i|)), i = x, y, z;  lo = w - h, hi = w + h.
+ * Guarantee: for any offset d with |d_i| <= h_i and any obstacle o, |E^-1 (o - w - d)| >= g - sum_i |d_i| |E^-1 e_i|
+ * >= 1, i.e. the robot ellipsoid (same attitude) translated anywhere in the box contains no obstacle point.
+ * A colliding waypoint gets h = 0: lo == hi, the reference's equality row.  First/last rows of a trajectory get
+ * lo == hi == w (the corridor solver fixes the end points).
+ *   d_times      may be NULL when d_coeff is NULL
+ *   d_obstacles  [n_obs][3] float64 (exhaustive scan, like uavqp_ellipsoid_check_device)
+ *   d_corr_lo / d_corr_hi  [n_rows][3] float64 out
+ *   d_clearance  [n_rows] float64 out (g), may be NULL
+ * Asynchronous on the ctx stream. */
+int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                     int n_rows, const double* d_waypoints, const double* d_times, const double* d_coeff,
+                                     const double* d_obstacles, int n_obs, double robot_r, double robot_h, double h_max,
+                                     double* d_corr_lo, double* d_corr_hi, double* d_clearance);
+
 /* hipGraph capture of a launch-bound inner loop: everything enqueued on the ctx stream between
  * uavqp_capture_begin and uavqp_capture_end (any number of uavqp_solve_batch_device calls with their
  * workspaces already sized by one eager call) becomes one executable graph; uavqp_graph_launch replays

@@ -35,3 +35,37 @@ int oracle_is_collision_free(const double* pt, const double* acc, const double* 
     }
     return 1;
 }
+
+/* Corridor box of one waypoint from the obstacle cloud (config 5, "ellipsoid-derived corridor widths"): the
+ * specification of include/uavqp.h uavqp_corridor_from_cloud_device restated with the reference's own
+ * construction of E (kino_astar.cpp:724-737) and its collision metric |E^-1 (o - pt)| (:751-753), written with
+ * the explicit body-frame projections rather than the device's quadratic form.
+ *   g = min_o |E^-1 (o - pt)|;  h_i = min(h_max, max(0, g - 1) / (3 |E^-1 e_i|));  lo = pt - h, hi = pt + h.
+ * Returns g (INFINITY for an empty cloud). */
+double oracle_corridor_box(const double* pt, const double* acc, const double* obs, int n_obs, double robot_r, double robot_h,
+                           double h_max, double* lo, double* hi) {
+    double b3[3] = {acc[0], acc[1], acc[2] + 9.81}, c1[3] = {1.0, 0.0, 0.0}, b2[3], b1[3];
+    normalize3(b3);
+    cross3(b3, c1, b2); normalize3(b2);
+    cross3(b2, b3, b1); normalize3(b1);
+    double g = INFINITY;
+    for (int i = 0; i < n_obs; ++i) {
+        const double d[3] = {obs[3 * i] - pt[0], obs[3 * i + 1] - pt[1], obs[3 * i + 2] - pt[2]};
+        const double u[3] = {(b1[0] * d[0] + b1[1] * d[1] + b1[2] * d[2]) / robot_r,
+                             (b2[0] * d[0] + b2[1] * d[1] + b2[2] * d[2]) / robot_r,
+                             (b3[0] * d[0] + b3[1] * d[1] + b3[2] * d[2]) / robot_h};
+        const double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (n < g) g = n;
+    }
+    const double margin = g > 1.0 ? g - 1.0 : 0.0;
+    for (int i = 0; i < 3; ++i) {
+        /* |E^-1 e_i| = |P^-1 Rot' e_i| */
+        const double u[3] = {b1[i] / robot_r, b2[i] / robot_r, b3[i] / robot_h};
+        const double w = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        double h = margin / (3.0 * w);
+        if (!(h < h_max)) h = h_max;
+        lo[i] = pt[i] - h;
+        hi[i] = pt[i] + h;
+    }
+    return g;
+}

@@ -33,6 +33,7 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_cost.restype = ctypes.c_double
         _lib.oracle_residual.restype = ctypes.c_double
+        _lib.oracle_corridor_box.restype = ctypes.c_double
     return _lib
 
 
@@ -202,3 +203,16 @@ def is_collision_free(pt, acc, obstacles, robot_r, robot_h):
     a, pa = _d(acc)
     o, po = _d(obstacles)
     return bool(lib().oracle_is_collision_free(pp, pa, po, o.size // 3, ctypes.c_double(robot_r), ctypes.c_double(robot_h)))
+
+
+def corridor_box(pt, acc, obstacles, robot_r, robot_h, h_max):
+    """Corridor box of one waypoint from the obstacle cloud (spec of uavqp_corridor_from_cloud_device, built on the
+    reference's ellipsoid of kino_astar.cpp:721-758).  Returns (g, lo[3], hi[3])."""
+    p, pp = _d(pt)
+    a, pa = _d(acc)
+    o, po = _d(obstacles)
+    lo = np.zeros(3)
+    hi = np.zeros(3)
+    g = lib().oracle_corridor_box(pp, pa, po, o.size // 3, ctypes.c_double(robot_r), ctypes.c_double(robot_h),
+                                  ctypes.c_double(h_max), lo.ctypes.data_as(_dp), hi.ctypes.data_as(_dp))
+    return float(g), lo, hi

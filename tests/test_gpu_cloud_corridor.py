@@ -1,0 +1,198 @@
+"""-m gpu: corridor boxes from an obstacle point cloud (uavqp_corridor_from_cloud_device; BASELINE config 5
+"ellipsoid-derived corridor widths") through the C ABI.
+
+Checkers: (1) the C restatement built on the reference's ellipsoid (oracle.corridor_box, kino_astar.cpp:721-758)
+row by row; tolerance 1e-12 relative on the clearance and 1e-12 m on the bounds (the device evaluates the metric
+as a quadratic form, the oracle with explicit body-frame projections: same real number, different rounding);
+(2) the guarantee itself, with the reference's own collision test as the judge: the robot ellipsoid translated
+anywhere inside a box is collision-free per KinoAstar::isCollisionFree; (3) the config-5 pipeline end to end."""
+import numpy as np
+import pytest
+
+import uav_motion_planning_amd as U
+from uav_motion_planning_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+ROBOT_R, ROBOT_H = 0.4, 0.1   # test_kino_astar_searching.launch:56-57
+
+
+def _knot_acc(coef, so, T, r, k_traj, k):
+    """Acceleration of the solved polynomials at knot k of trajectory k_traj (numpy, independent of the device)."""
+    nc = 2 * r
+    s0, M = int(so[k_traj]), int(so[k_traj + 1] - so[k_traj])
+    c = coef[3 * nc * s0:3 * nc * (s0 + M)].reshape(3, M, nc)
+    if k < M:
+        return 2.0 * c[:, k, 2]
+    t = T[s0 + M - 1]
+    return np.array([sum(j * (j - 1) * c[ax, M - 1, j] * t ** (j - 2) for j in range(2, nc)) for ax in range(3)])
+
+
+def _run(ctx, r, b, obs, h_max, coef=None, uniform=0):
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    so = np.asarray(b["seg_offsets"])
+    n = so.size - 1
+    wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+    rows = wp.shape[0]
+    d_lo = torch.full((rows, 3), np.nan, dtype=torch.float64, device=dev)
+    d_hi = torch.full((rows, 3), np.nan, dtype=torch.float64, device=dev)
+    d_g = torch.full((rows,), np.nan, dtype=torch.float64, device=dev)
+    d_obs = up(obs) if obs.shape[0] else None
+    d_coef = up(coef) if coef is not None else None
+    d_T = up(np.asarray(b["times"]).reshape(-1)) if coef is not None else None
+    ctx.corridor_from_cloud_device(r, n, uniform, None if uniform else up(so.astype(np.int32)), rows, up(wp), d_T, d_coef,
+                                   d_obs, obs.shape[0], ROBOT_R, ROBOT_H, h_max, d_lo, d_hi, d_g)
+    ctx.synchronize()
+    return d_lo.cpu().numpy(), d_hi.cpu().numpy(), d_g.cpu().numpy()
+
+
+@pytest.mark.parametrize("r,with_attitude", [(4, False), (4, True), (3, True)])
+def test_cloud_corridor_matches_restatement_row_by_row(gpu_ctx, oracle, r, with_attitude):
+    n, h_max = 40, 0.8
+    b = W.ragged_batch(5, n, r, m_lo=3, m_hi=12)
+    so = b["seg_offsets"]
+    wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+    T = np.asarray(b["times"]).reshape(-1)
+    obs = W.pillar_cloud(5, n_pillars=40, resolution=0.25)
+    assert obs.shape[0] > 3000 and obs.shape[0] % 1024 not in (0, 1)   # several LDS tiles, odd tail
+    coef = None
+    if with_attitude:
+        coef, st = gpu_ctx.solve_batch_host(r, so, b["waypoints"], b["times"], b["bc"])
+        assert np.all(st == U.UAVQP_SOLVED)
+    lo, hi, g = _run(gpu_ctx, r, b, obs, h_max, coef)
+    n_interior = n_zero = n_cap = 0
+    for k in range(n):
+        M = int(so[k + 1] - so[k])
+        for j in range(M + 1):
+            row = int(so[k]) + k + j
+            acc = _knot_acc(coef, so, T, r, k, j) if with_attitude else np.zeros(3)
+            g_ref, lo_ref, hi_ref = oracle.corridor_box(wp[row], acc, obs, ROBOT_R, ROBOT_H, h_max)
+            assert abs(g[row] - g_ref) <= 1e-12 * g_ref
+            if j in (0, M):
+                assert np.array_equal(lo[row], wp[row]) and np.array_equal(hi[row], wp[row])
+                continue
+            assert np.max(np.abs(lo[row] - lo_ref)) <= 1e-12 and np.max(np.abs(hi[row] - hi_ref)) <= 1e-12
+            n_interior += 1
+            n_zero += int(np.all(hi[row] == lo[row]))
+            n_cap += int(np.any(hi[row] - wp[row] >= h_max))
+    assert n_interior > 100 and n_zero < n_interior and n_cap < n_interior   # a real mix of widths
+
+
+def test_cloud_corridor_box_is_collision_free_for_the_reference_test(gpu_ctx, oracle):
+    """The guarantee of include/uavqp.h, judged by the restated KinoAstar::isCollisionFree: sample offsets inside
+    every non-degenerate box (corners included, shrunk by 1e-9) and ask the reference's test."""
+    r, n, M, h_max = 4, 16, 6, 0.6
+    b = W.uniform_batch(5, n, M, r, time_mode="distance")
+    obs = W.pillar_cloud(5, n_pillars=60, resolution=0.2)
+    coef, st = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    lo, hi, g = _run(gpu_ctx, r, b, obs, h_max, coef, uniform=M)
+    wp = b["waypoints"].reshape(-1, 3)
+    so = b["seg_offsets"]
+    T = b["times"].reshape(-1)
+    rng = np.random.default_rng(5)
+    corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+    checked = 0
+    for k in range(n):
+        for j in range(1, M):
+            row = k * (M + 1) + j
+            h = hi[row] - wp[row]
+            if g[row] <= 1.0:
+                assert np.all(h == 0.0)
+                continue
+            acc = _knot_acc(coef, so, T, r, k, j)
+            offs = np.concatenate([corners, rng.uniform(-1, 1, size=(8, 3))]) * h * (1 - 1e-9)
+            for d in offs:
+                assert oracle.is_collision_free(wp[row] + d, acc, obs, ROBOT_R, ROBOT_H), (k, j, d, g[row])
+                checked += 1
+    assert checked > 500
+
+
+def test_cloud_corridor_edge_cases(gpu_ctx):
+    """Empty cloud -> every interior box is +-h_max; an obstacle point on a waypoint -> that row degenerates to the
+    reference's equality (lo == hi == waypoint) and the corridor solve reproduces the plain solve there."""
+    r, n, M, h_max = 3, 7, 5, 0.5
+    b = W.uniform_batch(5, n, M, r, time_mode="reference")
+    wp = b["waypoints"].reshape(-1, 3)
+    lo, hi, g = _run(gpu_ctx, r, b, np.zeros((0, 3)), h_max, uniform=M)
+    assert np.all(np.isinf(g))
+    for k in range(n):
+        for j in range(M + 1):
+            row = k * (M + 1) + j
+            exp = 0.0 if j in (0, M) else h_max
+            assert np.allclose(hi[row] - wp[row], exp, atol=1e-15) and np.allclose(wp[row] - lo[row], exp, atol=1e-15)
+    # every interior waypoint sits on an obstacle point: all boxes collapse, corridor solve == equality solve
+    lo, hi, g = _run(gpu_ctx, r, b, wp.copy(), h_max, uniform=M)
+    assert np.all(g == 0.0) and np.array_equal(lo, wp) and np.array_equal(hi, wp)
+    c_eq, st = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    c_co, st2, _ = gpu_ctx.solve_corridor_batch_host(r, None, b["waypoints"], b["times"], b["bc"], lo, hi, uniform_segments=M)
+    assert np.all(st == U.UAVQP_SOLVED) and np.all(st2 == U.UAVQP_SOLVED)
+    assert np.max(np.abs(c_eq - c_co)) <= 1e-9 * np.max(np.abs(c_eq))
+
+
+def test_cloud_corridor_rejects_bad_arguments(gpu_ctx):
+    lib = U.lib()
+    assert lib.uavqp_corridor_from_cloud_device(gpu_ctx._h, 5, 1, 4, None, 5, None, None, None, None, 0, 0.4, 0.1, 0.5, None, None, None) == -1
+    assert lib.uavqp_corridor_from_cloud_device(gpu_ctx._h, 4, 1, 4, None, 5, None, None, None, None, 0, 0.4, 0.1, 0.5, None, None, None) == -1   # null buffers
+    assert lib.uavqp_corridor_from_cloud_device(gpu_ctx._h, 4, 0, 4, None, 0, None, None, None, None, 0, 0.4, 0.1, 0.5, None, None, None) == 0    # empty batch
+
+
+def test_config5_pipeline_cloud_corridors_then_corridor_solve_and_reallocation(oracle):
+    """BASELINE config 5 end to end on device buffers: plain solve -> corridor boxes from the pillar cloud with the
+    attitude of that solve -> corridor-constrained solve -> time re-allocation loop (<= 5).  Checked: all statuses
+    SOLVED, every interior knot of the final trajectories inside its box, and -- since the boxes are collision-free
+    for the attitude they were derived with -- the robot ellipsoid at every interior knot position with that attitude
+    passes the reference's collision test."""
+    import torch
+    r, n, h_max, v_max, a_max = 4, 64, 0.8, 7.0, 10.0
+    b = W.ragged_batch(5, n, r, m_lo=4, m_hi=12)
+    so = b["seg_offsets"]
+    wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+    rows = wp.shape[0]
+    obs = W.pillar_cloud(5, n_pillars=50, resolution=0.25)
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_so, d_wp, d_T, d_bc, d_obs = up(so), up(wp), up(b["times"]), up(b["bc"]), up(obs)
+    d_lo = torch.zeros((rows, 3), dtype=torch.float64, device=dev)
+    d_hi = torch.zeros((rows, 3), dtype=torch.float64, device=dev)
+    d_out = torch.zeros(int(so[-1]) * 24, dtype=torch.float64, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ch = torch.zeros(n, dtype=torch.int32, device=dev)
+    lib = U.lib()
+    with U.Context(0) as ctx:
+        ctx.solve_batch_device(r, n, 0, 12, d_so, d_wp, d_T, d_bc, d_out, d_st)
+        ctx.corridor_from_cloud_device(r, n, 0, d_so, rows, d_wp, d_T, d_out, d_obs, obs.shape[0], ROBOT_R, ROBOT_H, h_max, d_lo, d_hi)
+        ctx.synchronize()
+        assert bool((d_st == U.UAVQP_SOLVED).all())
+        coef0 = d_out.cpu().numpy().copy()
+        T0 = d_T.cpu().numpy().copy()
+        T_prev = T0
+        for outer in range(5):        # the cap of config 5
+            rc = lib.uavqp_solve_corridor_batch_device(ctx._h, r, n, 0, 12, d_so.data_ptr(), d_wp.data_ptr(), d_T.data_ptr(), d_bc.data_ptr(),
+                                                       d_lo.data_ptr(), d_hi.data_ptr(), d_out.data_ptr(), d_st.data_ptr(), None)
+            assert rc == 0
+            ctx.synchronize()
+            coef = d_out.cpu().numpy().copy()      # solution for the durations of THIS round
+            ctx.time_reallocate_device(r, n, 0, d_so, d_T, d_out, v_max, a_max, samples_per_seg=16, max_stretch=2.0, changed=d_ch)
+            ctx.synchronize()
+            assert bool((d_st == U.UAVQP_SOLVED).all())
+            T_now = d_T.cpu().numpy()
+            assert np.all(T_now >= T_prev * (1 - 1e-15))
+            T_prev = T_now
+            if int(d_ch.sum().item()) == 0:
+                break
+        assert int((d_ch > 0).sum().item()) <= n // 16     # the loop has (all but) settled within the cap
+        lo, hi = d_lo.cpu().numpy(), d_hi.cpu().numpy()
+    n_wide = 0
+    for k in range(n):
+        s0, M = int(so[k]), int(so[k + 1] - so[k])
+        c = coef[24 * s0:24 * (s0 + M)].reshape(3, M, 8)
+        for j in range(1, M):
+            row = s0 + k + j
+            p = c[:, j, 0]                       # position at the start of segment j = knot j
+            assert np.all(p >= lo[row] - 1e-9) and np.all(p <= hi[row] + 1e-9)
+            if np.any(hi[row] > lo[row]):
+                n_wide += 1
+                acc0 = _knot_acc(coef0, so, T0, r, k, j)
+                assert oracle.is_collision_free(p - (p - wp[row]) * 1e-9, acc0, obs, ROBOT_R, ROBOT_H)
+    assert n_wide > 50

@@ -91,6 +91,51 @@ def main():
     print(json.dumps({"config": "N1-eval", "n": n, "samples": ns, "ms": ms, "samples_per_s": n * ns / ms * 1e3,
                       "GB_per_s": (n * ns * 72 + n * 1536) / ms / 1e6}))
 
+    # ---- config 5: 16384 ragged (M in [4, 24]), r=4: plain solve -> corridor boxes from a pillar cloud (attitude of
+    # that solve) -> corridor solve + time re-allocation, 5 outer rounds (the cap of SURVEY.md section 8-d)
+    r, n, h_max = 4, 16384, 0.8
+    b = W.ragged_batch(5, n, r)
+    so = b["seg_offsets"]
+    rows = int(so[-1]) + n
+    obs = W.pillar_cloud(5, n_pillars=60, resolution=0.2)
+    d_so = torch.from_numpy(so).to(dev)
+    d = {k: up(b[k]) for k in ("waypoints", "times", "bc")}
+    d_obs = up(obs)
+    out = torch.zeros(int(so[-1]) * 3 * 2 * r, dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev)
+    ch = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_lo = torch.zeros(rows * 3, dtype=torch.float64, device=dev)
+    d_hi = torch.zeros(rows * 3, dtype=torch.float64, device=dev)
+    T0 = d["times"].clone()
+    ms_solve = timeit(lambda: ctx.solve_batch_device(r, n, 0, 24, d_so, d["waypoints"], d["times"], d["bc"], out, st), s)
+    ms_cloud = timeit(lambda: ctx.corridor_from_cloud_device(r, n, 0, d_so, rows, d["waypoints"], d["times"], out, d_obs, obs.shape[0],
+                                                             0.4, 0.1, h_max, d_lo, d_hi), s, n=5, warm=1)
+    width = (d_hi - d_lo).reshape(rows, 3)
+
+    def corridor5():
+        rc = lib.uavqp_solve_corridor_batch_device(ctx._h, r, n, 0, 24, d_so.data_ptr(), d["waypoints"].data_ptr(), d["times"].data_ptr(),
+                                                   d["bc"].data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), out.data_ptr(), st.data_ptr(), it.data_ptr())
+        assert rc == 0
+    ms_corr = timeit(corridor5, s, n=5, warm=1)
+    it_mean = float(it.float().mean())
+
+    def outer_loop():
+        d["times"].copy_(T0)
+        for _ in range(5):
+            corridor5()
+            ctx.time_reallocate_device(r, n, 0, d_so, d["times"], out, 7.0, 10.0, samples_per_seg=16, max_stretch=2.0, changed=ch)
+    with torch.cuda.stream(s):
+        ms_loop = timeit(outer_loop, s, n=3, warm=1)
+    print(json.dumps({"config": "5-pipeline", "n": n, "sum_M": int(so[-1]), "r": r, "n_obs": int(obs.shape[0]),
+                      "ms_plain_solve": ms_solve, "ms_cloud_corridor": ms_cloud,
+                      "cloud_pairs_per_s": rows * obs.shape[0] / ms_cloud * 1e3,
+                      "ms_corridor_solve": ms_corr, "iters_mean": it_mean, "ms_5_outer_rounds": ms_loop,
+                      "traj_per_s_whole_pipeline": n / (ms_solve + ms_cloud + ms_loop) * 1e3,
+                      "solved": int((st == 1).sum()), "still_stretching": int((ch > 0).sum()),
+                      "box_halfwidth_mean_xyz": [float(x) for x in (width.mean(dim=0) / 2)],
+                      "rows_degenerate_frac": float((width.amax(dim=1) == 0).float().mean())}))
+
 
 if __name__ == "__main__":
     main()

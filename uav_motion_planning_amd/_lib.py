@@ -38,6 +38,7 @@ SYMBOLS = (
     "uavqp_time_reallocate_device",
     "uavqp_eval_batch_device",
     "uavqp_ellipsoid_check_device",
+    "uavqp_corridor_from_cloud_device",
     "uavqp_capture_begin",
     "uavqp_capture_end",
     "uavqp_graph_launch",
@@ -96,6 +97,8 @@ def lib():
     L.uavqp_eval_batch_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, i32, dp]
     L.uavqp_ellipsoid_check_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, dp, i32,
                                                ctypes.c_double, ctypes.c_double, ip, vp]
+    L.uavqp_corridor_from_cloud_device.argtypes = [vp, i32, i32, i32, ip, i32, dp, dp, dp, dp, i32, ctypes.c_double, ctypes.c_double,
+                                                   ctypes.c_double, dp, dp, dp]
     L.uavqp_capture_begin.argtypes = [vp]
     L.uavqp_capture_end.argtypes = [vp, ctypes.POINTER(vp)]
     L.uavqp_graph_launch.argtypes = [vp, vp]

@@ -60,8 +60,23 @@ __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     if (i < n) p[i] = v;
 }
 
-// r = 3 is held to 2 waves per SIMD (256 registers, ~100 B/lane scratch): the sweeps are chains of dependent
-// HBM round trips, a second wave hides them (measured on config 3: 4.30 ms at 1 wave, 3.25 ms at 2, 4.19 ms at 3).
+// r = 3 is held to 2 waves per SIMD (256 registers, some scratch): the sweeps are chains of dependent
+// operations, a second wave fills the gaps (measured on config 3: 4.30 ms at 1 wave, 3.25 ms at 2, 4.19 ms at 3).
+//
+// Every active-set iteration is exactly ONE forward and ONE backward pass over the knots; everything else is
+// folded into them, and every HBM access of a pass is issued one knot ahead of its use:
+//   * the update of the feasible iterate z decided by the previous iteration (block-pivot clip, partial step of
+//     the ratio test, full step) is applied lazily in the forward sweep, one knot ahead of the elimination;
+//   * the decisions of the iteration -- block-pivot sets, ratio test over the free positions, multipliers of the
+//     active bounds (row 0 of the unmasked block row, finished one knot late when x_{k-1} appears) -- are
+//     accumulated in the backward sweep.
+// (The first version ran these as separate loops of dependent HBM round trips: 2-3x the time of the sweeps.)
+template <int R>
+struct SegRow0 {
+    // what the multiplier of knot j needs from a segment s: e11[c] = B11_s[0][c], e01r[c] = B01_s[0][c], e01c[c] = B01_s[c][0]
+    double e11[R], e01r[R], e01c[R];
+};
+
 template <int R>
 __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(CorridorArgs a) {
     constexpr int ND = R - 1, NC = 2 * R;
@@ -69,12 +84,14 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
     // overwritten by the solution in the backward sweep) and the current position iterate z_k.  E_k = S_k^-1 M_k is
     // NOT stored: it is re-derived from the factors where needed (the kernel is bound by this HBM traffic).
     constexpr int NL = R * (R - 1) / 2;
-    constexpr int F_L = 0, F_DI = NL, F_X = NL + R, F_Z = NL + 2 * R, F = NL + 2 * R + 1, F_H = F_X;
+    constexpr int F_L = 0, F_DI = NL, F_X = NL + R, F_Z = NL + 2 * R, F = NL + 2 * R + 1;
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_slots = gridDim.x * blockDim.x;
-    double* __restrict__ ws = a.ws + slot;
-    const size_t wst = (size_t)n_slots;
-    auto W = [&](int k, int f) -> double& { return ws[((size_t)(k - 1) * F + f) * wst]; };  // interior knot k = 1..M-1
+    // workspace: [wave][interior knot][field][lane] -- a wave's record of one knot is F consecutive 512-byte rows (one
+    // page, not F pages a batch-stride apart: the sweeps are latency-bound, TLB and DRAM-row locality matter)
+    const int kmax = (a.uniform > 0 ? a.uniform : a.max_segments) - 1;
+    double* __restrict__ ws = a.ws + (size_t)(slot >> 6) * (size_t)(kmax > 1 ? kmax : 1) * F * 64 + (slot & 63);
+    auto W = [&](int k, int f) -> double& { return ws[((size_t)(k - 1) * F + f) * 64]; };  // interior knot k = 1..M-1
 
     const long long total = (long long)a.n_traj * 3;
     for (long long g = slot; g < total; g += n_slots) {
@@ -122,16 +139,50 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
         int pdas_left = 3;  // PDAS_ITERS (measured on config 3: 3 rounds 13.8 mean iterations, 0 rounds 17.5, 10 rounds 15.7)
         bool converged = (M == 1);
         bool final_pass = false;  // max_iter hit: one last solve with every position pinned at the feasible iterate
+        // pending update of z, applied by the next forward sweep (zmode 0: none; 1: block-pivot round; 2: partial step
+        // of length zalpha blocked at knot zblock; 3: full step)
+        int zmode = 0, zblock = -1;
+        bool zblock_upper = false;
+        unsigned long long zpin = 0ull;
+        double zalpha = 1.0;
+        auto znew = [&](int k, double x0old, double zold, double l, double h) -> double {
+            const bool zp = (zpin >> k) & 1ull;
+            const double clipped = x0old < l ? l : (x0old > h ? h : x0old);
+            double z = zold;
+            if (zmode == 1) {
+                // every (newly) pinned position sits on its bound, the free ones keep a feasible iterate for the safe
+                // phase: the clipped subspace minimiser
+                z = zp ? (((eqmask >> k) & 1ull) ? zold : (((upper >> k) & 1ull) ? h : l)) : clipped;
+            } else if (zmode == 2) {
+                z = zp ? zold : (k == zblock ? (zblock_upper ? h : l) : zold + zalpha * (x0old - zold));
+            } else if (zmode == 3) {
+                z = zp ? zold : clipped;
+            }
+            return z;
+        };
+
         while (!converged) {
-            // ================= pinned block-Thomas solve =================
+            // ================= forward sweep: lazy z update + pinned block elimination =================
             {
                 FullBlocks<R> sa;
                 sa.build(T[0]);
                 SmallLDL<R> lprev;
                 double hprev[R];
+                // raw fields of knot k+1 (old x[0], old z, bounds) are in flight while knot k is eliminated
+                double zp_ = 0.0, zc, zn = 0.0;
+                double nx0 = 0.0, nz = 0.0, nl = 0.0, nh = 0.0, Tn;
+                zc = znew(1, W(1, F_X), W(1, F_Z), lo[3], hi[3]);
+                if (M > 2) { nx0 = W(2, F_X); nz = W(2, F_Z); nl = lo[6]; nh = hi[6]; }
+                Tn = T[1];
                 for (int k = 1; k < M; ++k) {
                     FullBlocks<R> sb;
-                    sb.build(T[k]);
+                    sb.build(Tn);
+                    if (k + 1 < M) {
+                        zn = znew(k + 1, nx0, nz, nl, nh);
+                        Tn = T[k + 1];
+                    }
+                    if (k + 2 < M) { nx0 = W(k + 2, F_X); nz = W(k + 2, F_Z); nl = lo[3 * (k + 2)]; nh = hi[3 * (k + 2)]; }
+                    W(k, F_Z) = zc;
                     const bool pk = (pin >> k) & 1ull;
                     const bool pprev = (k > 1) && ((pin >> (k - 1)) & 1ull);
                     const bool pnext = (k < M - 1) && ((pin >> (k + 1)) & 1ull);
@@ -148,9 +199,8 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
 #pragma unroll
                             for (int c = 0; c < R; ++c) rhs[i] -= sa.B01[c][i] * x0[c];
                     } else if (pprev) {
-                        const double zp = W(k - 1, F_Z);
 #pragma unroll
-                        for (int i = 0; i < R; ++i) rhs[i] -= sa.B01[0][i] * zp;
+                        for (int i = 0; i < R; ++i) rhs[i] -= sa.B01[0][i] * zp_;
                     }
                     if (k == M - 1) {
 #pragma unroll
@@ -158,20 +208,18 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
 #pragma unroll
                             for (int c = 0; c < R; ++c) rhs[i] -= sb.B01[i][c] * xM[c];
                     } else if (pnext) {
-                        const double zn = W(k + 1, F_Z);
 #pragma unroll
                         for (int i = 0; i < R; ++i) rhs[i] -= sb.B01[i][0] * zn;
                     }
                     if (pk) {
-                        const double zk = W(k, F_Z);
 #pragma unroll
                         for (int i = 1; i < R; ++i) {
-                            rhs[i] -= D[i][0] * zk;
+                            rhs[i] -= D[i][0] * zc;
                             D[i][0] = 0.0;
                             D[0][i] = 0.0;
                         }
                         D[0][0] = 1.0;
-                        rhs[0] = zk;
+                        rhs[0] = zc;
                     }
                     if (k > 1) {
                         // masked coupling block between (k-1, k) and E = S_{k-1}^-1 Mp from the previous factors
@@ -216,55 +264,145 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                     }
                     lprev = ldl;
                     sa = sb;
+                    zp_ = zc;
+                    zc = zn;
                 }
-                // backward sweep: x_k = h_k - S_k^-1 (M_k x_{k+1}); the state of knot k-1 is fetched while knot k is
-                // processed (one lane per (trajectory, axis) has nothing else to hide an HBM round trip per knot behind)
-                constexpr int NB = NL + 2 * R;  // factors + h
-                double xn[R], nx[NB];
+            }
+            zmode = 0;
+
+            // ================= backward sweep: x_k = h_k - S_k^-1 (M_k x_{k+1}) + the decisions of this iteration ======
+            // The record of knot k-1 (factors, h, z) and its bounds are fetched while knot k is processed.
+            const bool pdas = pdas_left > 0;
+            unsigned long long npin = eqmask, nupper = 0ull;  // block-pivot round
+            double alpha = 1.0, worst = 0.0;                    // ratio test / worst wrong-signed multiplier
+            int block = -1, rel = -1;
+            bool block_upper = false;
+            {
+                double xn[R], nx[F], nl, nh, Tn;
+                double lamA = 0.0, magA = 0.0;  // part of knot (k+1)'s multiplier known before x_k is
 #pragma unroll
-                for (int f = 0; f < NB; ++f) nx[f] = W(M - 1, f);
-                for (int k = M - 1; k >= 1; --k) {
-                    double cur[NB];
+                for (int f = 0; f < F; ++f) nx[f] = W(M - 1, f);
+                nl = lo[3 * (M - 1)];
+                nh = hi[3 * (M - 1)];
+                Tn = T[M - 1];
 #pragma unroll
-                    for (int f = 0; f < NB; ++f) cur[f] = nx[f];
-                    if (k >= 2) {
+                for (int i = 0; i < R; ++i) xn[i] = xM[i];
+                for (int k = M - 1; k >= 0; --k) {
+                    // segment k: inverse powers of its duration, coupling block B01 and the row-0 pieces
+                    const double itv = fast_rcp(Tn);
+                    double ip[2 * R];
+                    ip[0] = 1.0;
 #pragma unroll
-                        for (int f = 0; f < NB; ++f) nx[f] = W(k - 1, f);
+                    for (int j = 1; j < 2 * R; ++j) ip[j] = ip[j - 1] * itv;
+                    SegRow0<R> s0r;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        const double p = ip[2 * R - 1 - c];
+                        s0r.e11[c] = p * Tab<R>::W(0, c);
+                        s0r.e01r[c] = -p * Tab<R>::V(0, c);
+                        s0r.e01c[c] = -p * Tab<R>::V(c, 0);
                     }
                     double x[R];
+                    double zk = 0.0, lk = 0.0, hk = 0.0;
+                    if (k >= 1) {
+                        double cur[F];
 #pragma unroll
-                    for (int i = 0; i < R; ++i) x[i] = cur[F_X + i];
-                    if (k < M - 1) {
-                        FullBlocks<R> sb;
-                        sb.build(T[k]);
-                        const bool pk = (pin >> k) & 1ull;
-                        const bool pnext = (pin >> (k + 1)) & 1ull;
-                        double t[R];
+                        for (int f = 0; f < F; ++f) cur[f] = nx[f];
+                        lk = nl;
+                        hk = nh;
+                        zk = cur[F_Z];
+                        if (k >= 2) {
 #pragma unroll
-                        for (int i = 0; i < R; ++i) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int c = 0; c < R; ++c) acc += (((pk && i == 0) || (pnext && c == 0)) ? 0.0 : sb.B01[i][c]) * xn[c];
-                            t[i] = acc;
+                            for (int f = 0; f < F; ++f) nx[f] = W(k - 1, f);
+                            nl = lo[3 * (k - 1)];
+                            nh = hi[3 * (k - 1)];
                         }
-                        SmallLDL<R> ldl;
-                        {
-                            int f = 0;
+                        Tn = T[k - 1];
 #pragma unroll
-                            for (int i = 1; i < R; ++i)
+                        for (int i = 0; i < R; ++i) x[i] = cur[F_X + i];
+                        if (k < M - 1) {
+                            const bool pk = (pin >> k) & 1ull;
+                            const bool pnext = (pin >> (k + 1)) & 1ull;
+                            double t[R];
 #pragma unroll
-                                for (int c = 0; c < i; ++c) ldl.l[i][c] = cur[F_L + (f++)];
+                            for (int i = 0; i < R; ++i) {
+                                double acc = 0.0;
+#pragma unroll
+                                for (int c = 0; c < R; ++c) {
+                                    const double m = -ip[2 * R - 1 - i - c] * Tab<R>::V(i, c);  // B01 of segment k
+                                    acc += (((pk && i == 0) || (pnext && c == 0)) ? 0.0 : m) * xn[c];
+                                }
+                                t[i] = acc;
+                            }
+                            SmallLDL<R> ldl;
+                            {
+                                int f = 0;
+#pragma unroll
+                                for (int i = 1; i < R; ++i)
+#pragma unroll
+                                    for (int c = 0; c < i; ++c) ldl.l[i][c] = cur[F_L + (f++)];
+                            }
+#pragma unroll
+                            for (int i = 0; i < R; ++i) ldl.dinv[i] = cur[F_DI + i];
+                            ldl.solve(t);
+#pragma unroll
+                            for (int i = 0; i < R; ++i) x[i] -= t[i];
+#pragma unroll
+                            for (int i = 0; i < R; ++i) W(k, F_X + i) = x[i];
                         }
+                    } else {
 #pragma unroll
-                        for (int i = 0; i < R; ++i) ldl.dinv[i] = cur[F_DI + i];
-                        ldl.solve(t);
-#pragma unroll
-                        for (int i = 0; i < R; ++i) x[i] -= t[i];
-#pragma unroll
-                        for (int i = 0; i < R; ++i) W(k, F_X + i) = x[i];
+                        for (int i = 0; i < R; ++i) x[i] = x0[i];
                     }
+                    // ---- multiplier of knot j = k+1, now that x_k is known: d(cost)/d p_j (up to the factor 2), row 0 of
+                    // the unmasked block row;  lower bound active: need lam >= 0, upper: lam <= 0
+                    if (k + 1 <= M - 1) {
+                        const int j = k + 1;
+                        double lam = lamA, mag = magA;
 #pragma unroll
-                    for (int i = 0; i < R; ++i) xn[i] = x[i];
+                        for (int c = 0; c < R; ++c) {
+                            const double t1 = s0r.e01c[c] * x[c], t2 = s0r.e11[c] * xn[c];
+                            lam += t1 + t2;
+                            mag += fabs(t1) + fabs(t2);
+                        }
+                        const bool pj = (pin >> j) & 1ull, ej = (eqmask >> j) & 1ull, uj = (upper >> j) & 1ull;
+                        const double viol = uj ? lam : -lam;
+                        const bool wrong = viol > 1e-11 * mag;
+                        if (pj && !ej) {
+                            if (!wrong) {  // multiplier has the right sign: stays active in a block-pivot round
+                                npin |= 1ull << j;
+                                if (uj) nupper |= 1ull << j;
+                            } else if (viol > worst || (viol == worst && rel >= 0)) {  // ties: the lowest knot, as an ascending scan
+                                worst = viol;
+                                rel = j;
+                            }
+                        }
+                    }
+                    if (k >= 1) {
+                        // ---- first half of knot k's multiplier (needs x_k and x_{k+1} only)
+                        lamA = 0.0;
+                        magA = 0.0;
+#pragma unroll
+                        for (int c = 0; c < R; ++c) {
+                            const double t2 = ((c & 1) ? -s0r.e11[c] : s0r.e11[c]) * x[c], t3 = s0r.e01r[c] * xn[c];
+                            lamA += t2 + t3;
+                            magA += fabs(t2) + fabs(t3);
+                        }
+                        // ---- free position: outside its box?
+                        if (!((pin >> k) & 1ull)) {
+                            const double ph = x[0];
+                            const bool below = ph < lk - 1e-12 * (1.0 + fabs(lk));
+                            const bool above = !below && (ph > hk + 1e-12 * (1.0 + fabs(hk)));
+                            if (below || above) {
+                                npin |= 1ull << k;
+                                if (above) nupper |= 1ull << k;
+                                const double al = ((above ? hk : lk) - zk) / (ph - zk);
+                                if (al < alpha || (al == alpha && block >= 0)) { alpha = al; block = k; block_upper = above; }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < R; ++i) xn[i] = x[i];
+                    }
                 }
             }
             if (final_pass) break;
@@ -274,127 +412,40 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
             // pinned at the violated bound, every pinned one whose multiplier has the wrong sign is released.
             // It usually identifies the active set in 2-3 solves (vs one change per solve) but is not monotone, so
             // after PDAS_ITERS rounds the safe single-pivot method below takes over from the clipped (feasible) point.
-            if (pdas_left > 0) {
-                unsigned long long npin = eqmask, nupper = 0ull;
-                {
-                    FullBlocks<R> sa;
-                    sa.build(T[0]);
-                    for (int k = 1; k < M; ++k) {
-                        FullBlocks<R> sb;
-                        sb.build(T[k]);
-                        const double l = lo[3 * k], h = hi[3 * k];
-                        if ((eqmask >> k) & 1ull) {
-                        } else if ((pin >> k) & 1ull) {
-                            double lam = 0.0, mag = 0.0;
-#pragma unroll
-                            for (int c = 0; c < R; ++c) {
-                                const double xp = (k == 1) ? x0[c] : W(k - 1, F_X + c);
-                                const double xk = W(k, F_X + c);
-                                const double xq = (k == M - 1) ? xM[c] : W(k + 1, F_X + c);
-                                const double t1 = sa.B01[c][0] * xp, t2 = (sa.B11[0][c] + sb.B00(0, c)) * xk, t3 = sb.B01[0][c] * xq;
-                                lam += t1 + t2 + t3;
-                                mag += fabs(t1) + fabs(t2) + fabs(t3);
-                            }
-                            const bool up = (upper >> k) & 1ull;
-                            const double viol = up ? lam : -lam;
-                            if (!(viol > 1e-11 * mag)) {  // multiplier has the right sign: stays active
-                                npin |= 1ull << k;
-                                if (up) nupper |= 1ull << k;
-                            }
-                        } else {
-                            const double ph = W(k, F_X);
-                            if (ph < l - 1e-12 * (1.0 + fabs(l))) npin |= 1ull << k;
-                            else if (ph > h + 1e-12 * (1.0 + fabs(h))) { npin |= 1ull << k; nupper |= 1ull << k; }
-                        }
-                        sa = sb;
-                    }
-                }
+            if (pdas) {
                 ++it;
-                if (npin == pin && nupper == upper) {
-                    // KKT point: free positions feasible, all multipliers right
-                    for (int k = 1; k < M; ++k)
-                        if (!((pin >> k) & 1ull)) W(k, F_Z) = W(k, F_X);
+                if (npin == pin && nupper == upper) {  // KKT point: free positions feasible, all multipliers right
                     converged = true;
                     continue;
                 }
                 --pdas_left;
-                for (int k = 1; k < M; ++k) {
-                    const double l = lo[3 * k], h = hi[3 * k];
-                    if ((npin >> k) & 1ull) {
-                        if (!((eqmask >> k) & 1ull)) W(k, F_Z) = ((nupper >> k) & 1ull) ? h : l;
-                    } else {
-                        // keep a feasible iterate for the safe phase: clip the subspace minimiser
-                        double z = W(k, F_X);
-                        W(k, F_Z) = z < l ? l : (z > h ? h : z);
-                    }
-                }
+                zmode = 1;
+                zpin = npin;
                 pin = npin;
                 upper = nupper;
                 if (it >= a.max_iter) { pin = ~0ull; final_pass = true; }
                 continue;
             }
 
-            // ================= ratio test on the free positions =================
-            double alpha = 1.0;
-            int block = -1;
-            bool block_upper = false;
-            for (int k = 1; k < M; ++k) {
-                if ((pin >> k) & 1ull) continue;
-                const double ph = W(k, F_X), zc = W(k, F_Z), l = lo[3 * k], h = hi[3 * k];
-                if (ph < l - 1e-12 * (1.0 + fabs(l))) {
-                    const double al = (l - zc) / (ph - zc);
-                    if (al < alpha) { alpha = al; block = k; block_upper = false; }
-                } else if (ph > h + 1e-12 * (1.0 + fabs(h))) {
-                    const double al = (h - zc) / (ph - zc);
-                    if (al < alpha) { alpha = al; block = k; block_upper = true; }
-                }
-            }
+            // ================= safe phase: primal active set, one change per solve =================
             if (block >= 0) {
-                if (alpha < 0.0) alpha = 0.0;
-                for (int k = 1; k < M; ++k) {
-                    if ((pin >> k) & 1ull) continue;
-                    const double zc = W(k, F_Z);
-                    W(k, F_Z) = zc + alpha * (W(k, F_X) - zc);
-                }
-                W(block, F_Z) = block_upper ? hi[3 * block] : lo[3 * block];
+                // partial step to the first blocking bound, which joins the working set
+                zmode = 2;
+                zpin = pin;
+                zblock = block;
+                zblock_upper = block_upper;
+                zalpha = alpha < 0.0 ? 0.0 : alpha;
                 pin |= 1ull << block;
                 if (block_upper) upper |= 1ull << block; else upper &= ~(1ull << block);
             } else {
-                // full step: free positions move to the subspace minimiser; check the multipliers of the active bounds
-                for (int k = 1; k < M; ++k)
-                    if (!((pin >> k) & 1ull)) {
-                        const double l = lo[3 * k], h = hi[3 * k];
-                        double z = W(k, F_X);
-                        W(k, F_Z) = z < l ? l : (z > h ? h : z);
-                    }
-                double worst = 0.0;
-                int rel = -1;
-                if (pin != eqmask) {
-                    FullBlocks<R> sa;
-                    sa.build(T[0]);
-                    for (int k = 1; k < M; ++k) {
-                        FullBlocks<R> sb;
-                        sb.build(T[k]);
-                        if (((pin & ~eqmask) >> k) & 1ull) {
-                            // d(cost)/d p_k (up to the factor 2): row 0 of the unmasked block row
-                            double lam = 0.0, mag = 0.0;
-#pragma unroll
-                            for (int c = 0; c < R; ++c) {
-                                const double xp = (k == 1) ? x0[c] : W(k - 1, F_X + c);
-                                const double xk = W(k, F_X + c);
-                                const double xq = (k == M - 1) ? xM[c] : W(k + 1, F_X + c);
-                                const double t1 = sa.B01[c][0] * xp, t2 = (sa.B11[0][c] + sb.B00(0, c)) * xk, t3 = sb.B01[0][c] * xq;
-                                lam += t1 + t2 + t3;
-                                mag += fabs(t1) + fabs(t2) + fabs(t3);
-                            }
-                            const double viol = ((upper >> k) & 1ull) ? lam : -lam;  // lower: need lam >= 0, upper: lam <= 0
-                            if (viol > 1e-11 * mag && viol > worst) { worst = viol; rel = k; }
-                        }
-                        sa = sb;
-                    }
+                // full step: free positions move to the subspace minimiser; release the worst wrong-signed multiplier
+                if (rel < 0) {
+                    converged = true;
+                } else {
+                    zmode = 3;
+                    zpin = pin;
+                    pin &= ~(1ull << rel);
                 }
-                if (rel < 0) converged = true;
-                else pin &= ~(1ull << rel);
             }
             ++it;
             if (!converged && it >= a.max_iter) {
@@ -403,20 +454,33 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
             }
         }
 
-        // ================= emission =================
+        // ================= emission (record of knot k-1 in flight while segment k is written) =================
         double xe[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) xe[i] = xM[i];
         bool finite = true;
+        double nxs[R + 1], Tn = T[M - 1];
+        if (M >= 2) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) nxs[i] = W(M - 1, F_X + i);
+            nxs[R] = W(M - 1, F_Z);
+        }
         for (int k = M - 1; k >= 0; --k) {
             double xs[R];
+            const double Tk = Tn;
             if (k == 0) {
 #pragma unroll
                 for (int i = 0; i < R; ++i) xs[i] = x0[i];
             } else {
 #pragma unroll
-                for (int i = 0; i < R; ++i) xs[i] = W(k, F_X + i);
-                if (!final_pass && ((pin >> k) & 1ull)) xs[0] = W(k, F_Z);  // pinned positions: exact bound value
+                for (int i = 0; i < R; ++i) xs[i] = nxs[i];
+                if (!final_pass && ((pin >> k) & 1ull)) xs[0] = nxs[R];  // pinned positions: exact bound value
+                if (k >= 2) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) nxs[i] = W(k - 1, F_X + i);
+                    nxs[R] = W(k - 1, F_Z);
+                }
+                Tn = T[k - 1];
             }
             double ys[ND], ye[ND], c[NC];
 #pragma unroll
@@ -424,7 +488,6 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                 ys[d] = xs[d + 1];
                 ye[d] = xe[d + 1];
             }
-            const double Tk = T[k];
             segment_coeffs<R>(xs[0], ys, xe[0], ye, Tk, fast_rcp(Tk), c);
             double* o = out + (size_t)k * NC;
 #pragma unroll

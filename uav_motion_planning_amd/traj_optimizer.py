@@ -88,6 +88,18 @@ class Context:
                                                      float(robot_r), float(robot_h), p(first_hit), p(flags))
         _lib.check(rc, "uavqp_ellipsoid_check_device")
 
+    def corridor_from_cloud_device(self, r, n_traj, uniform_segments, seg_offsets, n_rows, waypoints, times, coeff,
+                                   obstacles, n_obs, robot_r, robot_h, h_max, corr_lo, corr_hi, clearance=None):
+        """Corridor boxes of every waypoint row from an obstacle cloud, robot ellipsoid of kino_astar.cpp:721-758
+        (device buffers; coeff/times None = hover attitude)."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_corridor_from_cloud_device(self._h, r, n_traj, uniform_segments, p(seg_offsets), int(n_rows),
+                                                         p(waypoints), p(times), p(coeff), p(obstacles), int(n_obs),
+                                                         float(robot_r), float(robot_h), float(h_max), p(corr_lo), p(corr_hi),
+                                                         p(clearance))
+        _lib.check(rc, "uavqp_corridor_from_cloud_device")
+
     def capture_begin(self):
         """Start hipGraph capture of everything subsequently enqueued on the ctx stream."""
         _lib.check(_lib.lib().uavqp_capture_begin(self._h), "uavqp_capture_begin")

@@ -113,3 +113,35 @@ def corridor_boxes(batch, config_index=3, h_lo=0.3, h_hi=0.8, seed=None):
         lo[idx] = flat[idx]
         hi[idx] = flat[idx]
     return lo.reshape(wp.shape), hi.reshape(wp.shape)
+
+
+def pillar_cloud(config_index=5, n_pillars=60, resolution=0.2, radius=(0.5, 0.7), height=3.0, box=None, seed=None,
+                 keep_clear=None, clear_radius=1.0):
+    """Obstacle point cloud in the style of the reference's random map (simulator map_generator,
+    random_forest.cpp:203-228: vertical pillars rasterised at `resolution_`, points at voxel centres + 1e-2;
+    pillar radii 0.5-0.7, simulator.xml:26-27) over the reference map box.  Only the shell of each pillar is kept
+    (interior voxels can never be the nearest obstacle of a free waypoint).  keep_clear: optional [k,3] points
+    (e.g. start positions) no pillar axis may come within `clear_radius` + radius of.  Returns [n_obs, 3] float64."""
+    rng = np.random.default_rng(SEED0 + 200 + config_index if seed is None else seed)
+    lo_b, hi_b = (BOX_LO, BOX_HI) if box is None else box
+    pts = []
+    kc = None if keep_clear is None else np.asarray(keep_clear, dtype=np.float64).reshape(-1, 3)[:, :2]
+    placed, tries = 0, 0
+    while placed < n_pillars and tries < 100 * n_pillars:
+        tries += 1
+        c = rng.uniform(lo_b[:2], hi_b[:2])
+        rad = rng.uniform(*radius)
+        if kc is not None and kc.size and np.min(np.linalg.norm(kc - c, axis=1)) < clear_radius + rad:
+            continue
+        c = np.floor(c / resolution) * resolution + resolution / 2.0
+        nw = int(np.ceil(rad / resolution)) + 1
+        g = (np.arange(-nw, nw + 1) + 0.5) * resolution
+        xx, yy = np.meshgrid(g, g, indexing="ij")
+        d = np.hypot(xx, yy)
+        shell = (d <= rad) & (d > rad - 1.5 * resolution)
+        zz = (np.arange(int(np.ceil(height / resolution))) + 0.5) * resolution
+        xy = np.stack([xx[shell] + c[0], yy[shell] + c[1]], axis=1) + 1e-2
+        p = np.concatenate([np.repeat(xy, zz.size, axis=0), np.tile(zz + 1e-2, xy.shape[0])[:, None]], axis=1)
+        pts.append(p)
+        placed += 1
+    return np.concatenate(pts) if pts else np.zeros((0, 3))
