@@ -130,6 +130,20 @@ int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj, int unifo
                                     const double* bc, const double* corr_lo, const double* corr_hi,
                                     double* coeff_out, int32_t* status_out, int32_t* iters_out);
 
+/* Warm-started corridor solve for outer loops (BASELINE config 5: the corridor QP is re-solved after every time
+ * re-allocation, and its working set barely moves).  Same problem, same result as uavqp_solve_corridor_batch_device;
+ * d_active_set [n_traj][3][2] uint64 holds per (trajectory, axis) the working set of the active-set method: word 0
+ * bit k = the box of interior waypoint k (1 <= k <= M-1 <= 63) is active, word 1 bit k = at its upper bound.
+ *   warm_start == 0: the buffer is only written (working set at the solution);
+ *   warm_start != 0: it is read as the initial working set (any bit pattern is a valid guess: wrong guesses cost
+ *                    iterations, never correctness) and overwritten with the final one.
+ * A trajectory that ends UAVQP_MAX_ITER_REACHED writes an empty set.  No reference counterpart. */
+int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                     const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                     const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
+                                     double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
+                                     uint64_t* d_active_set, int warm_start);
+
 /* Time re-allocation step of the outer loop of BASELINE config 5 (north-star extension; the reference uses a
  * constant 1.0 s per segment, test_minimum_jerk.cpp:65-71, and has no such loop -- nothing to mirror, parity is
  * per inner solve).  The 3-axis speed |v| and acceleration |a| of the solved polynomials are sampled at

@@ -172,3 +172,62 @@ def test_config5_shape_corridor_plus_time_reallocation_outer_loop(oracle):
                                                b["bc"][k, 0, :, ax], b["bc"][k, 1, :, ax],
                                                lo[so[k] + k + 1:so[k + 1] + k, ax], hi[so[k] + k + 1:so[k + 1] + k, ax])
             assert prim < 1e-9 and stat < 1e-7 and comp < 1e-6
+
+
+@pytest.mark.parametrize("r,ragged", [(3, False), (4, True)])
+def test_warm_started_corridor_solve(gpu_ctx, r, ragged):
+    """uavqp_solve_corridor_warm_device: (1) restarting from the working set of the solution takes exactly one
+    iteration and reproduces the cold solve bit for bit (same pins, same pinned values, same arithmetic);
+    (2) ANY bit pattern is an admissible guess -- random sets still end at the same minimiser (1e-9 relative);
+    (3) after a 10 % time re-allocation the previous working set is a good guess: far fewer iterations than cold."""
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    if ragged:
+        n = 150
+        b = W.ragged_batch(5, n, r, m_lo=2, m_hi=20)
+        uni, mx = 0, 20
+    else:
+        n, M = 200, 16
+        b = W.uniform_batch(3, n, M, r, time_mode="distance")
+        uni, mx = M, M
+    so = b["seg_offsets"]
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    d_so = up(so) if ragged else None
+    d_wp, d_T, d_bc, d_lo, d_hi = up(b["waypoints"]), up(b["times"]), up(b["bc"]), up(lo), up(hi)
+    nco = int(so[-1]) * 6 * r
+
+    def run(active, warm, times=d_T):
+        out = torch.zeros(nco, dtype=torch.float64, device=dev)
+        st = torch.zeros(n, dtype=torch.int32, device=dev)
+        it = torch.zeros(n, dtype=torch.int32, device=dev)
+        gpu_ctx.solve_corridor_device(r, n, uni, mx, d_so, d_wp, times, d_bc, d_lo, d_hi, out, st, it, active, warm)
+        gpu_ctx.synchronize()
+        assert bool((st == U.UAVQP_SOLVED).all())
+        return out.cpu().numpy(), it.cpu().numpy()
+
+    act = torch.zeros((n, 3, 2), dtype=torch.int64, device=dev)
+    c_cold, it_cold = run(act, False)
+    c_plain, _ = run(None, False)
+    assert np.array_equal(c_cold, c_plain)
+    sets = act.cpu().numpy().copy()
+    assert np.any(sets[:, :, 0] != 0)                       # some boxes are active at the solution
+    assert np.all((sets[:, :, 1] & ~sets[:, :, 0]) == 0)    # "upper" only where active
+    # (1) exact restart
+    c_warm, it_warm = run(act, True)
+    assert np.array_equal(c_warm, c_cold)
+    assert np.all(it_warm == 1)
+    assert np.array_equal(act.cpu().numpy(), sets)
+    # (2) garbage guesses
+    rng = np.random.default_rng(9)
+    junk = torch.from_numpy(rng.integers(-2**63, 2**63 - 1, size=(n, 3, 2), dtype=np.int64)).to(dev)
+    c_junk, it_junk = run(junk, True)
+    assert np.max(np.abs(c_junk - c_cold)) <= 1e-9 * np.max(np.abs(c_cold))
+    assert np.array_equal(junk.cpu().numpy(), sets)
+    # (3) outer-loop situation
+    d_T2 = d_T * 1.1
+    act2 = act.clone()
+    c2_warm, it2_warm = run(act2, True, d_T2)
+    c2_cold, it2_cold = run(None, False, d_T2)
+    assert np.max(np.abs(c2_warm - c2_cold)) <= 1e-9 * np.max(np.abs(c2_cold))
+    assert it2_warm.mean() < 0.5 * it2_cold.mean()

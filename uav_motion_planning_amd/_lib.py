@@ -35,6 +35,7 @@ SYMBOLS = (
     "uavqp_solve_axis_host",
     "uavqp_solve_corridor_batch_device",
     "uavqp_solve_corridor_batch_host",
+    "uavqp_solve_corridor_warm_device",
     "uavqp_time_reallocate_device",
     "uavqp_eval_batch_device",
     "uavqp_ellipsoid_check_device",
@@ -92,6 +93,7 @@ def lib():
     L.uavqp_solve_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
     L.uavqp_solve_axis_host.argtypes = [vp, i32, i32, dp, dp, dp, dp, dp, dp, ctypes.POINTER(ctypes.c_int32)]
     L.uavqp_solve_corridor_batch_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip]
+    L.uavqp_solve_corridor_warm_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip, vp, i32]
     L.uavqp_solve_corridor_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip]
     L.uavqp_time_reallocate_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, ctypes.c_double, ctypes.c_double, i32, ctypes.c_double, ip]
     L.uavqp_eval_batch_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, i32, dp]

@@ -29,6 +29,8 @@ struct CorridorArgs {
     int32_t* status;  // pre-filled with UAVQP_SOLVED; failing axes atomicMin their code in
     int32_t* iters;   // pre-filled with 0; atomicMax over axes (may be null)
     double* ws;
+    unsigned long long* active;  // [n_traj][3][2] working set in/out (may be null)
+    int warm;                    // read `active` as the initial working set
 };
 
 // r x r blocks of one segment including the position component (index 0):
@@ -125,15 +127,29 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
         }
 
         // ---- initial feasible point and permanent pins (lo == hi: a true equality row, as in the reference)
+        // A warm start only supplies the first working set (bounds guessed active sit on their bound); wrong guesses
+        // are repaired by the iterations below like any other intermediate working set.
         unsigned long long eqmask = 0ull, pin = 0ull, upper = 0ull;
+        unsigned long long wpin = 0ull, wupper = 0ull;
+        if (a.active && a.warm) {
+            wpin = a.active[2 * g];
+            wupper = a.active[2 * g + 1];
+        }
         for (int k = 1; k < M; ++k) {
             const double l = lo[3 * k], h = hi[3 * k];
             double z = wp[3 * k];
             z = z < l ? l : (z > h ? h : z);
+            if (l == h) {
+                eqmask |= 1ull << k;
+            } else if ((wpin >> k) & 1ull) {
+                const bool up = (wupper >> k) & 1ull;
+                z = up ? h : l;
+                pin |= 1ull << k;
+                if (up) upper |= 1ull << k;
+            }
             W(k, F_Z) = z;
-            if (l == h) eqmask |= 1ull << k;
         }
-        pin = eqmask;
+        pin |= eqmask;
 
         int it = 0;
         int pdas_left = 3;  // PDAS_ITERS (measured on config 3: 3 rounds 13.8 mean iterations, 0 rounds 17.5, 10 rounds 15.7)
@@ -499,6 +515,12 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
         if (!finite) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
         else if (final_pass) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
         if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
+        if (a.active) {
+            const unsigned long long valid = M >= 2 ? ((1ull << M) - 2ull) : 0ull;  // bits 1..M-1
+            const unsigned long long fin = final_pass ? 0ull : (pin & ~eqmask & valid);
+            a.active[2 * g] = fin;
+            a.active[2 * g + 1] = upper & fin;
+        }
     }
 }
 

@@ -974,17 +974,20 @@ extern "C" int uavqp_eval_batch_device(uavqp_ctx* ctx, int r, int n_traj, int un
     return UAVQP_OK;
 }
 
-extern "C" int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
-                                                 const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
-                                                 const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
-                                                 double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out) {
+extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                                const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                                const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
+                                                double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
+                                                uint64_t* d_active_set, int warm_start) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
     if (n_traj == 0) return UAVQP_OK;
     if (!d_waypoints || !d_times || !d_bc || !d_corr_lo || !d_corr_hi || !d_coeff_out || !d_status_out) return UAVQP_ERR_INVALID_ARG;
     if (uniform_segments == 0 && (!d_seg_offsets || max_segments < 1)) return UAVQP_ERR_INVALID_ARG;
+    if (warm_start && !d_active_set) return UAVQP_ERR_INVALID_ARG;
     UAVQP_HIP(hipSetDevice(ctx->device));
     const int Mmax = uniform_segments > 0 ? uniform_segments : max_segments;
     uavqp::CorridorArgs a;
+    a.active = (unsigned long long*)d_active_set; a.warm = warm_start ? 1 : 0;
     a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax; a.max_iter = 8 * Mmax + 20;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.coeff = d_coeff_out; a.status = d_status_out; a.iters = d_iters_out;
@@ -1006,6 +1009,14 @@ extern "C" int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_tr
         hipLaunchKernelGGL(uavqp::solve_corridor_kernel<4>, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
+}
+
+extern "C" int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                                 const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                                 const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
+                                                 double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out) {
+    return uavqp_solve_corridor_warm_device(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times, d_bc,
+                                            d_corr_lo, d_corr_hi, d_coeff_out, d_status_out, d_iters_out, nullptr, 0);
 }
 
 extern "C" int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,

@@ -88,6 +88,17 @@ class Context:
                                                      float(robot_r), float(robot_h), p(first_hit), p(flags))
         _lib.check(rc, "uavqp_ellipsoid_check_device")
 
+    def solve_corridor_device(self, r, n_traj, uniform_segments, max_segments, seg_offsets, waypoints, times, bc, corr_lo, corr_hi,
+                              coeff_out, status_out, iters_out=None, active_set=None, warm_start=False):
+        """Corridor-constrained solve on device buffers; active_set ([n_traj,3,2] int64/uint64 device tensor) carries the
+        working set between the re-solves of an outer loop (warm_start=True reads it)."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_solve_corridor_warm_device(self._h, r, n_traj, uniform_segments, max_segments, p(seg_offsets), p(waypoints),
+                                                         p(times), p(bc), p(corr_lo), p(corr_hi), p(coeff_out), p(status_out),
+                                                         p(iters_out), p(active_set), 1 if warm_start else 0)
+        _lib.check(rc, "uavqp_solve_corridor_warm_device")
+
     def corridor_from_cloud_device(self, r, n_traj, uniform_segments, seg_offsets, n_rows, waypoints, times, coeff,
                                    obstacles, n_obs, robot_r, robot_h, h_max, corr_lo, corr_hi, clearance=None):
         """Corridor boxes of every waypoint row from an obstacle cloud, robot ellipsoid of kino_astar.cpp:721-758
