@@ -74,7 +74,9 @@ int uavqp_create(uavqp_ctx** out_ctx, int device);
 int uavqp_destroy(uavqp_ctx* ctx);
 
 /* Run all subsequent device work of this ctx on an existing hipStream_t (e.g. the caller's compute
- * stream).  NULL restores the ctx-owned stream. */
+ * stream).  NULL restores the ctx-owned stream.  The ctx's sweep workspaces are shared by its calls and
+ * ordered by the stream: work still in flight on the previous stream must be complete before switching
+ * (uavqp_synchronize), and concurrent streams need one ctx each. */
 int uavqp_set_stream(uavqp_ctx* ctx, void* hip_stream);
 int uavqp_synchronize(uavqp_ctx* ctx);
 

@@ -82,6 +82,9 @@ struct SegRow0 {
 template <int R>
 __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(CorridorArgs a) {
     constexpr int ND = R - 1, NC = 2 * R;
+    // prefetch distance in knots: 2 for r = 4 (one wave per SIMD, nothing else hides a round trip; config 5 corridor
+    // solve 2.90 -> 2.76 ms), 1 for r = 3 (two waves per SIMD; the second buffer only costs registers there)
+    constexpr bool PF2 = (R == 4);
     // sweep state per interior knot: LDL' factors of S_k (strict lower triangle + inverse pivots), x_k (first h_k,
     // overwritten by the solution in the backward sweep) and the current position iterate z_k.  E_k = S_k^-1 M_k is
     // NOT stored: it is re-derived from the factors where needed (the kernel is bound by this HBM traffic).
@@ -186,18 +189,27 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                 double hprev[R];
                 // raw fields of knot k+1 (old x[0], old z, bounds) are in flight while knot k is eliminated
                 double zp_ = 0.0, zc, zn = 0.0;
-                double nx0 = 0.0, nz = 0.0, nl = 0.0, nh = 0.0, Tn;
+                double nx0 = 0.0, nz = 0.0, nl = 0.0, nh = 0.0, Tn;      // knot k+1
+                double mx0 = 0.0, mz = 0.0, ml = 0.0, mh = 0.0, Tm = 1.0;  // knot k+2
                 zc = znew(1, W(1, F_X), W(1, F_Z), lo[3], hi[3]);
                 if (M > 2) { nx0 = W(2, F_X); nz = W(2, F_Z); nl = lo[6]; nh = hi[6]; }
                 Tn = T[1];
+                if constexpr (PF2) {
+                    if (M > 3) { mx0 = W(3, F_X); mz = W(3, F_Z); ml = lo[9]; mh = hi[9]; }
+                    if (M > 2) Tm = T[2];
+                }
                 for (int k = 1; k < M; ++k) {
                     FullBlocks<R> sb;
                     sb.build(Tn);
-                    if (k + 1 < M) {
-                        zn = znew(k + 1, nx0, nz, nl, nh);
-                        Tn = T[k + 1];
+                    if (k + 1 < M) zn = znew(k + 1, nx0, nz, nl, nh);
+                    if constexpr (PF2) {
+                        nx0 = mx0; nz = mz; nl = ml; nh = mh; Tn = Tm;
+                        if (k + 3 < M) { mx0 = W(k + 3, F_X); mz = W(k + 3, F_Z); ml = lo[3 * (k + 3)]; mh = hi[3 * (k + 3)]; }
+                        if (k + 2 < M) Tm = T[k + 2];
+                    } else {
+                        if (k + 2 < M) { nx0 = W(k + 2, F_X); nz = W(k + 2, F_Z); nl = lo[3 * (k + 2)]; nh = hi[3 * (k + 2)]; }
+                        if (k + 1 < M) Tn = T[k + 1];
                     }
-                    if (k + 2 < M) { nx0 = W(k + 2, F_X); nz = W(k + 2, F_Z); nl = lo[3 * (k + 2)]; nh = hi[3 * (k + 2)]; }
                     W(k, F_Z) = zc;
                     const bool pk = (pin >> k) & 1ull;
                     const bool pprev = (k > 1) && ((pin >> (k - 1)) & 1ull);
@@ -294,13 +306,20 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
             int block = -1, rel = -1;
             bool block_upper = false;
             {
-                double xn[R], nx[F], nl, nh, Tn;
+                double xn[R], nx[F], nl, nh, Tn;            // record of the knot processed next
+                double mx[F], ml = 0.0, mh = 0.0, Tm = 1.0;  // ... and of the one after it
                 double lamA = 0.0, magA = 0.0;  // part of knot (k+1)'s multiplier known before x_k is
 #pragma unroll
                 for (int f = 0; f < F; ++f) nx[f] = W(M - 1, f);
                 nl = lo[3 * (M - 1)];
                 nh = hi[3 * (M - 1)];
                 Tn = T[M - 1];
+                if constexpr (PF2) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) mx[f] = M > 2 ? W(M - 2, f) : 0.0;
+                    if (M > 2) { ml = lo[3 * (M - 2)]; mh = hi[3 * (M - 2)]; }
+                    Tm = T[M - 2];
+                }
 #pragma unroll
                 for (int i = 0; i < R; ++i) xn[i] = xM[i];
                 for (int k = M - 1; k >= 0; --k) {
@@ -327,13 +346,28 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                         lk = nl;
                         hk = nh;
                         zk = cur[F_Z];
-                        if (k >= 2) {
+                        if constexpr (PF2) {
 #pragma unroll
-                            for (int f = 0; f < F; ++f) nx[f] = W(k - 1, f);
-                            nl = lo[3 * (k - 1)];
-                            nh = hi[3 * (k - 1)];
+                            for (int f = 0; f < F; ++f) nx[f] = mx[f];
+                            nl = ml;
+                            nh = mh;
+                            Tn = Tm;
+                            if (k >= 3) {
+#pragma unroll
+                                for (int f = 0; f < F; ++f) mx[f] = W(k - 2, f);
+                                ml = lo[3 * (k - 2)];
+                                mh = hi[3 * (k - 2)];
+                            }
+                            if (k >= 2) Tm = T[k - 2];
+                        } else {
+                            if (k >= 2) {
+#pragma unroll
+                                for (int f = 0; f < F; ++f) nx[f] = W(k - 1, f);
+                                nl = lo[3 * (k - 1)];
+                                nh = hi[3 * (k - 1)];
+                            }
+                            Tn = T[k - 1];
                         }
-                        Tn = T[k - 1];
 #pragma unroll
                         for (int i = 0; i < R; ++i) x[i] = cur[F_X + i];
                         if (k < M - 1) {

@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void cloud_corridor_kernel(CloudCorridorArgs a
 // Time re-allocation: one lane per segment; peak |v|, |a| by sampling, stretch-only update of T.
 // ---------------------------------------------------------------------------------------------------
 struct ReallocArgs {
-    int n_traj, uniform, total_seg, samples;
+    int n_traj, uniform, samples;
     const int32_t* seg_offsets;
     double* times;
     const double* coeff;
@@ -1087,9 +1087,8 @@ extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, i
     if (n_traj == 0) return UAVQP_OK;
     if (!d_times || !d_coeff || (uniform_segments == 0 && !d_seg_offsets)) return UAVQP_ERR_INVALID_ARG;
     UAVQP_HIP(hipSetDevice(ctx->device));
-    const int total_seg = 0;  // (unused: one lane per trajectory)
     uavqp::ReallocArgs a;
-    a.n_traj = n_traj; a.uniform = uniform_segments; a.total_seg = total_seg; a.samples = samples_per_seg;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.samples = samples_per_seg;
     a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.v_max = v_max; a.a_max = a_max;
     a.max_stretch = max_stretch; a.changed = d_changed_out;
     int grid = (n_traj + 63) / 64;
