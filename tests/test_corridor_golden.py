@@ -1,0 +1,71 @@
+"""Exact-rational corridor fixtures (tests/golden/corridor_exact.json, made by gen_golden_corridor.py by
+enumerating every active set in Fractions on the reference-formulation matrices).
+
+CPU (not gpu): the OSQP-faithful port with inequality rows must converge to them (tolerance 1e-6 relative to
+max|coef| at eps 1e-10: what ADMM reaches).  GPU: the device active-set solve through the C ABI must reproduce
+the coefficients to 1e-10 relative AND report exactly the fixture's active set."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "corridor_exact.json")))["cases"]
+
+
+def _arrays(case):
+    wp = np.array(case["waypoints"])
+    half = np.array(case["half_width"])
+    return wp, wp - half, wp + half, np.array(case["times"]), np.array(case["bc"])
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_osqp_port_with_corridor_rows_converges_to_exact_minimiser(oracle, case):
+    r, M = case["r"], case["M"]
+    wp, lo, hi, T, bc = _arrays(case)
+    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=400000)
+    so = np.array([0, M], dtype=np.int32)
+    got, st, _ = oracle.osqp_solve_batch(r, so, wp[None], T[None], bc[None], settings=s, corr_lo=lo[None], corr_hi=hi[None])
+    assert st[0] == oracle.PORT_SOLVED
+    exp = np.array(case["coef"])
+    assert np.max(np.abs(got.reshape(3, -1) - exp)) <= 1e-6 * np.max(np.abs(exp))
+
+
+def test_fixture_active_sets_are_a_real_mix():
+    states = np.concatenate([np.ravel(c["active"]) for c in CASES])
+    assert (states == 0).sum() >= 8 and (states == -1).sum() >= 8 and (states == 1).sum() >= 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_device_corridor_solve_reproduces_exact_minimiser_and_active_set(gpu_ctx, case):
+    import torch
+    import uav_motion_planning_amd as U
+    r, M = case["r"], case["M"]
+    wp, lo, hi, T, bc = _arrays(case)
+    n = 3        # replicated: lanes of one wave on different trajectories
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(np.tile(x[None], (n,) + (1,) * x.ndim))).to(dev)
+    out = torch.zeros(n * 3 * 2 * r * M, dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    act = torch.zeros((n, 3, 2), dtype=torch.int64, device=dev)
+    gpu_ctx.solve_corridor_device(r, n, M, M, None, up(wp), up(T), up(bc), up(lo), up(hi), out, st, None, act, False)
+    gpu_ctx.synchronize()
+    assert bool((st == U.UAVQP_SOLVED).all())
+    got = out.cpu().numpy().reshape(n, 3, 2 * r * M)
+    exp = np.array(case["coef"])
+    assert np.max(np.abs(got - exp[None])) <= 1e-10 * np.max(np.abs(exp))
+    sets = act.cpu().numpy()
+    half = np.array(case["half_width"])
+    for ax in range(3):
+        pin, upper = int(sets[0, ax, 0]), int(sets[0, ax, 1])
+        for k in range(1, M):
+            s = case["active"][ax][k - 1]
+            if half[k, ax] == 0.0:
+                assert not (pin >> k) & 1        # lo == hi rows are permanent equalities, not part of the working set
+                continue
+            assert ((pin >> k) & 1) == (1 if s != 0 else 0), (ax, k)
+            if s != 0:
+                assert ((upper >> k) & 1) == (1 if s > 0 else 0), (ax, k)
+    assert np.array_equal(sets[1:], np.tile(sets[:1], (n - 1, 1, 1)))
