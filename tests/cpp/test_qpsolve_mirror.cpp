@@ -54,5 +54,29 @@ int main(int argc, char** argv) {
     worst = std::fmax(worst, std::fabs(opt.getPolyCoeff(0, 2)[i] + exp[i]));
   }
   std::printf("TrajOptimizer KAT max abs err %.3e\n", worst);
-  return worst < 1e-11 ? 0 : 8;
+  if (!(worst < 1e-11)) return 8;
+
+  // corridor extension through the same facade: degenerate boxes (lo = hi = waypoints) are the reference's
+  // equality rows again; boxes of +-0.25 around the interior waypoints must bind (x is a straight ramp whose
+  // minimum-jerk interpolant already passes through the waypoints with zero cost change possible only inside)
+  double lo[12], hi[12];
+  for (int i = 0; i < 12; ++i) { lo[i] = xyz[i]; hi[i] = xyz[i]; }
+  opt.setCorridor(lo, hi);
+  if (!opt.solve()) return 9;
+  double worst_c = 0;
+  for (int i = 0; i < 18; ++i) worst_c = std::fmax(worst_c, std::fabs(opt.getPolyCoeff(0, 0)[i] - exp[i]));
+  std::printf("TrajOptimizer degenerate corridor max abs err %.3e\n", worst_c);
+  if (!(worst_c < 1e-10)) return 10;
+  for (int i = 0; i < 12; ++i) { lo[i] = xyz[i] - 0.25; hi[i] = xyz[i] + 0.25; }
+  opt.setCorridor(lo, hi);
+  if (!opt.solve()) return 11;
+  // interior knot positions (c0 of segments 1 and 2, x axis) stay inside their boxes
+  for (int seg = 1; seg <= 2; ++seg) {
+    const double p = opt.getPolyCoeff(0, 0)[6 * seg];
+    if (p < xyz[3 * seg] - 0.25 - 1e-12 || p > xyz[3 * seg] + 0.25 + 1e-12) return 12;
+  }
+  opt.setCorridor(nullptr, nullptr);
+  if (!opt.solve()) return 13;
+  if (std::fabs(opt.getPolyCoeff(0, 0)[3] - exp[3]) > 1e-11) return 14;
+  return 0;
 }

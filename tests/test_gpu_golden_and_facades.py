@@ -73,6 +73,23 @@ def test_python_traj_optimizer_batch_facade(oracle):
     per = opt.getPolyCoeff(k)
     assert per.shape == (3, so[k + 1] - so[k], 8)
     assert np.array_equal(per.ravel(), got[24 * so[k]:24 * so[k + 1]])
+    # corridor extension through the facade: boxes from the config-3 generator; setCorridor(None, None) restores equalities
+    lo, hi = W.corridor_boxes(b, config_index=4)
+    opt.setCorridor(lo, hi)
+    assert opt.solve() is True and opt.iterations.max() >= 1
+    cor = opt.getPolyCoeff()
+    wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+    moved = 0
+    for t in range(40):
+        c = cor[24 * so[t]:24 * so[t + 1]].reshape(3, -1, 8)
+        for j in range(1, so[t + 1] - so[t]):
+            row = so[t] + t + j
+            assert np.all(c[:, j, 0] >= lo[row] - 1e-9) and np.all(c[:, j, 0] <= hi[row] + 1e-9)
+            moved += int(np.any(np.abs(c[:, j, 0] - wp[row]) > 1e-6))
+    assert moved > 20
+    opt.setCorridor(None, None)
+    assert opt.solve() is True
+    assert np.array_equal(opt.getPolyCoeff(), got)
 
 
 def test_cpp_facades_mirror_of_test_qpsolve():

@@ -33,6 +33,16 @@ class TrajOptimizer {
     void setTimeAllocation(const double* T) { T_.assign(T, T + (n_traj_ > 0 ? seg_offsets_[n_traj_] : 0)); }
     // bc: [n_traj][2][order-1][3] = [start|end][vel, acc(, jerk)][xyz]; default all zero.
     void setBoundary(const double* bc) { bc_.assign(bc, bc + static_cast<size_t>(n_traj_) * 2 * (order_ - 1) * 3); }
+    // Optional corridor (north-star extension): boxes lo <= p <= hi, [sum_b n_waypoints_b][3] like xyz, replace the
+    // interior-waypoint equalities; first/last rows of a trajectory are ignored.  nullptr restores the equalities.
+    void setCorridor(const double* lo, const double* hi) {
+        lo_.clear();
+        hi_.clear();
+        if (lo && hi) {
+            lo_.assign(lo, lo + wp_.size());
+            hi_.assign(hi, hi + wp_.size());
+        }
+    }
 
     bool solve() {
         if (n_traj_ <= 0 || T_.size() != static_cast<size_t>(seg_offsets_[n_traj_])) return false;
@@ -44,8 +54,11 @@ class TrajOptimizer {
         if (bc_.empty()) bc_.assign(static_cast<size_t>(n_traj_) * 2 * (order_ - 1) * 3, 0.0);
         coef_.assign(static_cast<size_t>(3) * 2 * order_ * seg_offsets_[n_traj_], 0.0);
         status_.assign(n_traj_, 0);
-        const int rc = uavqp_solve_batch_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(),
-                                              bc_.data(), coef_.data(), status_.data());
+        const int rc = lo_.empty()
+            ? uavqp_solve_batch_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(),
+                                     coef_.data(), status_.data())
+            : uavqp_solve_corridor_batch_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(),
+                                              lo_.data(), hi_.data(), coef_.data(), status_.data(), nullptr);
         if (rc != UAVQP_OK) {
             std::cout << "solver solve failed! (" << uavqp_last_error() << ")" << std::endl;
             return false;
@@ -66,7 +79,7 @@ class TrajOptimizer {
     int order_, device_, n_traj_ = 0;
     uavqp_ctx* ctx_ = nullptr;
     std::vector<int32_t> seg_offsets_, status_;
-    std::vector<double> wp_, T_, bc_, coef_;
+    std::vector<double> wp_, T_, bc_, coef_, lo_, hi_;
 };
 
 }  // namespace traj_optimization

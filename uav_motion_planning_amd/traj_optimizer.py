@@ -248,6 +248,8 @@ class TrajOptimizer:
     setWaypoints(xyz, wp_offsets)    xyz [sum(M_b+1)][3]; wp_offsets[n_traj+1] (or None + uniform count)
     setTimeAllocation(T)             T [sum M_b]
     setBoundary(bc)                  bc [n_traj][2][r-1][3]; default: all zero (test_minimum_jerk.cpp:59-63)
+    setCorridor(lo, hi)              optional boxes [sum(M_b+1)][3] replacing the interior-waypoint equalities
+                                     (north-star extension; None, None restores the reference's equality rows)
     solve() -> bool                  True iff every trajectory solved (statuses in .status)
     getPolyCoeff()                   flat float64 array, trajectory b at 3*2r*seg_offsets[b], [axis][seg][2r]
     """
@@ -258,8 +260,10 @@ class TrajOptimizer:
         self._device = device
         self._ctx = None
         self._wp = self._T = self._bc = self._so = None
+        self._lo = self._hi = None
         self._coef = np.zeros(0)
         self.status = np.zeros(0, dtype=np.int32)
+        self.iterations = np.zeros(0, dtype=np.int32)
 
     def setWaypoints(self, xyz, wp_offsets=None, n_waypoints=None):
         self._wp = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
@@ -278,16 +282,29 @@ class TrajOptimizer:
     def setBoundary(self, bc):
         self._bc = np.ascontiguousarray(bc, dtype=np.float64)
 
+    def setCorridor(self, lo, hi):
+        if lo is None or hi is None:
+            self._lo = self._hi = None
+            return
+        self._lo = np.ascontiguousarray(lo, dtype=np.float64).reshape(-1, 3)
+        self._hi = np.ascontiguousarray(hi, dtype=np.float64).reshape(-1, 3)
+
     def solve(self):
         if self._wp is None or self._T is None:
             return False
         n_traj = self._so.size - 1
         if self._T.size != int(self._so[-1]):
             return False
+        if self._lo is not None and (self._lo.shape != self._wp.shape or self._hi.shape != self._wp.shape):
+            return False
         bc = self._bc if self._bc is not None else np.zeros((n_traj, 2, self._r - 1, 3))
         if self._ctx is None:
             self._ctx = Context(self._device)  # raises UavqpError without libuavqp.so / without a GPU
-        self._coef, self.status = self._ctx.solve_batch_host(self._r, self._so, self._wp, self._T, bc)
+        if self._lo is not None:
+            self._coef, self.status, self.iterations = self._ctx.solve_corridor_batch_host(
+                self._r, self._so, self._wp, self._T, bc, self._lo, self._hi)
+        else:
+            self._coef, self.status = self._ctx.solve_batch_host(self._r, self._so, self._wp, self._T, bc)
         return bool(np.all(self.status == _lib.UAVQP_SOLVED))
 
     def getPolyCoeff(self, traj=None):
