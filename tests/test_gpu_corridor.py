@@ -231,3 +231,31 @@ def test_warm_started_corridor_solve(gpu_ctx, r, ragged):
     c2_cold, it2_cold = run(None, False, d_T2)
     assert np.max(np.abs(c2_warm - c2_cold)) <= 1e-9 * np.max(np.abs(c2_cold))
     assert it2_warm.mean() < 0.5 * it2_cold.mean()
+
+
+def test_mid_segment_samples_by_knot_insertion(gpu_ctx, oracle):
+    """adapters.refine_with_mid_knots + the ordinary corridor solve: positions at the inserted knots (the
+    mid-segment sample times of the original segments) stay inside chord +- h, the refined solve is KKT-optimal for
+    the refined problem, and a corridor that is wide at the mids reproduces nothing tighter than the plain corridor."""
+    from uav_motion_planning_amd import adapters as A
+    r, n, M, h_mid = 3, 24, 6, 0.15
+    b = W.uniform_batch(3, n, M, r, time_mode="distance")
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    ref = A.refine_with_mid_knots(b["seg_offsets"], b["waypoints"], b["times"], lo, hi, k_mid=2, mid_half_width=h_mid)
+    so2 = ref["seg_offsets"]
+    coef, st, it = gpu_ctx.solve_corridor_batch_host(r, so2, ref["waypoints"], ref["times"], b["bc"], ref["corr_lo"], ref["corr_hi"])
+    assert np.all(st == U.UAVQP_SOLVED)
+    M2 = 3 * M
+    c = coef.reshape(n, 3, M2, 2 * r)
+    knots = c[:, :, 1:, 0]                                            # positions at interior knots 1..M2-1: [n,3,M2-1]
+    lo2 = ref["corr_lo"].reshape(n, M2 + 1, 3)[:, 1:M2].transpose(0, 2, 1)
+    hi2 = ref["corr_hi"].reshape(n, M2 + 1, 3)[:, 1:M2].transpose(0, 2, 1)
+    assert np.all(knots >= lo2 - 1e-9) and np.all(knots <= hi2 + 1e-9)
+    tight = np.isclose(hi2 - lo2, 2 * h_mid)
+    assert (np.isclose(knots, lo2, atol=1e-9) | np.isclose(knots, hi2, atol=1e-9))[tight].sum() > 10   # mids really bind
+    for k in range(0, n, 5):
+        for ax in range(3):
+            prim, stat, comp = kkt_certificate(oracle, r, M2, ref["times"][k * M2:(k + 1) * M2], c[k, ax].ravel(),
+                                               ref["waypoints"].reshape(n, M2 + 1, 3)[k, :, ax], b["bc"][k, 0, :, ax], b["bc"][k, 1, :, ax],
+                                               lo2[k, ax], hi2[k, ax])
+            assert prim < 1e-9 and stat < 1e-7 and comp < 1e-6

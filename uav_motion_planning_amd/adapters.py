@@ -76,3 +76,47 @@ def unpack_like_traj_server(msg):
     n = msg["num_order"] + 1
     return [(msg["coef_x"][i * n:(i + 1) * n], msg["coef_y"][i * n:(i + 1) * n], msg["coef_z"][i * n:(i + 1) * n],
              msg["time"][i]) for i in range(msg["num_segment"])]
+
+
+def refine_with_mid_knots(seg_offsets, waypoints, times, corr_lo, corr_hi, k_mid, mid_half_width):
+    """Mid-segment corridor samples by knot insertion (SURVEY.md section 8-a': "or K samples per segment").
+
+    The device corridor solve bounds positions at KNOTS.  To bound the path inside a segment as well, every segment is
+    split into k_mid + 1 equal-duration pieces; each inserted knot gets the box  chord point +- mid_half_width  (scalar
+    or [n_segments] array), the original knots keep their boxes.  The refined problem is then an ordinary corridor batch
+    (k_mid + 1 times the segments).  Note the semantics: the inserted knots are real spline knots (continuity up to
+    derivative r-1 there), so the minimiser is taken over a larger spline space than a reference-formulation QP with
+    extra inequality rows at those times -- its cost is lower or equal, the position bounds are identical.
+    Returns dict(seg_offsets, waypoints, times, corr_lo, corr_hi, parent_segment) with parent_segment[new] = old."""
+    so = np.asarray(seg_offsets, dtype=np.int64)
+    wp = np.asarray(waypoints, dtype=np.float64).reshape(-1, 3)
+    T = np.asarray(times, dtype=np.float64).reshape(-1)
+    lo = np.asarray(corr_lo, dtype=np.float64).reshape(-1, 3)
+    hi = np.asarray(corr_hi, dtype=np.float64).reshape(-1, 3)
+    n = so.size - 1
+    k_mid = int(k_mid)
+    if k_mid < 0:
+        raise ValueError("k_mid must be >= 0")
+    hw = np.broadcast_to(np.asarray(mid_half_width, dtype=np.float64), (int(so[-1]),))
+    f = k_mid + 1
+    new_so = so * f
+    n_rows = int(new_so[-1]) + n
+    o_wp, o_lo, o_hi = np.zeros((n_rows, 3)), np.zeros((n_rows, 3)), np.zeros((n_rows, 3))
+    o_T = np.repeat(T / f, f)
+    parent = np.repeat(np.arange(int(so[-1])), f)
+    frac = (np.arange(1, f) / f)[:, None]
+    for b in range(n):
+        s0, M = int(so[b]), int(so[b + 1] - so[b])
+        r_old, r_new = s0 + b, int(new_so[b]) + b
+        for i in range(M):
+            a, c = wp[r_old + i], wp[r_old + i + 1]
+            base = r_new + i * f
+            o_wp[base], o_lo[base], o_hi[base] = a, lo[r_old + i], hi[r_old + i]
+            if k_mid:
+                mid = a + frac * (c - a)
+                o_wp[base + 1:base + f] = mid
+                o_lo[base + 1:base + f] = mid - hw[s0 + i]
+                o_hi[base + 1:base + f] = mid + hw[s0 + i]
+        o_wp[r_new + M * f], o_lo[r_new + M * f], o_hi[r_new + M * f] = wp[r_old + M], lo[r_old + M], hi[r_old + M]
+    return dict(seg_offsets=new_so.astype(np.int32), waypoints=o_wp, times=o_T, corr_lo=o_lo, corr_hi=o_hi,
+                parent_segment=parent)
