@@ -113,3 +113,23 @@ def test_refine_with_mid_knots_layout():
             assert np.all(ref["parent_segment"][(int(so[k]) + i) * 3:(int(so[k]) + i) * 3 + 3] == int(so[k]) + i)
     same = A.refine_with_mid_knots(so, b["waypoints"], b["times"], lo, hi, k_mid=0, mid_half_width=0.1)
     assert np.array_equal(same["waypoints"], wp) and np.array_equal(same["times"], b["times"])
+
+
+def test_downsample_dense_astar_path():
+    from uav_motion_planning_amd import adapters as A
+    res = 0.1
+    leg1 = np.stack([np.arange(0, 3.0 + 1e-9, res), np.zeros(31), np.ones(31)], axis=1)            # 3 m along x
+    leg2 = np.stack([np.full(20, 3.0), np.arange(res, 2.0 + 1e-9, res), np.ones(20)], axis=1)      # 2 m along y
+    leg3 = np.stack([3.0 + np.arange(res, 1.0 + 1e-9, res)] * 2 + [np.ones(10)], axis=1)
+    leg3[:, 1] += 2.0 - 3.0                                                                         # diagonal from (3,2)
+    dense = np.concatenate([leg1, leg2, leg3])
+    out = A.downsample_dense_path(dense, max_spacing=2.0)
+    assert np.array_equal(out[0], dense[0]) and np.array_equal(out[-1], dense[-1])
+    for corner in ([3.0, 0.0, 1.0], [3.0, 2.0, 1.0]):
+        assert np.any(np.all(np.isclose(out, corner), axis=1))
+    assert np.max(np.linalg.norm(np.diff(out, axis=0), axis=1)) <= 2.0 + 1e-9
+    assert 4 <= out.shape[0] <= 7
+    assert A.downsample_dense_path(dense, max_spacing=2.0, max_segments=2).shape[0] == 3
+    assert A.downsample_dense_path(dense[:2]).shape[0] == 2 and A.downsample_dense_path(dense[:1]).shape[0] == 1
+    flat = A.flatten_paths([out, A.downsample_dense_path(dense[:15])])
+    assert flat["seg_offsets"][-1] == out.shape[0] - 1 + 1

@@ -6,6 +6,8 @@ N2  front-end -> optimiser:  flatten the waypoint lists the reference's searcher
     kino_astar.cpp:473-490,107,124,236) into the C ABI's CSR layout, including the reference's empty-path
     edge case (RRT* leaves optimal_path_ empty when the first feasible path is never improved,
     rrt_star.cpp:348-367 vs :386-394 -- SURVEY H8): such paths are dropped and reported, not solved.
+    downsample_dense_path thins A*'s one-point-per-cell output (a_star.cpp:179-189) to corners + bounded spacing;
+    refine_with_mid_knots adds mid-segment corridor samples by knot insertion (SURVEY 8-a').
 N3  optimiser -> executor:   quadrotor_msgs/PolynomialTrajectory fields
     (src/simulator/utils/quadrotor_msgs/msg/PolynomialTrajectory.msg:1-28) exactly as poly_traj_server's
     trajCallback unpacks them (traj_server/src/poly_traj_server.cpp:57-81):
@@ -120,3 +122,35 @@ def refine_with_mid_knots(seg_offsets, waypoints, times, corr_lo, corr_hi, k_mid
         o_wp[r_new + M * f], o_lo[r_new + M * f], o_hi[r_new + M * f] = wp[r_old + M], lo[r_old + M], hi[r_old + M]
     return dict(seg_offsets=new_so.astype(np.int32), waypoints=o_wp, times=o_T, corr_lo=o_lo, corr_hi=o_hi,
                 parent_segment=parent)
+
+
+def downsample_dense_path(path, max_spacing=2.0, max_segments=None, collinear_tol=1e-9):
+    """A* returns every grid cell of the path (Astar::retrievePath, path_searching/src/a_star.cpp:179-189: one point
+    per `resolution_` step); a polynomial segment per cell is neither needed nor well conditioned.  Keeps the end
+    points and the corners (where the step direction changes), then adds points on straight runs so that no segment
+    is longer than max_spacing (cf. RRT* step_length 1.5 m, test_minimum_jerk.launch:45), and finally thins uniformly
+    to at most max_segments segments.  Returns the kept points [m, 3] (m >= 2 for an input of >= 2 points)."""
+    p = np.asarray(path, dtype=np.float64).reshape(-1, 3)
+    if p.shape[0] <= 2:
+        return p.copy()
+    d = np.diff(p, axis=0)
+    nrm = np.linalg.norm(d, axis=1, keepdims=True)
+    u = d / np.where(nrm > 0, nrm, 1.0)
+    corner = np.linalg.norm(u[1:] - u[:-1], axis=1) > collinear_tol          # direction change at interior point i+1
+    keep = [0] + [i + 1 for i in np.nonzero(corner)[0]] + [p.shape[0] - 1]
+    out = [keep[0]]
+    arc = np.concatenate([[0.0], np.cumsum(nrm[:, 0])])
+    for a, b in zip(keep[:-1], keep[1:]):
+        length = arc[b] - arc[a]
+        n_piece = max(1, int(np.ceil(length / max_spacing - 1e-12)))
+        for j in range(1, n_piece):                                          # dense-path points closest to the equal split
+            target = arc[a] + length * j / n_piece
+            idx = a + int(np.argmin(np.abs(arc[a:b + 1] - target)))
+            if idx > out[-1]:
+                out.append(idx)
+        if b > out[-1]:
+            out.append(b)
+    if max_segments is not None and len(out) - 1 > max_segments:
+        sel = np.unique(np.round(np.linspace(0, len(out) - 1, max_segments + 1)).astype(int))
+        out = [out[i] for i in sel]
+    return p[out].copy()
