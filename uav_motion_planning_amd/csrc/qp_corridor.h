@@ -79,12 +79,11 @@ struct SegRow0 {
     double e11[R], e01r[R], e01c[R];
 };
 
-template <int R>
+template <int R, int LDS_KNOTS>
 __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(CorridorArgs a) {
     constexpr int ND = R - 1, NC = 2 * R;
-    // prefetch distance in knots: 2 for r = 4 (one wave per SIMD, nothing else hides a round trip; config 5 corridor
-    // solve 2.90 -> 2.76 ms), 1 for r = 3 (two waves per SIMD; the second buffer only costs registers there)
-    constexpr bool PF2 = (R == 4);
+    // Prefetch distance is ONE knot.  Two was measured and is worse: the second record buffer pushes the r = 4 kernel
+    // (256 VGPRs + AGPR spills already) over the edge -- config 5's corridor solve 2.83 ms at distance 1, 3.4 ms at 2.
     // sweep state per interior knot: LDL' factors of S_k (strict lower triangle + inverse pivots), x_k (first h_k,
     // overwritten by the solution in the backward sweep) and the current position iterate z_k.  E_k = S_k^-1 M_k is
     // NOT stored: it is re-derived from the factors where needed (the kernel is bound by this HBM traffic).
@@ -96,7 +95,21 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
     // page, not F pages a batch-stride apart: the sweeps are latency-bound, TLB and DRAM-row locality matter)
     const int kmax = (a.uniform > 0 ? a.uniform : a.max_segments) - 1;
     double* __restrict__ ws = a.ws + (size_t)(slot >> 6) * (size_t)(kmax > 1 ? kmax : 1) * F * 64 + (slot & 63);
-    auto W = [&](int k, int f) -> double& { return ws[((size_t)(k - 1) * F + f) * 64]; };  // interior knot k = 1..M-1
+    // The records of the last NT interior knots of a UNIFORM batch live in LDS instead (the forward sweep writes them
+    // last, the backward sweep reads them first): NT of M-1 knots less HBM traffic for the bandwidth-bound large batch
+    // (config 3: 4 of 15).  Ragged batches keep everything in HBM (NT = 0 instantiation): lanes of one wave would diverge on the test, and
+    // the tests alone cost the latency-bound ragged case 30 % (config 5: 2.76 -> 3.61 ms when they were left in).
+    constexpr int NT = LDS_KNOTS;
+    __shared__ double s_rec[NT > 0 ? NT * F * 64 : 1];
+    // knots k >= lds_from are in LDS; the ragged instantiation (NT = 0) compiles every test below away
+    const int lds_from = NT > 0 ? a.uniform - NT : 0;
+    const int lane = threadIdx.x & 63;
+    auto G = [&](int k, int f) -> double& { return ws[((size_t)(k - 1) * F + f) * 64]; };        // interior knot k = 1..M-1
+    auto S = [&](int k, int f) -> double& { return s_rec[((k - lds_from) * F + f) * 64 + lane]; };
+    auto ld_xz = [&](int k, double& x0, double& z) {
+        if (NT > 0 && k >= lds_from) { x0 = S(k, F_X); z = S(k, F_Z); } else { x0 = G(k, F_X); z = G(k, F_Z); }
+    };
+    auto st_z = [&](int k, double z) { if (NT > 0 && k >= lds_from) S(k, F_Z) = z; else G(k, F_Z) = z; };
 
     const long long total = (long long)a.n_traj * 3;
     for (long long g = slot; g < total; g += n_slots) {
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                 pin |= 1ull << k;
                 if (up) upper |= 1ull << k;
             }
-            W(k, F_Z) = z;
+            st_z(k, z);
         }
         pin |= eqmask;
 
@@ -189,28 +202,21 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                 double hprev[R];
                 // raw fields of knot k+1 (old x[0], old z, bounds) are in flight while knot k is eliminated
                 double zp_ = 0.0, zc, zn = 0.0;
-                double nx0 = 0.0, nz = 0.0, nl = 0.0, nh = 0.0, Tn;      // knot k+1
-                double mx0 = 0.0, mz = 0.0, ml = 0.0, mh = 0.0, Tm = 1.0;  // knot k+2
-                zc = znew(1, W(1, F_X), W(1, F_Z), lo[3], hi[3]);
-                if (M > 2) { nx0 = W(2, F_X); nz = W(2, F_Z); nl = lo[6]; nh = hi[6]; }
-                Tn = T[1];
-                if constexpr (PF2) {
-                    if (M > 3) { mx0 = W(3, F_X); mz = W(3, F_Z); ml = lo[9]; mh = hi[9]; }
-                    if (M > 2) Tm = T[2];
+                double nx0 = 0.0, nz = 0.0, nl = 0.0, nh = 0.0, Tn;  // knot k+1
+                {
+                    double fx, fz;
+                    ld_xz(1, fx, fz);
+                    zc = znew(1, fx, fz, lo[3], hi[3]);
                 }
+                if (M > 2) { ld_xz(2, nx0, nz); nl = lo[6]; nh = hi[6]; }
+                Tn = T[1];
                 for (int k = 1; k < M; ++k) {
                     FullBlocks<R> sb;
                     sb.build(Tn);
                     if (k + 1 < M) zn = znew(k + 1, nx0, nz, nl, nh);
-                    if constexpr (PF2) {
-                        nx0 = mx0; nz = mz; nl = ml; nh = mh; Tn = Tm;
-                        if (k + 3 < M) { mx0 = W(k + 3, F_X); mz = W(k + 3, F_Z); ml = lo[3 * (k + 3)]; mh = hi[3 * (k + 3)]; }
-                        if (k + 2 < M) Tm = T[k + 2];
-                    } else {
-                        if (k + 2 < M) { nx0 = W(k + 2, F_X); nz = W(k + 2, F_Z); nl = lo[3 * (k + 2)]; nh = hi[3 * (k + 2)]; }
-                        if (k + 1 < M) Tn = T[k + 1];
-                    }
-                    W(k, F_Z) = zc;
+                    if (k + 2 < M) { ld_xz(k + 2, nx0, nz); nl = lo[3 * (k + 2)]; nh = hi[3 * (k + 2)]; }
+                    if (k + 1 < M) Tn = T[k + 1];
+                    st_z(k, zc);
                     const bool pk = (pin >> k) & 1ull;
                     const bool pprev = (k > 1) && ((pin >> (k - 1)) & 1ull);
                     const bool pnext = (k < M - 1) && ((pin >> (k + 1)) & 1ull);
@@ -277,19 +283,22 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                     SmallLDL<R> ldl;
                     ldl.factor(D);
                     ldl.solve(rhs);
-                    {
+                    auto put = [&](auto&& at) {   // factors + h of knot k, straight from the registers they were computed in
                         int f = 0;
 #pragma unroll
                         for (int i = 1; i < R; ++i)
 #pragma unroll
-                            for (int c = 0; c < i; ++c) W(k, F_L + (f++)) = ldl.l[i][c];
-                    }
+                            for (int c = 0; c < i; ++c) at(F_L + (f++)) = ldl.l[i][c];
 #pragma unroll
-                    for (int i = 0; i < R; ++i) {
-                        W(k, F_DI + i) = ldl.dinv[i];
-                        hprev[i] = rhs[i];
-                        W(k, F_X + i) = rhs[i];
-                    }
+                        for (int i = 0; i < R; ++i) {
+                            at(F_DI + i) = ldl.dinv[i];
+                            at(F_X + i) = rhs[i];
+                        }
+                    };
+                    if (NT > 0 && k >= lds_from) put([&](int q) -> double& { return S(k, q); });
+                    else put([&](int q) -> double& { return G(k, q); });
+#pragma unroll
+                    for (int i = 0; i < R; ++i) hprev[i] = rhs[i];
                     lprev = ldl;
                     sa = sb;
                     zp_ = zc;
@@ -306,20 +315,13 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
             int block = -1, rel = -1;
             bool block_upper = false;
             {
-                double xn[R], nx[F], nl, nh, Tn;            // record of the knot processed next
-                double mx[F], ml = 0.0, mh = 0.0, Tm = 1.0;  // ... and of the one after it
+                double xn[R], nx[F], nl, nh, Tn;  // record of the knot processed next
                 double lamA = 0.0, magA = 0.0;  // part of knot (k+1)'s multiplier known before x_k is
 #pragma unroll
-                for (int f = 0; f < F; ++f) nx[f] = W(M - 1, f);
+                for (int f = 0; f < F; ++f) nx[f] = (NT > 0 && M - 1 >= lds_from) ? S(M - 1, f) : G(M - 1, f);
                 nl = lo[3 * (M - 1)];
                 nh = hi[3 * (M - 1)];
                 Tn = T[M - 1];
-                if constexpr (PF2) {
-#pragma unroll
-                    for (int f = 0; f < F; ++f) mx[f] = M > 2 ? W(M - 2, f) : 0.0;
-                    if (M > 2) { ml = lo[3 * (M - 2)]; mh = hi[3 * (M - 2)]; }
-                    Tm = T[M - 2];
-                }
 #pragma unroll
                 for (int i = 0; i < R; ++i) xn[i] = xM[i];
                 for (int k = M - 1; k >= 0; --k) {
@@ -346,28 +348,18 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                         lk = nl;
                         hk = nh;
                         zk = cur[F_Z];
-                        if constexpr (PF2) {
+                        if (k >= 2) {
+                            if (NT > 0 && k - 1 >= lds_from) {
 #pragma unroll
-                            for (int f = 0; f < F; ++f) nx[f] = mx[f];
-                            nl = ml;
-                            nh = mh;
-                            Tn = Tm;
-                            if (k >= 3) {
+                                for (int f = 0; f < F; ++f) nx[f] = S(k - 1, f);
+                            } else {
 #pragma unroll
-                                for (int f = 0; f < F; ++f) mx[f] = W(k - 2, f);
-                                ml = lo[3 * (k - 2)];
-                                mh = hi[3 * (k - 2)];
+                                for (int f = 0; f < F; ++f) nx[f] = G(k - 1, f);
                             }
-                            if (k >= 2) Tm = T[k - 2];
-                        } else {
-                            if (k >= 2) {
-#pragma unroll
-                                for (int f = 0; f < F; ++f) nx[f] = W(k - 1, f);
-                                nl = lo[3 * (k - 1)];
-                                nh = hi[3 * (k - 1)];
-                            }
-                            Tn = T[k - 1];
+                            nl = lo[3 * (k - 1)];
+                            nh = hi[3 * (k - 1)];
                         }
+                        Tn = T[k - 1];
 #pragma unroll
                         for (int i = 0; i < R; ++i) x[i] = cur[F_X + i];
                         if (k < M - 1) {
@@ -397,8 +389,13 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                             ldl.solve(t);
 #pragma unroll
                             for (int i = 0; i < R; ++i) x[i] -= t[i];
+                            if (NT > 0 && k >= lds_from) {
 #pragma unroll
-                            for (int i = 0; i < R; ++i) W(k, F_X + i) = x[i];
+                                for (int i = 0; i < R; ++i) S(k, F_X + i) = x[i];
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < R; ++i) G(k, F_X + i) = x[i];
+                            }
                         }
                     } else {
 #pragma unroll
@@ -512,8 +509,8 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
         double nxs[R + 1], Tn = T[M - 1];
         if (M >= 2) {
 #pragma unroll
-            for (int i = 0; i < R; ++i) nxs[i] = W(M - 1, F_X + i);
-            nxs[R] = W(M - 1, F_Z);
+            for (int i = 0; i < R; ++i) nxs[i] = (NT > 0 && M - 1 >= lds_from) ? S(M - 1, F_X + i) : G(M - 1, F_X + i);
+            nxs[R] = (NT > 0 && M - 1 >= lds_from) ? S(M - 1, F_Z) : G(M - 1, F_Z);
         }
         for (int k = M - 1; k >= 0; --k) {
             double xs[R];
@@ -526,9 +523,15 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
                 for (int i = 0; i < R; ++i) xs[i] = nxs[i];
                 if (!final_pass && ((pin >> k) & 1ull)) xs[0] = nxs[R];  // pinned positions: exact bound value
                 if (k >= 2) {
+                    if (NT > 0 && k - 1 >= lds_from) {
 #pragma unroll
-                    for (int i = 0; i < R; ++i) nxs[i] = W(k - 1, F_X + i);
-                    nxs[R] = W(k - 1, F_Z);
+                        for (int i = 0; i < R; ++i) nxs[i] = S(k - 1, F_X + i);
+                        nxs[R] = S(k - 1, F_Z);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < R; ++i) nxs[i] = G(k - 1, F_X + i);
+                        nxs[R] = G(k - 1, F_Z);
+                    }
                 }
                 Tn = T[k - 1];
             }

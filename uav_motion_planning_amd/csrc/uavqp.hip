@@ -1003,10 +1003,18 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     a.ws = ctx->ws;
     hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
     if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
-    if (r == 3)
-        hipLaunchKernelGGL(uavqp::solve_corridor_kernel<3>, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(uavqp::solve_corridor_kernel<4>, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+    // uniform batches keep the sweep state of their last 4 (r = 3) / 5 (r = 4) knots in LDS; ragged ones all in HBM
+    if (r == 3) {
+        if (uniform_segments > 0)
+            hipLaunchKernelGGL((uavqp::solve_corridor_kernel<3, 4>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((uavqp::solve_corridor_kernel<3, 0>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+    } else {
+        if (uniform_segments > 0)
+            hipLaunchKernelGGL((uavqp::solve_corridor_kernel<4, 5>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((uavqp::solve_corridor_kernel<4, 0>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+    }
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }
