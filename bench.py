@@ -197,8 +197,9 @@ def main():
         step(i)
     for k in range(S):
         ev1[k].record(streams[k])
-    fence()
-    dt = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0   # this rank's K steps, complete on the device; MAX over ranks below
+    fence()                         # closing barrier + synchronize (its own cost is not part of the K steps)
     # average time one launch occupies its stream (kernel + boundary), from the events of the timed region
     region_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) / max(1, len(range(k, args.steps, S))) for k in range(S)]))
     if use_dist:
