@@ -69,7 +69,9 @@ const char* uavqp_version(void);
 const char* uavqp_last_error(void);
 
 /* Replaces construction of traj_optimization::MinimumControl + OsqpEigen::Solver
- * (minimum_control.h:14,44).  One ctx per host thread / device; owns a HIP stream and workspaces. */
+ * (minimum_control.h:14,44).  One ctx per host thread / device; owns a HIP stream and workspaces.  The owned stream is
+ * a blocking stream, i.e. ordered with the legacy default (NULL) stream: buffers filled or read there need no extra
+ * synchronisation.  A stream passed through uavqp_set_stream is used as it is. */
 int uavqp_create(uavqp_ctx** out_ctx, int device);
 int uavqp_destroy(uavqp_ctx* ctx);
 

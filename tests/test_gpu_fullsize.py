@@ -167,3 +167,46 @@ def test_long_trajectories_generic_path(gpu_ctx, oracle):
         ref, _ = oracle.solve_exact_batch(3, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
         assert np.all(st == U.UAVQP_SOLVED)
         assert np.max(np.abs(got - ref)) < 1e-8 * np.max(np.abs(ref))
+
+
+def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx, monkeypatch):
+    """Large ragged batches are dealt to the lanes in windows of 1024 trajectories by descending segment count
+    (solve_generic_kernel<R, LSORT>).  Which lane solves a trajectory must not change a single bit: compare with the
+    plain lane order (UAVQP_NO_LSORT=1) on a batch that needs two grid rounds, is not a multiple of the window, and
+    contains single-segment and over-long (flagged invalid) trajectories."""
+    import torch
+    r, n = 4, 140001
+    rng = np.random.default_rng(44)
+    Ms = rng.integers(1, 27, size=n)                       # max_segments = 24 below: 25 and 26 are invalid input
+    so = np.zeros(n + 1, dtype=np.int32)
+    so[1:] = np.cumsum(Ms)
+    tot = int(so[-1])
+    wp = np.cumsum(rng.uniform(-1.0, 1.0, size=(tot + n, 3)), axis=0)
+    T = rng.uniform(0.4, 2.0, size=tot)
+    bc = rng.uniform(-1.0, 1.0, size=(n, 2, r - 1, 3))
+    dev = torch.device("cuda", 0)
+    d_so, d_wp, d_T, d_bc = (torch.from_numpy(x).to(dev) for x in (so, wp, T, bc))
+
+    def run():
+        out = torch.full((tot * 24,), np.nan, dtype=torch.float64, device=dev)
+        st = torch.zeros(n, dtype=torch.int32, device=dev)
+        gpu_ctx.solve_batch_device(r, n, 0, 24, d_so, d_wp, d_T, d_bc, out, st)
+        gpu_ctx.synchronize()
+        return out.cpu().numpy(), st.cpu().numpy()
+
+    monkeypatch.delenv("UAVQP_NO_LSORT", raising=False)
+    c_deal, st_deal = run()
+    monkeypatch.setenv("UAVQP_NO_LSORT", "1")
+    c_plain, st_plain = run()
+    assert np.array_equal(st_deal, st_plain)
+    assert np.array_equal(st_deal == U.UAVQP_SOLVED, Ms <= 24)
+    assert np.all(st_deal[Ms > 24] == U.UAVQP_INVALID_INPUT)
+    valid = np.repeat(Ms <= 24, Ms * 24)
+    assert np.array_equal(c_deal[valid], c_plain[valid])
+    assert np.all(np.isfinite(c_deal[valid])) and np.all(np.isnan(c_deal[~valid]))   # invalid ones are left untouched
+    # spot check: waypoint interpolation of a few trajectories from both ends of the batch
+    for k in (0, 1, n // 2, n - 2, n - 1):
+        if Ms[k] > 24:
+            continue
+        c = c_deal[24 * so[k]:24 * so[k + 1]].reshape(3, Ms[k], 8)
+        assert np.allclose(c[:, :, 0].T, wp[so[k] + k:so[k + 1] + k], rtol=0, atol=1e-9 * max(1.0, np.abs(wp).max()))

@@ -39,15 +39,77 @@ struct BatchArgs {
 // lane-interleaved HBM workspace  ws[((k-1)*F + f) * n_slots + slot]  (coalesced across the wave),
 // the backward sweep re-reads them and emits segment coefficients as it goes.
 // ---------------------------------------------------------------------------------------------------
-template <int R>
+// LSORT (ragged batches): every group of 16 consecutive single-wave workgroups shares a window of 1024 consecutive
+// trajectories and deals them out by descending segment count -- workgroup q of the group takes ranks [64 q, 64 q + 64) --
+// so that the lanes of one wave run sweeps of nearly equal length while the window stays contiguous in memory (a GLOBAL
+// sort by M was measured at 157 -> 244 us on config 4: it destroys the locality the strided per-lane accesses live on).
+// Each workgroup runs the same counting sort of the window's 1024 counts in LDS (one wave: 16 keys per lane, 256 bins)
+// and keeps its own 64 entries; the order inside a bin is whatever the LDS atomics give -- it only decides WHICH lane
+// solves a trajectory, never the result.
+template <int R, bool LSORT>
 __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
     constexpr int ND = R - 1, NC = 2 * R, F = ND * ND + 3 * ND;
+    constexpr int WIN = 1024, GRP = WIN / 64;
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_slots = gridDim.x * blockDim.x;
+    const int n_slots = gridDim.x * blockDim.x;  // LSORT: the host rounds the grid to a multiple of GRP
     double* __restrict__ ws = a.ws + slot;
     const size_t wstride = (size_t)n_slots;
+    __shared__ int s_cnt[LSORT ? 256 : 1];   // per bin: count, then running fill position
+    __shared__ int s_mine[LSORT ? 64 : 1];
 
-    for (int b = slot; b < a.n_traj; b += n_slots) {
+    const int n_round = (a.n_traj + n_slots - 1) / n_slots;
+    for (int round = 0; round < n_round; ++round) {
+        int b = round * n_slots + slot;
+        if constexpr (LSORT) {
+            const int lane = threadIdx.x;
+            const int q = blockIdx.x % GRP;
+            const int base = round * n_slots + (blockIdx.x - q) * 64;  // first trajectory of the group's window
+            int key[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+                const int t = base + j * 64 + lane;
+                int Mt = -1;
+                if (t < a.n_traj) {
+                    Mt = a.seg_offsets[t + 1] - a.seg_offsets[t];
+                    Mt = Mt < 0 ? 0 : (Mt > 255 ? 255 : Mt);
+                }
+                key[j] = Mt;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_cnt[4 * lane + j] = 0;
+            s_mine[lane] = -1;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < GRP; ++j)
+                if (key[j] >= 0) atomicAdd(&s_cnt[255 - key[j]], 1);  // bin 0 = longest
+            __syncthreads();
+            // exclusive prefix over the 256 bins: 4 bins per lane + a wave scan
+            int c[4], tot = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[j] = s_cnt[4 * lane + j]; tot += c[j]; }
+            int incl = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            int run = incl - tot;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s_cnt[4 * lane + j] = run; run += c[j]; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < GRP; ++j)
+                if (key[j] >= 0) {
+                    const int pos = atomicAdd(&s_cnt[255 - key[j]], 1);
+                    if ((pos >> 6) == q) s_mine[pos & 63] = j * 64 + lane;
+                }
+            __syncthreads();
+            const int mine = s_mine[lane];
+            __syncthreads();  // before the next round clears s_mine
+            b = mine >= 0 ? base + mine : a.n_traj;
+        }
+        if (b >= a.n_traj) continue;
         int s0, M;
         if (a.uniform > 0) {
             M = a.uniform;
@@ -674,7 +736,10 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
-    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    // A BLOCKING stream: ordered with the legacy default (NULL) stream, which is where a caller that never thinks about
+    // streams (and PyTorch by default) fills and reads the buffers it hands over.  Callers that want overlap pass their
+    // own stream through uavqp_set_stream.
+    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamDefault);
     if (e != hipSuccess) {
         g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         delete ctx;
@@ -805,19 +870,26 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
             return UAVQP_ERR_INVALID_ARG;
         }
     }
+    // ragged batches of some size: 256-thread workgroups that deal their chunk to the lanes by segment count
+    // ragged batches of some size: groups of 16 workgroups deal a 1024-trajectory window to their lanes by segment count
+    const bool lsort = uniform_segments == 0 && n_traj >= 2048 && !std::getenv("UAVQP_NO_LSORT");
     const int block = 64;
     int grid = (n_traj + block - 1) / block;
     const int max_grid = ctx->num_cus * 8;
     if (grid > max_grid) grid = max_grid;
+    if (lsort) grid = (grid + 15) / 16 * 16;
     const int F = (r - 1) * (r - 1) + 3 * (r - 1);
     const size_t ws_bytes = sizeof(double) * (size_t)(Mmax > 1 ? Mmax - 1 : 1) * F * (size_t)grid * block;
     int rc = ensure_ws(ctx, ws_bytes);
     if (rc != UAVQP_OK) return rc;
     a.ws = ctx->ws;
-    if (r == 3)
-        hipLaunchKernelGGL(uavqp::solve_generic_kernel<3>, dim3(grid), dim3(block), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(uavqp::solve_generic_kernel<4>, dim3(grid), dim3(block), 0, ctx->stream, a);
+    if (r == 3) {
+        if (lsort) hipLaunchKernelGGL((uavqp::solve_generic_kernel<3, true>), dim3(grid), dim3(block), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((uavqp::solve_generic_kernel<3, false>), dim3(grid), dim3(block), 0, ctx->stream, a);
+    } else {
+        if (lsort) hipLaunchKernelGGL((uavqp::solve_generic_kernel<4, true>), dim3(grid), dim3(block), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((uavqp::solve_generic_kernel<4, false>), dim3(grid), dim3(block), 0, ctx->stream, a);
+    }
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }
