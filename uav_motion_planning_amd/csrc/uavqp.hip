@@ -34,42 +34,58 @@ struct BatchArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// Generic kernel: one lane per trajectory, any segment count (ragged batches), r = 3 or 4.
+// Generic kernel: any segment count (ragged batches), r = 3 or 4.
 // Forward block elimination keeps E_k = S_k^-1 A01(k) and h_k = S_k^-1 z_k per interior knot in a
 // lane-interleaved HBM workspace  ws[((k-1)*F + f) * n_slots + slot]  (coalesced across the wave),
 // the backward sweep re-reads them and emits segment coefficients as it goes.
+//
+// NAX = 3: one lane per trajectory carries all three axes (the factorisation is shared).
+// NAX = 1: one lane per (trajectory, axis), 21 trajectories per wave: the 3 lanes of a trajectory repeat the (cheap)
+//          matrix elimination, each carries one right-hand side and emits one axis.  Three times the waves and a
+//          third of the per-lane state -- for batches that do not fill the machine with one lane per trajectory.
+//          E_k is stored once per trajectory (by the x lane, in its own slot) and read by all three lanes from that
+//          slot: same wave, program order, so the hand-off needs no fence.
 // ---------------------------------------------------------------------------------------------------
-// LSORT (ragged batches): every group of 16 consecutive single-wave workgroups shares a window of 1024 consecutive
-// trajectories and deals them out by descending segment count -- workgroup q of the group takes ranks [64 q, 64 q + 64) --
-// so that the lanes of one wave run sweeps of nearly equal length while the window stays contiguous in memory (a GLOBAL
-// sort by M was measured at 157 -> 244 us on config 4: it destroys the locality the strided per-lane accesses live on).
-// Each workgroup runs the same counting sort of the window's 1024 counts in LDS (one wave: 16 keys per lane, 256 bins)
-// and keeps its own 64 entries; the order inside a bin is whatever the LDS atomics give -- it only decides WHICH lane
-// solves a trajectory, never the result.
-template <int R, bool LSORT>
+// LSORT (ragged batches): every group of 16 consecutive single-wave workgroups shares a window of 16 x IPW consecutive
+// trajectories (IPW = trajectories per wave: 64 or 21) and deals them out by descending segment count -- workgroup q of
+// the group takes ranks [IPW q, IPW (q + 1)) -- so that the lanes of one wave run sweeps of nearly equal length while
+// the window stays contiguous in memory (a GLOBAL sort by M was measured at 157 -> 244 us on config 4: it destroys the
+// locality the strided per-lane accesses live on).  Each workgroup runs the same counting sort of the window's counts
+// in LDS (one wave, 256 bins) and keeps its own IPW entries; the order inside a bin is whatever the LDS atomics give --
+// it only decides WHICH lane solves a trajectory, never the result.
+template <int R, bool LSORT, int NAX>
 __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
-    constexpr int ND = R - 1, NC = 2 * R, F = ND * ND + 3 * ND;
-    constexpr int WIN = 1024, GRP = WIN / 64;
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_slots = gridDim.x * blockDim.x;  // LSORT: the host rounds the grid to a multiple of GRP
+    constexpr int ND = R - 1, NC = 2 * R, F = ND * ND + NAX * ND;
+    constexpr int LPI = 3 / NAX;              // lanes per trajectory
+    constexpr int IPW = 64 / LPI;             // trajectories per wave (64 or 21)
+    constexpr int GRP = 16, WIN = GRP * IPW;  // LSORT window
+    constexpr int KPL = (WIN + 63) / 64;      // keys per lane
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;
+    const int n_slots = gridDim.x * 64;  // LSORT: the host rounds the grid to a multiple of GRP
+    const int ax0 = NAX == 1 ? lane % 3 : 0;
+    const int item = lane / LPI;
+    const bool lane_used = item < IPW;   // NAX = 1: lane 63 idles
     double* __restrict__ ws = a.ws + slot;
+    const double* __restrict__ wsE = ws - ax0;  // the x lane's slot holds E for the whole trajectory
     const size_t wstride = (size_t)n_slots;
     __shared__ int s_cnt[LSORT ? 256 : 1];   // per bin: count, then running fill position
     __shared__ int s_mine[LSORT ? 64 : 1];
 
-    const int n_round = (a.n_traj + n_slots - 1) / n_slots;
+    const int n_items = gridDim.x * IPW;
+    const int n_round = (a.n_traj + n_items - 1) / n_items;
     for (int round = 0; round < n_round; ++round) {
-        int b = round * n_slots + slot;
+        int b = lane_used ? round * n_items + blockIdx.x * IPW + item : a.n_traj;
         if constexpr (LSORT) {
-            const int lane = threadIdx.x;
             const int q = blockIdx.x % GRP;
-            const int base = round * n_slots + (blockIdx.x - q) * 64;  // first trajectory of the group's window
-            int key[GRP];
+            const int base = round * n_items + (blockIdx.x - q) * IPW;  // first trajectory of the group's window
+            int key[KPL];
 #pragma unroll
-            for (int j = 0; j < GRP; ++j) {
-                const int t = base + j * 64 + lane;
+            for (int j = 0; j < KPL; ++j) {
+                const int w = j * 64 + lane;
+                const int t = base + w;
                 int Mt = -1;
-                if (t < a.n_traj) {
+                if (w < WIN && t < a.n_traj) {
                     Mt = a.seg_offsets[t + 1] - a.seg_offsets[t];
                     Mt = Mt < 0 ? 0 : (Mt > 255 ? 255 : Mt);
                 }
@@ -80,7 +96,7 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
             s_mine[lane] = -1;
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < GRP; ++j)
+            for (int j = 0; j < KPL; ++j)
                 if (key[j] >= 0) atomicAdd(&s_cnt[255 - key[j]], 1);  // bin 0 = longest
             __syncthreads();
             // exclusive prefix over the 256 bins: 4 bins per lane + a wave scan
@@ -99,13 +115,13 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
             for (int j = 0; j < 4; ++j) { s_cnt[4 * lane + j] = run; run += c[j]; }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < GRP; ++j)
+            for (int j = 0; j < KPL; ++j)
                 if (key[j] >= 0) {
                     const int pos = atomicAdd(&s_cnt[255 - key[j]], 1);
-                    if ((pos >> 6) == q) s_mine[pos & 63] = j * 64 + lane;
+                    if (pos / IPW == q) s_mine[pos % IPW] = j * 64 + lane;
                 }
             __syncthreads();
-            const int mine = s_mine[lane];
+            const int mine = lane_used ? s_mine[item] : -1;
             __syncthreads();  // before the next round clears s_mine
             b = mine >= 0 ? base + mine : a.n_traj;
         }
@@ -127,60 +143,60 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
         if (ok)
             for (int i = 0; i < M; ++i) ok = ok && (T[i] > 0.0) && (T[i] < INFINITY);
         if (!ok) {
-            if (a.status) a.status[b] = UAVQP_INVALID_INPUT;
+            if (a.status && ax0 == 0) a.status[b] = UAVQP_INVALID_INPUT;
             continue;
         }
 
-        double y0[ND][3], yM[ND][3];
+        double y0[ND][NAX], yM[ND][NAX];
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                y0[d][ax] = bc[d * 3 + ax];
-                yM[d][ax] = bc[(ND + d) * 3 + ax];
+            for (int ax = 0; ax < NAX; ++ax) {
+                y0[d][ax] = bc[d * 3 + ax0 + ax];
+                yM[d][ax] = bc[(ND + d) * 3 + ax0 + ax];
             }
 
         // ---------------- forward elimination over interior knots k = 1..M-1 ----------------
         SegBlocks<R> sa;
         sa.build(T[0]);
-        double pb[3], dpa[3];
+        double pb[NAX], dpa[NAX];
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            pb[ax] = wp[3 + ax];
-            dpa[ax] = pb[ax] - wp[ax];
+        for (int ax = 0; ax < NAX; ++ax) {
+            pb[ax] = wp[3 + ax0 + ax];
+            dpa[ax] = pb[ax] - wp[ax0 + ax];
         }
-        double Eprev[ND][ND], hprev[ND][3];
+        double Eprev[ND][ND], hprev[ND][NAX];
         // software prefetch: the loads of step k+1 are issued before the arithmetic of step k (one lane per
         // trajectory has nothing else to hide an HBM round trip per knot behind)
-        double Tn = M > 1 ? T[1] : 1.0, pn[3];
+        double Tn = M > 1 ? T[1] : 1.0, pn[NAX];
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) pn[ax] = M > 1 ? wp[6 + ax] : 0.0;
+        for (int ax = 0; ax < NAX; ++ax) pn[ax] = M > 1 ? wp[6 + ax0 + ax] : 0.0;
         for (int k = 1; k < M; ++k) {
             const double Tk_ = Tn;
-            double pcur[3];
+            double pcur[NAX];
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) pcur[ax] = pn[ax];
+            for (int ax = 0; ax < NAX; ++ax) pcur[ax] = pn[ax];
             if (k + 1 < M) {
                 Tn = T[k + 1];
 #pragma unroll
-                for (int ax = 0; ax < 3; ++ax) pn[ax] = wp[3 * (k + 2) + ax];
+                for (int ax = 0; ax < NAX; ++ax) pn[ax] = wp[3 * (k + 2) + ax0 + ax];
             }
             SegBlocks<R> sb;
             sb.build(Tk_);
-            double dpb[3];
+            double dpb[NAX];
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
+            for (int ax = 0; ax < NAX; ++ax) {
                 const double pc = pcur[ax];
                 dpb[ax] = pc - pb[ax];
                 pb[ax] = pc;
             }
-            double S[ND][ND], z[ND][3];
+            double S[ND][ND], z[ND][NAX];
 #pragma unroll
             for (int i = 0; i < ND; ++i) {
 #pragma unroll
                 for (int j = 0; j < ND; ++j) S[i][j] = sa.A11[i][j] + sb.A00(i, j);
 #pragma unroll
-                for (int ax = 0; ax < 3; ++ax) z[i][ax] = sb.gv(i) * dpb[ax] - sa.gw[i] * dpa[ax];
+                for (int ax = 0; ax < NAX; ++ax) z[i][ax] = sb.gv(i) * dpb[ax] - sa.gw[i] * dpa[ax];
             }
             if (k == 1) {
 #pragma unroll
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
 #pragma unroll
                     for (int j = 0; j < ND; ++j)
 #pragma unroll
-                        for (int ax = 0; ax < 3; ++ax) z[i][ax] -= sa.A01[j][i] * y0[j][ax];
+                        for (int ax = 0; ax < NAX; ++ax) z[i][ax] -= sa.A01[j][i] * y0[j][ax];
             } else {
 #pragma unroll
                 for (int i = 0; i < ND; ++i)
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
 #pragma unroll
                         for (int c = 0; c < ND; ++c) S[i][c] -= sa.A01[j][i] * Eprev[j][c];
 #pragma unroll
-                        for (int ax = 0; ax < 3; ++ax) z[i][ax] -= sa.A01[j][i] * hprev[j][ax];
+                        for (int ax = 0; ax < NAX; ++ax) z[i][ax] -= sa.A01[j][i] * hprev[j][ax];
                     }
             }
             if (k == M - 1) {
@@ -206,12 +222,12 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
 #pragma unroll
                     for (int j = 0; j < ND; ++j)
 #pragma unroll
-                        for (int ax = 0; ax < 3; ++ax) z[i][ax] -= sb.A01[i][j] * yM[j][ax];
+                        for (int ax = 0; ax < NAX; ++ax) z[i][ax] -= sb.A01[i][j] * yM[j][ax];
             }
             SmallLDL<ND> ldl;
             ldl.factor(S);
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
+            for (int ax = 0; ax < NAX; ++ax) {
                 double col[ND];
 #pragma unroll
                 for (int i = 0; i < ND; ++i) col[i] = z[i][ax];
@@ -229,65 +245,67 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
                 for (int i = 0; i < ND; ++i) Eprev[i][c] = col[i];
             }
             double* w = ws + (size_t)(k - 1) * F * wstride;
+            if (ax0 == 0) {
 #pragma unroll
-            for (int i = 0; i < ND; ++i) {
+                for (int i = 0; i < ND; ++i)
 #pragma unroll
-                for (int c = 0; c < ND; ++c) w[(size_t)(i * ND + c) * wstride] = Eprev[i][c];
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) w[(size_t)(ND * ND + i * 3 + ax) * wstride] = hprev[i][ax];
+                    for (int c = 0; c < ND; ++c) w[(size_t)(i * ND + c) * wstride] = Eprev[i][c];
             }
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+#pragma unroll
+                for (int ax = 0; ax < NAX; ++ax) w[(size_t)(ND * ND + i * NAX + ax) * wstride] = hprev[i][ax];
             sa = sb;
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) dpa[ax] = dpb[ax];
+            for (int ax = 0; ax < NAX; ++ax) dpa[ax] = dpb[ax];
         }
 
         // ---------------- backward substitution + coefficient emission ----------------
-        double ynext[ND][3], pend[3];
+        double ynext[ND][NAX], pend[NAX];
         bool finite = true;
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            pend[ax] = wp[3 * M + ax];
+        for (int ax = 0; ax < NAX; ++ax) {
+            pend[ax] = wp[3 * M + ax0 + ax];
 #pragma unroll
             for (int d = 0; d < ND; ++d) ynext[d][ax] = yM[d][ax];
         }
         // software prefetch of the sweep state of knot k-1 (and of T, waypoint) while knot k is processed
-        double wn[F], Tkn = T[M - 1], pkn[3];
+        double wn[F], Tkn = T[M - 1], pkn[NAX];
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) pkn[ax] = wp[3 * (M - 1) + ax];
-        if (M >= 2) {
-            const double* w = ws + (size_t)(M - 2) * F * wstride;
+        for (int ax = 0; ax < NAX; ++ax) pkn[ax] = wp[3 * (M - 1) + ax0 + ax];
+        auto load_rec = [&](int knot, double (&dst)[F]) {  // interior knot `knot` = 1..M-1
+            const size_t off = (size_t)(knot - 1) * F * wstride;
 #pragma unroll
-            for (int f = 0; f < F; ++f) wn[f] = w[(size_t)f * wstride];
-        }
+            for (int f = 0; f < ND * ND; ++f) dst[f] = wsE[off + (size_t)f * wstride];
+#pragma unroll
+            for (int f = ND * ND; f < F; ++f) dst[f] = ws[off + (size_t)f * wstride];
+        };
+        if (M >= 2) load_rec(M - 1, wn);
         for (int k = M - 1; k >= 0; --k) {
             double wc[F];
 #pragma unroll
             for (int f = 0; f < F; ++f) wc[f] = wn[f];
             const double Tk = Tkn;
-            double pkc[3];
+            double pkc[NAX];
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) pkc[ax] = pkn[ax];
+            for (int ax = 0; ax < NAX; ++ax) pkc[ax] = pkn[ax];
             if (k >= 1) {
                 Tkn = T[k - 1];
 #pragma unroll
-                for (int ax = 0; ax < 3; ++ax) pkn[ax] = wp[3 * (k - 1) + ax];
-                if (k >= 2) {
-                    const double* w = ws + (size_t)(k - 2) * F * wstride;
-#pragma unroll
-                    for (int f = 0; f < F; ++f) wn[f] = w[(size_t)f * wstride];
-                }
+                for (int ax = 0; ax < NAX; ++ax) pkn[ax] = wp[3 * (k - 1) + ax0 + ax];
+                if (k >= 2) load_rec(k - 1, wn);
             }
-            double y[ND][3];
+            double y[ND][NAX];
             if (k == 0) {
 #pragma unroll
                 for (int d = 0; d < ND; ++d)
 #pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) y[d][ax] = y0[d][ax];
+                    for (int ax = 0; ax < NAX; ++ax) y[d][ax] = y0[d][ax];
             } else {
 #pragma unroll
                 for (int i = 0; i < ND; ++i)
 #pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) y[i][ax] = wc[ND * ND + i * 3 + ax];
+                    for (int ax = 0; ax < NAX; ++ax) y[i][ax] = wc[ND * ND + i * NAX + ax];
                 if (k < M - 1) {
 #pragma unroll
                     for (int i = 0; i < ND; ++i)
@@ -295,13 +313,13 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
                         for (int c = 0; c < ND; ++c) {
                             const double e = wc[i * ND + c];
 #pragma unroll
-                            for (int ax = 0; ax < 3; ++ax) y[i][ax] -= e * ynext[c][ax];
+                            for (int ax = 0; ax < NAX; ++ax) y[i][ax] -= e * ynext[c][ax];
                         }
                 }
             }
             const double itk = 1.0 / Tk;
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
+            for (int ax = 0; ax < NAX; ++ax) {
                 const double pk = pkc[ax];
                 double ys[ND], ye[ND], c[NC];
 #pragma unroll
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
                     ye[d] = ynext[d][ax];
                 }
                 segment_coeffs<R>(pk, ys, pend[ax], ye, Tk, itk, c);
-                double* o = out + ((size_t)ax * M + k) * NC;
+                double* o = out + ((size_t)(ax0 + ax) * M + k) * NC;
 #pragma unroll
                 for (int j = 0; j < NC; ++j) o[j] = c[j];
                 finite = finite && (fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY);
@@ -319,9 +337,13 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
 #pragma unroll
             for (int d = 0; d < ND; ++d)
 #pragma unroll
-                for (int ax = 0; ax < 3; ++ax) ynext[d][ax] = y[d][ax];
+                for (int ax = 0; ax < NAX; ++ax) ynext[d][ax] = y[d][ax];
         }
-        if (a.status) a.status[b] = finite ? UAVQP_SOLVED : UAVQP_NON_FINITE;
+        if constexpr (NAX == 1) {  // AND over the three lanes of the trajectory (they took the same branches)
+            const int f0 = finite ? 1 : 0, l0 = lane - ax0;
+            finite = (__shfl(f0, l0, 64) & __shfl(f0, l0 + 1, 64) & __shfl(f0, l0 + 2, 64)) != 0;
+        }
+        if (a.status && ax0 == 0) a.status[b] = finite ? UAVQP_SOLVED : UAVQP_NON_FINITE;
     }
 }
 
@@ -871,25 +893,37 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
         }
     }
     // ragged batches of some size: 256-thread workgroups that deal their chunk to the lanes by segment count
-    // ragged batches of some size: groups of 16 workgroups deal a 1024-trajectory window to their lanes by segment count
+    // Lanes: one per (trajectory, axis) for small batches -- 21 trajectories per wave, a shorter dependent chain per lane
+    // (measured, r = 4: M = 14 24 -> 18 us, M = 24 40 -> 29 us up to 4096 trajectories) -- and one per trajectory (3 axes
+    // share the factorisation, a third of the E traffic) once the batch is throughput-bound (cross-over at ~8192;
+    // 32768 x M = 14: 50 vs 76 us).  Ragged batches of some size deal windows of 16 waves' trajectories by segment count.
     const bool lsort = uniform_segments == 0 && n_traj >= 2048 && !std::getenv("UAVQP_NO_LSORT");
+    int nax = n_traj <= 32 * ctx->num_cus ? 1 : 3;
+    if (const char* e = std::getenv("UAVQP_GENERIC_NAX")) nax = std::atoi(e) == 3 ? 3 : 1;
+    const int ipw = nax == 3 ? 64 : 21;
     const int block = 64;
-    int grid = (n_traj + block - 1) / block;
-    const int max_grid = ctx->num_cus * 8;
+    int grid = (n_traj + ipw - 1) / ipw;
+    const int max_grid = ctx->num_cus * (nax == 3 ? 8 : 12);
     if (grid > max_grid) grid = max_grid;
     if (lsort) grid = (grid + 15) / 16 * 16;
-    const int F = (r - 1) * (r - 1) + 3 * (r - 1);
+    const int F = (r - 1) * (r - 1) + nax * (r - 1);
     const size_t ws_bytes = sizeof(double) * (size_t)(Mmax > 1 ? Mmax - 1 : 1) * F * (size_t)grid * block;
     int rc = ensure_ws(ctx, ws_bytes);
     if (rc != UAVQP_OK) return rc;
     a.ws = ctx->ws;
-    if (r == 3) {
-        if (lsort) hipLaunchKernelGGL((uavqp::solve_generic_kernel<3, true>), dim3(grid), dim3(block), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((uavqp::solve_generic_kernel<3, false>), dim3(grid), dim3(block), 0, ctx->stream, a);
-    } else {
-        if (lsort) hipLaunchKernelGGL((uavqp::solve_generic_kernel<4, true>), dim3(grid), dim3(block), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((uavqp::solve_generic_kernel<4, false>), dim3(grid), dim3(block), 0, ctx->stream, a);
-    }
+#define UAVQP_GENERIC(RR)                                                                                                   \
+    do {                                                                                                                    \
+        if (nax == 3) {                                                                                                     \
+            if (lsort) hipLaunchKernelGGL((uavqp::solve_generic_kernel<RR, true, 3>), dim3(grid), dim3(block), 0, ctx->stream, a);  \
+            else hipLaunchKernelGGL((uavqp::solve_generic_kernel<RR, false, 3>), dim3(grid), dim3(block), 0, ctx->stream, a);       \
+        } else {                                                                                                            \
+            if (lsort) hipLaunchKernelGGL((uavqp::solve_generic_kernel<RR, true, 1>), dim3(grid), dim3(block), 0, ctx->stream, a);  \
+            else hipLaunchKernelGGL((uavqp::solve_generic_kernel<RR, false, 1>), dim3(grid), dim3(block), 0, ctx->stream, a);       \
+        }                                                                                                                   \
+    } while (0)
+    if (r == 3) UAVQP_GENERIC(3);
+    else UAVQP_GENERIC(4);
+#undef UAVQP_GENERIC
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }
