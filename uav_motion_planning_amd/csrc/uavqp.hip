@@ -903,7 +903,13 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     const int ipw = nax == 3 ? 64 : 21;
     const int block = 64;
     int grid = (n_traj + ipw - 1) / ipw;
-    const int max_grid = ctx->num_cus * (nax == 3 ? 8 : 12);
+    // Resident waves: the kernel is bound by the E/h workspace round trip, and the workspace is per resident lane.  With
+    // one wave per CU it is ~30 MB (r = 4, M = 14) and stays in L2 while the grid strides over the batch (measured with
+    // tools/generic_grid_probe.py: 65536 x M=14: 111 us at 1 wave/CU vs 141 us at 8; 262144: 524 vs 640 us; r = 3, M = 20,
+    // 262144: 625 vs 920 us); up to 128 trajectories per CU two waves per CU run the batch in a single round (49 vs 58 us).
+    int waves_per_cu = nax == 3 ? (n_traj <= 128 * ctx->num_cus ? 2 : 1) : 12;
+    if (const char* e = std::getenv("UAVQP_GENERIC_WPC")) waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : waves_per_cu;
+    const int max_grid = ctx->num_cus * waves_per_cu;
     if (grid > max_grid) grid = max_grid;
     if (lsort) grid = (grid + 15) / 16 * 16;
     const int F = (r - 1) * (r - 1) + nax * (r - 1);
@@ -1100,7 +1106,7 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     const int block = 64;
     long long lanes = 3LL * n_traj;
     long long grid = (lanes + block - 1) / block;
-    const long long max_grid = (long long)ctx->num_cus * 8;
+    const long long max_grid = (long long)ctx->num_cus * 8;  // measured on config 3: 2 waves/CU 3.68 ms, 4: 2.30, 6: 2.02, 8: 2.01
     if (grid > max_grid) grid = max_grid;
     const int F = r * (r - 1) / 2 + 2 * r + 1;  // must match solve_corridor_kernel's state layout
     const size_t ws_bytes = sizeof(double) * (size_t)(Mmax > 1 ? Mmax - 1 : 1) * F * (size_t)grid * block;
