@@ -36,7 +36,7 @@ struct BatchArgs {
 // ---------------------------------------------------------------------------------------------------
 // Generic kernel: any segment count (ragged batches), r = 3 or 4.
 // Forward block elimination keeps E_k = S_k^-1 A01(k) and h_k = S_k^-1 z_k per interior knot in a
-// lane-interleaved HBM workspace  ws[((k-1)*F + f) * n_slots + slot]  (coalesced across the wave),
+// HBM workspace  ws[wave][k-1][f][lane]  (every access a coalesced 512-byte row of the wave),
 // the backward sweep re-reads them and emits segment coefficients as it goes.
 //
 // NAX = 3: one lane per trajectory carries all three axes (the factorisation is shared).
@@ -61,18 +61,18 @@ __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
     constexpr int GRP = 16, WIN = GRP * IPW;  // LSORT window
     constexpr int KPL = (WIN + 63) / 64;      // keys per lane
     const int lane = threadIdx.x;
-    const int slot = blockIdx.x * 64 + lane;
-    const int n_slots = gridDim.x * 64;  // LSORT: the host rounds the grid to a multiple of GRP
     const int ax0 = NAX == 1 ? lane % 3 : 0;
     const int item = lane / LPI;
     const bool lane_used = item < IPW;   // NAX = 1: lane 63 idles
-    double* __restrict__ ws = a.ws + slot;
+    // workspace [wave][interior knot][field][lane]: a wave's record of one knot is F consecutive 512-byte rows
+    const int kmax = a.max_segments > 1 ? a.max_segments - 1 : 1;
+    double* __restrict__ ws = a.ws + (size_t)blockIdx.x * kmax * F * 64 + lane;
     const double* __restrict__ wsE = ws - ax0;  // the x lane's slot holds E for the whole trajectory
-    const size_t wstride = (size_t)n_slots;
+    constexpr size_t wstride = 64;
     __shared__ int s_cnt[LSORT ? 256 : 1];   // per bin: count, then running fill position
     __shared__ int s_mine[LSORT ? 64 : 1];
 
-    const int n_items = gridDim.x * IPW;
+    const int n_items = gridDim.x * IPW;  // LSORT: the host rounds the grid to a multiple of GRP
     const int n_round = (a.n_traj + n_items - 1) / n_items;
     for (int round = 0; round < n_round; ++round) {
         int b = lane_used ? round * n_items + blockIdx.x * IPW + item : a.n_traj;
