@@ -259,3 +259,27 @@ def test_mid_segment_samples_by_knot_insertion(gpu_ctx, oracle):
                                                ref["waypoints"].reshape(n, M2 + 1, 3)[k, :, ax], b["bc"][k, 0, :, ax], b["bc"][k, 1, :, ax],
                                                lo2[k, ax], hi2[k, ax])
             assert prim < 1e-9 and stat < 1e-7 and comp < 1e-6
+
+
+@pytest.mark.parametrize("r,M", [(3, 10), (4, 6)])
+def test_corridor_stress_time_allocation_and_tiny_boxes(gpu_ctx, oracle, r, M):
+    """Stress: durations in [0.2, 5] s (block entries spanning T^-7..T^-1) and boxes from 1 mm to 1 m, some degenerate.
+    Every result must be feasible and pass the optimality certificate of the reference-formulation matrices
+    (stationarity tolerance 1e-6 here: the raw KKT condition numbers reach 1e13 for this allocation)."""
+    n = 48
+    b = W.uniform_batch(3, n, M, r, time_mode="wide")
+    rng = np.random.default_rng(123)
+    wp = b["waypoints"]
+    h = 10.0 ** rng.uniform(-3, 0, size=wp.shape)
+    h[rng.random(size=wp.shape) < 0.1] = 0.0
+    lo, hi = wp - h, wp + h
+    got, st, it = gpu_ctx.solve_corridor_batch_host(r, None, wp, b["times"], b["bc"], lo, hi, uniform_segments=M)
+    assert np.all(st == U.UAVQP_SOLVED), np.unique(st, return_counts=True)
+    g = got.reshape(n, 3, 2 * r * M)
+    worst = np.zeros(3)
+    for k in range(n):
+        for ax in range(3):
+            prim, stat, comp = kkt_certificate(oracle, r, M, b["times"][k], g[k, ax], wp[k, :, ax], b["bc"][k, 0, :, ax],
+                                               b["bc"][k, 1, :, ax], lo[k, 1:M, ax], hi[k, 1:M, ax])
+            worst = np.maximum(worst, [prim, stat, comp])
+    assert worst[0] < 1e-9 and worst[1] < 1e-6 and worst[2] < 1e-5, worst
