@@ -192,6 +192,23 @@ int uavqp_ellipsoid_check_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_
                                  const double* d_obstacles, int n_obs, double robot_r, double robot_h,
                                  int32_t* d_first_hit, uint8_t* d_flags);
 
+/* Uniform grid over an obstacle point cloud and the ellipsoid check that queries it instead of scanning every point:
+ * the batched stand-in for the kd-tree radius search of KinoAstar::isCollisionFree
+ * (src/planner/path_searching/src/kino_astar.cpp:747-750, kdtree radiusSearch(pt, robot_r + 0.1)).
+ *   uavqp_obstacle_grid_build_device: buckets d_obstacles [n_obs][3] by cell (cell_size > 0; robot_r + 0.1 makes a
+ *     query visit 27 cells; clouds too large for 2^22 cells get larger cells).  Synchronous (sizes depend on the
+ *     cloud's bounds); the grid owns a sorted copy of the points, d_obstacles may be freed afterwards.
+ *   uavqp_ellipsoid_check_grid_device: arguments and results of uavqp_ellipsoid_check_device with the grid in place
+ *     of the raw cloud -- same candidate set and the same arithmetic per candidate, hence identical flags.
+ * No reference counterpart as a batch; the per-query semantics are the reference's. */
+typedef struct uavqp_grid uavqp_grid;
+int uavqp_obstacle_grid_build_device(uavqp_ctx* ctx, const double* d_obstacles, int n_obs, double cell_size, uavqp_grid** out_grid);
+int uavqp_obstacle_grid_destroy(uavqp_ctx* ctx, uavqp_grid* grid);
+int uavqp_ellipsoid_check_grid_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                      const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
+                                      const uavqp_grid* grid, double robot_r, double robot_h, int32_t* d_first_hit,
+                                      uint8_t* d_flags);
+
 /* Corridor boxes from an obstacle point cloud (SURVEY.md section 8-d config 5 "ellipsoid-derived corridor widths",
  * 8-f N4).  No reference counterpart as a function: it turns the reference's SE(3) collision test
  * KinoAstar::isCollisionFree(pt, acc) (src/planner/path_searching/src/kino_astar.cpp:721-758) into the box

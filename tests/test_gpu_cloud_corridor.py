@@ -196,3 +196,72 @@ def test_config5_pipeline_cloud_corridors_then_corridor_solve_and_reallocation(o
                 acc0 = _knot_acc(coef0, so, T0, r, k, j)
                 assert oracle.is_collision_free(p - (p - wp[row]) * 1e-9, acc0, obs, ROBOT_R, ROBOT_H)
     assert n_wide > 50
+
+
+@pytest.mark.parametrize("cell", [0.5, 0.17, 3.0])
+def test_grid_ellipsoid_check_is_identical_to_the_exhaustive_scan(gpu_ctx, cell):
+    """uavqp_obstacle_grid_build_device + uavqp_ellipsoid_check_grid_device against uavqp_ellipsoid_check_device (itself
+    checked against the restated KinoAstar::isCollisionFree): same candidate set, same arithmetic per candidate, so the
+    flags and first-hit indices must be IDENTICAL -- for the natural cell size (robot_r + 0.1), a finer and a coarser one."""
+    import torch
+    r, n, ns, dt = 4, 96, 80, 0.06
+    b = W.ragged_batch(5, n, r, m_lo=2, m_hi=14)
+    so = b["seg_offsets"]
+    obs = W.pillar_cloud(5, n_pillars=120, resolution=0.2)
+    rng = np.random.default_rng(3)
+    wpts = np.asarray(b["waypoints"]).reshape(-1, 3)
+    obs = np.concatenate([obs, wpts[rng.integers(0, wpts.shape[0], 300)] + rng.normal(scale=0.3, size=(300, 3))])   # some right on the paths
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_so, d_T, d_obs = up(so), up(b["times"]), up(obs)
+    coef, st = gpu_ctx.solve_batch_host(r, so, b["waypoints"], b["times"], b["bc"])
+    d_coef = up(coef)
+    f_ex = torch.zeros(n * ns, dtype=torch.uint8, device=dev); h_ex = torch.zeros(n, dtype=torch.int32, device=dev)
+    f_gr = torch.zeros(n * ns, dtype=torch.uint8, device=dev); h_gr = torch.zeros(n, dtype=torch.int32, device=dev)
+    gpu_ctx.ellipsoid_check_device(r, n, 0, d_so, d_T, d_coef, ns, 0.0, dt, d_obs, obs.shape[0], ROBOT_R, ROBOT_H, h_ex, f_ex)
+    grid = gpu_ctx.obstacle_grid_build(d_obs, obs.shape[0], cell)
+    try:
+        gpu_ctx.ellipsoid_check_grid_device(r, n, 0, d_so, d_T, d_coef, ns, 0.0, dt, grid, ROBOT_R, ROBOT_H, h_gr, f_gr)
+        gpu_ctx.synchronize()
+        assert torch.equal(f_ex, f_gr) and torch.equal(h_ex, h_gr)
+        hits = int(f_ex.sum().item())
+        assert 0.01 * n * ns < hits < 0.9 * n * ns
+        # without the per-sample flags
+        gpu_ctx.ellipsoid_check_grid_device(r, n, 0, d_so, d_T, d_coef, ns, 0.0, dt, grid, ROBOT_R, ROBOT_H, h_gr, None)
+        gpu_ctx.synchronize()
+        assert torch.equal(h_ex, h_gr)
+    finally:
+        gpu_ctx.obstacle_grid_destroy(grid)
+
+
+def test_grid_edge_cases(gpu_ctx):
+    import torch
+    dev = torch.device("cuda", 0)
+    r, n, M, ns = 3, 5, 3, 10
+    b = W.uniform_batch(5, n, M, r, time_mode="reference")
+    coef, st = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    d_coef = torch.from_numpy(coef).to(dev)
+    d_T = torch.from_numpy(b["times"].reshape(-1).copy()).to(dev)
+    hit = torch.zeros(n, dtype=torch.int32, device=dev)
+    # empty cloud: valid grid, nothing collides
+    g0 = gpu_ctx.obstacle_grid_build(None, 0, 0.5)
+    gpu_ctx.ellipsoid_check_grid_device(r, n, M, None, d_T, d_coef, ns, 0.0, 0.3, g0, ROBOT_R, ROBOT_H, hit)
+    gpu_ctx.synchronize()
+    assert bool((hit == ns).all())
+    gpu_ctx.obstacle_grid_destroy(g0)
+    # a single point sitting on the first waypoint of trajectory 2: sample 0 of that trajectory collides, nothing else need
+    p = torch.from_numpy(b["waypoints"][2, 0].copy()).to(dev)
+    g1 = gpu_ctx.obstacle_grid_build(p, 1, 0.5)
+    gpu_ctx.ellipsoid_check_grid_device(r, n, M, None, d_T, d_coef, ns, 0.0, 0.3, g1, ROBOT_R, ROBOT_H, hit)
+    gpu_ctx.synchronize()
+    assert int(hit[2].item()) == 0
+    gpu_ctx.obstacle_grid_destroy(g1)
+    # invalid arguments
+    import ctypes
+    h = ctypes.c_void_p()
+    lib = U.lib()
+    assert lib.uavqp_obstacle_grid_build_device(gpu_ctx._h, None, 5, 0.5, ctypes.byref(h)) == -1       # points missing
+    assert lib.uavqp_obstacle_grid_build_device(gpu_ctx._h, None, 0, 0.0, ctypes.byref(h)) == -1       # cell size
+    bad = torch.tensor([[0.0, float("nan"), 1.0]], dtype=torch.float64, device=dev)
+    assert lib.uavqp_obstacle_grid_build_device(gpu_ctx._h, bad.data_ptr(), 1, 0.5, ctypes.byref(h)) == -1
+

@@ -141,6 +141,21 @@ def main():
     with torch.cuda.stream(s):
         ms_loop_warm = timeit(outer_loop_warm, s, n=3, warm=1)
         outer_loop_warm(record=True)
+    # final validation of config 5: SE(3) ellipsoid check of every trajectory at 100 samples, exhaustive vs grid
+    ns = 100
+    tot_T = float(d["times"].sum() / n)
+    fh = torch.zeros(n, dtype=torch.int32, device=dev)
+    ms_check = timeit(lambda: ctx.ellipsoid_check_device(r, n, 0, d_so, d["times"], out, ns, 0.0, tot_T / ns, d_obs, obs.shape[0], 0.4, 0.1, fh), s, n=3, warm=1)
+    t0 = time.perf_counter()
+    grid = ctx.obstacle_grid_build(d_obs, obs.shape[0], 0.5)
+    ms_grid_build = (time.perf_counter() - t0) * 1e3
+    fh2 = torch.zeros(n, dtype=torch.int32, device=dev)
+    ms_check_grid = timeit(lambda: ctx.ellipsoid_check_grid_device(r, n, 0, d_so, d["times"], out, ns, 0.0, tot_T / ns, grid, 0.4, 0.1, fh2), s, n=10, warm=2)
+    same = bool(torch.equal(fh, fh2))
+    ctx.obstacle_grid_destroy(grid)
+    print(json.dumps({"config": "5-validation", "n": n, "samples": ns, "n_obs": int(obs.shape[0]), "ms_exhaustive": ms_check,
+                      "ms_grid": ms_check_grid, "ms_grid_build_host_sync": ms_grid_build, "identical_first_hits": same,
+                      "colliding_trajectories": int((fh2 < ns).sum())}))
     print(json.dumps({"config": "5-pipeline", "n": n, "sum_M": int(so[-1]), "r": r, "n_obs": int(obs.shape[0]),
                       "ms_plain_solve": ms_solve, "ms_cloud_corridor": ms_cloud,
                       "cloud_pairs_per_s": rows * obs.shape[0] / ms_cloud * 1e3,

@@ -40,6 +40,9 @@ SYMBOLS = (
     "uavqp_eval_batch_device",
     "uavqp_ellipsoid_check_device",
     "uavqp_corridor_from_cloud_device",
+    "uavqp_obstacle_grid_build_device",
+    "uavqp_obstacle_grid_destroy",
+    "uavqp_ellipsoid_check_grid_device",
     "uavqp_capture_begin",
     "uavqp_capture_end",
     "uavqp_graph_launch",
@@ -101,6 +104,10 @@ def lib():
                                                ctypes.c_double, ctypes.c_double, ip, vp]
     L.uavqp_corridor_from_cloud_device.argtypes = [vp, i32, i32, i32, ip, i32, dp, dp, dp, dp, i32, ctypes.c_double, ctypes.c_double,
                                                    ctypes.c_double, dp, dp, dp]
+    L.uavqp_obstacle_grid_build_device.argtypes = [vp, dp, i32, ctypes.c_double, ctypes.POINTER(vp)]
+    L.uavqp_obstacle_grid_destroy.argtypes = [vp, vp]
+    L.uavqp_ellipsoid_check_grid_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, vp,
+                                                    ctypes.c_double, ctypes.c_double, ip, vp]
     L.uavqp_capture_begin.argtypes = [vp]
     L.uavqp_capture_end.argtypes = [vp, ctypes.POINTER(vp)]
     L.uavqp_graph_launch.argtypes = [vp, vp]

@@ -1,0 +1,295 @@
+// obstacle_grid.h -- uniform grid over an obstacle point cloud and the SE(3) ellipsoid check that queries it.
+//
+// Replaces the kd-tree radius search of KinoAstar::isCollisionFree (src/planner/path_searching/src/kino_astar.cpp:747-750:
+// kdtree radiusSearch(pt, robot_r + 0.1)) for batched queries: points are bucketed by cell (counting sort, cell >= the
+// search radius by default so that a query visits 27 cells), the query walks the cells overlapping the radius box and
+// applies exactly the tests of ellipsoid_kernel (uavqp.hip) -- same candidate set, same arithmetic per pair, so the
+// flags are identical to the exhaustive scan.
+#pragma once
+#include "qp_device.h"
+
+namespace uavqp {
+
+struct GridView {
+    double org[3];     // lower corner of cell (0,0,0)
+    double inv_cell;   // 1 / cell size
+    int dim[3];        // cells per axis
+    const int32_t* cell_start;  // [ncell + 1] exclusive prefix of the per-cell counts
+    const double* pts;          // [n_obs][3] sorted by cell
+};
+
+__device__ __forceinline__ int grid_coord(const GridView& g, double x, int ax) {
+    int c = (int)floor((x - g.org[ax]) * g.inv_cell);
+    return c < 0 ? 0 : (c >= g.dim[ax] ? g.dim[ax] - 1 : c);
+}
+
+// per-block partial bounds: out[block][6] = min xyz, max xyz
+__global__ void grid_bounds_kernel(const double* __restrict__ obs, int n_obs, double* __restrict__ out) {
+    __shared__ double s[256][6];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_obs; i += gridDim.x * 256)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const double v = obs[(size_t)i * 3 + ax];
+            if (fabs(v) < INFINITY) {
+                mn[ax] = fmin(mn[ax], v);
+                mx[ax] = fmax(mx[ax], v);
+            } else {  // NaN / inf: poison the bounds so that the host rejects the cloud
+                mn[ax] = -INFINITY;
+                mx[ax] = INFINITY;
+            }
+        }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) { s[threadIdx.x][ax] = mn[ax]; s[threadIdx.x][3 + ax] = mx[ax]; }
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                s[threadIdx.x][ax] = fmin(s[threadIdx.x][ax], s[threadIdx.x + d][ax]);
+                s[threadIdx.x][3 + ax] = fmax(s[threadIdx.x][3 + ax], s[threadIdx.x + d][3 + ax]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out[blockIdx.x * 6 + threadIdx.x] = s[0][threadIdx.x];
+}
+
+__global__ void grid_count_kernel(GridView g, const double* __restrict__ obs, int n_obs, int32_t* __restrict__ cell_of,
+                                  int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_obs) return;
+    const int cx = grid_coord(g, obs[(size_t)i * 3], 0), cy = grid_coord(g, obs[(size_t)i * 3 + 1], 1),
+              cz = grid_coord(g, obs[(size_t)i * 3 + 2], 2);
+    const int c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    cell_of[i] = c;
+    atomicAdd(&counts[c], 1);
+}
+
+__global__ void grid_scatter_kernel(const double* __restrict__ obs, int n_obs, const int32_t* __restrict__ cell_of,
+                                    int32_t* __restrict__ cursor, double* __restrict__ sorted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_obs) return;
+    const int pos = atomicAdd(&cursor[cell_of[i]], 1);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) sorted[(size_t)pos * 3 + ax] = obs[(size_t)i * 3 + ax];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Corridor boxes from an obstacle cloud (include/uavqp.h: uavqp_corridor_from_cloud_device).
+// One lane per waypoint row.  The ellipsoid metric is evaluated as d' Q d with Q = sum_j b_j b_j' / s_j^2 (6 unique
+// entries in registers): 12 FP64 operations per (row, obstacle) pair, no early exit (it is a min); the cloud streams
+// through LDS in 1024-point tiles (one 24-byte broadcast read per pair).
+// A grid-pruned variant (scan a box around the row, widen once to g * max(robot_r, robot_h): exact, bit-identical) was
+// built and measured 9x SLOWER on config 5 (25.6 vs 2.8 ms): the flat axis of the robot ellipsoid (robot_h = 0.1) makes
+// the clearance of a free waypoint reach 10-25, i.e. a Euclidean radius of 4-10 m in a 40 x 20 m map -- nearly every
+// cell, visited with divergent per-lane loops instead of LDS broadcasts.  The grid pays for the radius-limited
+// collision check below (71x), not here.
+// ---------------------------------------------------------------------------------------------------
+struct CloudCorridorArgs {
+    int n_traj, uniform, n_rows, n_obs;
+    const int32_t* seg_offsets;
+    const double* waypoints;
+    const double* times;
+    const double* coeff;
+    const double* obs;
+    double robot_r, robot_h, h_max;
+    double* lo;
+    double* hi;
+    double* clearance;
+};
+
+template <int R>
+struct CorridorRow {
+    double p[3];
+    double qxx, qyy, qzz, qxy2, qxz2, qyz2;
+    bool interior;
+
+    // position, attitude (kino_astar.cpp:724-737) and quadratic form of waypoint row g
+    __device__ __forceinline__ void setup(const CloudCorridorArgs& a, long long g) {
+        constexpr int NC = 2 * R;
+        int b, k, M, s0;
+        if (a.uniform > 0) {
+            M = a.uniform;
+            b = (int)(g / (M + 1));
+            k = (int)(g - (long long)b * (M + 1));
+            s0 = b * M;
+        } else {
+            // row g belongs to the trajectory b with seg_offsets[b] + b <= g < seg_offsets[b+1] + b + 1
+            int lo_b = 0, hi_b = a.n_traj - 1;
+            while (lo_b < hi_b) {
+                const int mid = (lo_b + hi_b + 1) >> 1;
+                if ((long long)a.seg_offsets[mid] + mid <= g) lo_b = mid; else hi_b = mid - 1;
+            }
+            b = lo_b;
+            s0 = a.seg_offsets[b];
+            M = a.seg_offsets[b + 1] - s0;
+            k = (int)(g - ((long long)s0 + b));
+        }
+        interior = (k > 0) && (k < M);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) p[ax] = a.waypoints[(size_t)g * 3 + ax];
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (a.coeff) {
+            // acceleration at the knot: start of segment k (2 c_2), or the end of the last segment for k = M
+            const int seg = k < M ? k : M - 1;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double* ca = a.coeff + (size_t)3 * NC * s0 + ((size_t)ax * M + seg) * NC;
+                if (k < M) {
+                    acc[ax] = 2.0 * ca[2];
+                } else {
+                    const double t = a.times[s0 + seg];
+                    double av = 0.0;
+#pragma unroll
+                    for (int j = NC - 1; j >= 2; --j) av = fma(av, t, (double)(j * (j - 1)) * ca[j]);
+                    acc[ax] = av;
+                }
+            }
+        }
+        // kino_astar.cpp:724-727
+        const double n3 = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + (acc[2] + 9.81) * (acc[2] + 9.81));
+        const double b3[3] = {acc[0] / n3, acc[1] / n3, (acc[2] + 9.81) / n3};
+        const double c2y = b3[2], c2z = -b3[1];  // b3 x (1,0,0) = (0, b3z, -b3y)
+        const double n2 = sqrt(c2y * c2y + c2z * c2z);
+        const double b2[3] = {0.0, c2y / n2, c2z / n2};
+        double b1[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
+        const double n1 = sqrt(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
+        b1[0] /= n1; b1[1] /= n1; b1[2] /= n1;
+        const double wr = 1.0 / (a.robot_r * a.robot_r), wh = 1.0 / (a.robot_h * a.robot_h);
+        qxx = (b1[0] * b1[0] + b2[0] * b2[0]) * wr + b3[0] * b3[0] * wh;
+        qyy = (b1[1] * b1[1] + b2[1] * b2[1]) * wr + b3[1] * b3[1] * wh;
+        qzz = (b1[2] * b1[2] + b2[2] * b2[2]) * wr + b3[2] * b3[2] * wh;
+        qxy2 = 2.0 * ((b1[0] * b1[1] + b2[0] * b2[1]) * wr + b3[0] * b3[1] * wh);
+        qxz2 = 2.0 * ((b1[0] * b1[2] + b2[0] * b2[2]) * wr + b3[0] * b3[2] * wh);
+        qyz2 = 2.0 * ((b1[1] * b1[2] + b2[1] * b2[2]) * wr + b3[1] * b3[2] * wh);
+    }
+    __device__ __forceinline__ double metric2(double ox, double oy, double oz) const {
+        const double dx = ox - p[0], dy = oy - p[1], dz = oz - p[2];
+        return dx * (qxx * dx + qxy2 * dy + qxz2 * dz) + dy * (qyy * dy + qyz2 * dz) + qzz * dz * dz;
+    }
+    // clearance g = sqrt(min metric^2) -> box and outputs
+    __device__ __forceinline__ void emit(const CloudCorridorArgs& a, long long g, double min2) const {
+        const double gmin = sqrt(fmax(min2, 0.0));
+        if (a.clearance) a.clearance[g] = gmin;
+        const double margin = gmin > 1.0 ? gmin - 1.0 : 0.0;
+        const double q[3] = {qxx, qyy, qzz};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double h = 0.0;
+            if (interior) {
+                h = margin / (3.0 * sqrt(q[ax]));
+                h = h < a.h_max ? h : a.h_max;  // also maps margin = inf (empty cloud) to h_max
+            }
+            a.lo[(size_t)g * 3 + ax] = p[ax] - h;
+            a.hi[(size_t)g * 3 + ax] = p[ax] + h;
+        }
+    }
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void cloud_corridor_kernel(CloudCorridorArgs a) {
+    constexpr int TILE = 1024;
+    __shared__ double s_obs[TILE * 3];
+    const long long n_round = ((long long)a.n_rows + 255) / 256 * 256;  // every thread of a block joins the LDS tile loads
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n_round; g += (long long)gridDim.x * 256) {
+        const bool live = g < a.n_rows;
+        CorridorRow<R> row;
+        if (live) row.setup(a, g);
+        double m0 = INFINITY, m1 = INFINITY;  // two independent min chains
+        for (int o0 = 0; o0 < a.n_obs; o0 += TILE) {
+            const int nt = min(TILE, a.n_obs - o0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nt * 3; i += 256) s_obs[i] = a.obs[(size_t)o0 * 3 + i];
+            __syncthreads();
+            if (live) {
+                int i = 0;
+                for (; i + 1 < nt; i += 2) {
+                    m0 = fmin(m0, row.metric2(s_obs[3 * i], s_obs[3 * i + 1], s_obs[3 * i + 2]));
+                    m1 = fmin(m1, row.metric2(s_obs[3 * i + 3], s_obs[3 * i + 4], s_obs[3 * i + 5]));
+                }
+                if (i < nt) m0 = fmin(m0, row.metric2(s_obs[3 * i], s_obs[3 * i + 1], s_obs[3 * i + 2]));
+            }
+        }
+        if (live) row.emit(a, g, fmin(m0, m1));
+    }
+}
+
+struct EllipsoidGridArgs {
+    int n_traj, uniform, n_samples;
+    const int32_t* seg_offsets;
+    const double* times;
+    const double* coeff;
+    GridView grid;
+    double t0, dt, robot_r, robot_h;
+    int32_t* first_hit;
+    uint8_t* flags;
+};
+
+// One lane per (trajectory, sample), as ellipsoid_kernel; the candidates come from the cells overlapping the
+// axis-aligned box of half-width robot_r + 0.1 around the sample.
+template <int R>
+__global__ __launch_bounds__(256) void ellipsoid_grid_kernel(EllipsoidGridArgs a) {
+    constexpr int NC = 2 * R;
+    const long long total = (long long)a.n_traj * a.n_samples;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int b = (int)(g / a.n_samples);
+        const int s = (int)(g - (long long)b * a.n_samples);
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        const double* __restrict__ T = a.times + s0;
+        double t = a.t0 + s * a.dt;
+        int idx = 0;
+        while (idx < M && t > T[idx] + 1e-4) { t -= T[idx]; ++idx; }
+        if (idx == M) { --idx; t = T[idx]; }
+        double p[3], acc[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const double* ca = a.coeff + (size_t)3 * NC * s0 + ((size_t)ax * M + idx) * NC;
+            double pv = 0.0, av = 0.0;
+#pragma unroll
+            for (int j = NC - 1; j >= 0; --j) pv = fma(pv, t, ca[j]);
+#pragma unroll
+            for (int j = NC - 1; j >= 2; --j) av = fma(av, t, (double)(j * (j - 1)) * ca[j]);
+            p[ax] = pv;
+            acc[ax] = av;
+        }
+        // kino_astar.cpp:724-727
+        const double n3 = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + (acc[2] + 9.81) * (acc[2] + 9.81));
+        const double b3[3] = {acc[0] / n3, acc[1] / n3, (acc[2] + 9.81) / n3};
+        const double c2[3] = {0.0, b3[2], -b3[1]};  // b3 x (1,0,0)
+        const double n2 = sqrt(c2[1] * c2[1] + c2[2] * c2[2]);
+        const double b2[3] = {0.0, c2[1] / n2, c2[2] / n2};
+        const double c1[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
+        const double n1 = sqrt(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+        const double b1[3] = {c1[0] / n1, c1[1] / n1, c1[2] / n1};
+        const double rad = a.robot_r + 1e-1, rad2 = rad * rad;
+        const double ir = 1.0 / a.robot_r, ih = 1.0 / a.robot_h;
+        int lo_c[3], hi_c[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            lo_c[ax] = grid_coord(a.grid, p[ax] - rad, ax);
+            hi_c[ax] = grid_coord(a.grid, p[ax] + rad, ax);
+        }
+        bool hit = false;
+        for (int cz = lo_c[2]; cz <= hi_c[2] && !hit; ++cz)
+            for (int cy = lo_c[1]; cy <= hi_c[1] && !hit; ++cy) {
+                // the cells of one x-row are consecutive: one contiguous range of sorted points
+                const int row = (cz * a.grid.dim[1] + cy) * a.grid.dim[0];
+                const int beg = a.grid.cell_start[row + lo_c[0]], end = a.grid.cell_start[row + hi_c[0] + 1];
+                for (int i = beg; i < end; ++i) {
+                    const double dx = a.grid.pts[(size_t)i * 3] - p[0], dy = a.grid.pts[(size_t)i * 3 + 1] - p[1],
+                                 dz = a.grid.pts[(size_t)i * 3 + 2] - p[2];
+                    if (dx * dx + dy * dy + dz * dz <= rad2) {  // the reference's radius search (r + 0.1)
+                        const double e1 = (b1[0] * dx + b1[1] * dy + b1[2] * dz) * ir;
+                        const double e2 = (b2[0] * dx + b2[1] * dy + b2[2] * dz) * ir;
+                        const double e3 = (b3[0] * dx + b3[1] * dy + b3[2] * dz) * ih;
+                        if (e1 * e1 + e2 * e2 + e3 * e3 <= 1.0) { hit = true; break; }  // |E^-1 d| <= 1
+                    }
+                }
+            }
+        if (a.flags) a.flags[g] = hit ? 1 : 0;
+        if (hit) atomicMin(&a.first_hit[b], s);
+    }
+}
+
+}  // namespace uavqp

@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "../../include/uavqp.h"
 #include "qp_device.h"
@@ -494,132 +496,6 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(EllipsoidArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Corridor boxes from an obstacle cloud: one lane per waypoint row, the cloud streamed through LDS tiles.
-// The ellipsoid metric is evaluated as d' Q d with Q = sum_j b_j b_j' / s_j^2 (6 unique entries in registers):
-// 12 FP64 operations and one 24-byte LDS broadcast read per (row, obstacle) pair, no early exit (it is a min).
-// ---------------------------------------------------------------------------------------------------
-struct CloudCorridorArgs {
-    int n_traj, uniform, n_rows, n_obs;
-    const int32_t* seg_offsets;
-    const double* waypoints;
-    const double* times;
-    const double* coeff;
-    const double* obs;
-    double robot_r, robot_h, h_max;
-    double* lo;
-    double* hi;
-    double* clearance;
-};
-
-template <int R>
-__global__ __launch_bounds__(256) void cloud_corridor_kernel(CloudCorridorArgs a) {
-    constexpr int NC = 2 * R, TILE = 1024;
-    __shared__ double s_obs[TILE * 3];
-    const long long n_round = ((long long)a.n_rows + 255) / 256 * 256;  // every thread of a block joins the LDS tile loads
-    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n_round; g += (long long)gridDim.x * 256) {
-        const bool live = g < a.n_rows;
-        double p[3] = {0, 0, 0};
-        double qxx = 0, qyy = 0, qzz = 0, qxy2 = 0, qxz2 = 0, qyz2 = 0;
-        bool interior = false;
-        if (live) {
-            int b, k, M, s0;
-            if (a.uniform > 0) {
-                M = a.uniform;
-                b = (int)(g / (M + 1));
-                k = (int)(g - (long long)b * (M + 1));
-                s0 = b * M;
-            } else {
-                // row g belongs to the trajectory b with seg_offsets[b] + b <= g < seg_offsets[b+1] + b + 1
-                int lo_b = 0, hi_b = a.n_traj - 1;
-                while (lo_b < hi_b) {
-                    const int mid = (lo_b + hi_b + 1) >> 1;
-                    if ((long long)a.seg_offsets[mid] + mid <= g) lo_b = mid; else hi_b = mid - 1;
-                }
-                b = lo_b;
-                s0 = a.seg_offsets[b];
-                M = a.seg_offsets[b + 1] - s0;
-                k = (int)(g - ((long long)s0 + b));
-            }
-            interior = (k > 0) && (k < M);
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) p[ax] = a.waypoints[(size_t)g * 3 + ax];
-            double acc[3] = {0.0, 0.0, 0.0};
-            if (a.coeff) {
-                // acceleration at the knot: start of segment k (2 c_2), or the end of the last segment for k = M
-                const int seg = k < M ? k : M - 1;
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    const double* ca = a.coeff + (size_t)3 * NC * s0 + ((size_t)ax * M + seg) * NC;
-                    if (k < M) {
-                        acc[ax] = 2.0 * ca[2];
-                    } else {
-                        const double t = a.times[s0 + seg];
-                        double av = 0.0;
-#pragma unroll
-                        for (int j = NC - 1; j >= 2; --j) av = fma(av, t, (double)(j * (j - 1)) * ca[j]);
-                        acc[ax] = av;
-                    }
-                }
-            }
-            // kino_astar.cpp:724-727
-            const double n3 = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + (acc[2] + 9.81) * (acc[2] + 9.81));
-            const double b3[3] = {acc[0] / n3, acc[1] / n3, (acc[2] + 9.81) / n3};
-            const double c2y = b3[2], c2z = -b3[1];  // b3 x (1,0,0) = (0, b3z, -b3y)
-            const double n2 = sqrt(c2y * c2y + c2z * c2z);
-            const double b2[3] = {0.0, c2y / n2, c2z / n2};
-            double b1[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
-            const double n1 = sqrt(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
-            b1[0] /= n1; b1[1] /= n1; b1[2] /= n1;
-            const double wr = 1.0 / (a.robot_r * a.robot_r), wh = 1.0 / (a.robot_h * a.robot_h);
-            qxx = (b1[0] * b1[0] + b2[0] * b2[0]) * wr + b3[0] * b3[0] * wh;
-            qyy = (b1[1] * b1[1] + b2[1] * b2[1]) * wr + b3[1] * b3[1] * wh;
-            qzz = (b1[2] * b1[2] + b2[2] * b2[2]) * wr + b3[2] * b3[2] * wh;
-            qxy2 = 2.0 * ((b1[0] * b1[1] + b2[0] * b2[1]) * wr + b3[0] * b3[1] * wh);
-            qxz2 = 2.0 * ((b1[0] * b1[2] + b2[0] * b2[2]) * wr + b3[0] * b3[2] * wh);
-            qyz2 = 2.0 * ((b1[1] * b1[2] + b2[1] * b2[2]) * wr + b3[1] * b3[2] * wh);
-        }
-        double m0 = INFINITY, m1 = INFINITY;  // two independent min chains
-        for (int o0 = 0; o0 < a.n_obs; o0 += TILE) {
-            const int nt = min(TILE, a.n_obs - o0);
-            __syncthreads();
-            for (int i = threadIdx.x; i < nt * 3; i += 256) s_obs[i] = a.obs[(size_t)o0 * 3 + i];
-            __syncthreads();
-            if (live) {
-                int i = 0;
-                for (; i + 1 < nt; i += 2) {
-                    const double dx = s_obs[3 * i] - p[0], dy = s_obs[3 * i + 1] - p[1], dz = s_obs[3 * i + 2] - p[2];
-                    const double ex = s_obs[3 * i + 3] - p[0], ey = s_obs[3 * i + 4] - p[1], ez = s_obs[3 * i + 5] - p[2];
-                    const double t0 = dx * (qxx * dx + qxy2 * dy + qxz2 * dz) + dy * (qyy * dy + qyz2 * dz) + qzz * dz * dz;
-                    const double t1 = ex * (qxx * ex + qxy2 * ey + qxz2 * ez) + ey * (qyy * ey + qyz2 * ez) + qzz * ez * ez;
-                    m0 = fmin(m0, t0);
-                    m1 = fmin(m1, t1);
-                }
-                if (i < nt) {
-                    const double dx = s_obs[3 * i] - p[0], dy = s_obs[3 * i + 1] - p[1], dz = s_obs[3 * i + 2] - p[2];
-                    m0 = fmin(m0, dx * (qxx * dx + qxy2 * dy + qxz2 * dz) + dy * (qyy * dy + qyz2 * dz) + qzz * dz * dz);
-                }
-            }
-        }
-        if (live) {
-            const double gmin = sqrt(fmax(fmin(m0, m1), 0.0));
-            if (a.clearance) a.clearance[g] = gmin;
-            const double margin = gmin > 1.0 ? gmin - 1.0 : 0.0;
-            const double q[3] = {qxx, qyy, qzz};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                double h = 0.0;
-                if (interior) {
-                    h = margin / (3.0 * sqrt(q[ax]));
-                    h = h < a.h_max ? h : a.h_max;  // also maps margin = inf (empty cloud) to h_max
-                }
-                a.lo[(size_t)g * 3 + ax] = p[ax] - h;
-                a.hi[(size_t)g * 3 + ax] = p[ax] + h;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Time re-allocation: one lane per segment; peak |v|, |a| by sampling, stretch-only update of T.
 // ---------------------------------------------------------------------------------------------------
 struct ReallocArgs {
@@ -679,6 +555,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 #include "qp_twisted.h"
 #include "qp_phased.h"
 #include "qp_corridor.h"
+#include "obstacle_grid.h"
 
 namespace uavqp {
 // Specialised (R, M) instantiations of the register-resident kernel; everything else takes the generic one.
@@ -1244,6 +1121,151 @@ extern "C" int uavqp_ellipsoid_check_device(uavqp_ctx* ctx, int r, int n_traj, i
         hipLaunchKernelGGL(uavqp::ellipsoid_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL(uavqp::ellipsoid_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+    UAVQP_HIP(hipGetLastError());
+    return UAVQP_OK;
+}
+
+// ---- obstacle grid (uniform cells over the cloud) + grid-accelerated ellipsoid check ------------------------------
+struct uavqp_grid {
+    int device = 0;
+    int n_obs = 0;
+    uavqp::GridView view{};
+    int32_t* d_cell_start = nullptr;
+    double* d_pts = nullptr;
+};
+
+extern "C" int uavqp_obstacle_grid_destroy(uavqp_ctx* ctx, uavqp_grid* grid) {
+    if (!grid) return UAVQP_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(grid->device);
+    if (grid->d_cell_start) (void)hipFree(grid->d_cell_start);
+    if (grid->d_pts) (void)hipFree(grid->d_pts);
+    delete grid;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_obstacle_grid_build_device(uavqp_ctx* ctx, const double* d_obstacles, int n_obs, double cell_size,
+                                                uavqp_grid** out_grid) {
+    if (!ctx || !out_grid || n_obs < 0 || (n_obs > 0 && !d_obstacles) || !(cell_size > 0.0) || !(cell_size < INFINITY))
+        return UAVQP_ERR_INVALID_ARG;
+    *out_grid = nullptr;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    uavqp_grid* g = new (std::nothrow) uavqp_grid();
+    if (!g) return UAVQP_ERR_ALLOC;
+    g->device = ctx->device;
+    g->n_obs = n_obs;
+    hipStream_t s = ctx->stream;
+    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    int rc = UAVQP_OK;
+    double* d_part = nullptr;
+    int32_t* d_cell_of = nullptr;
+    int32_t* d_cursor = nullptr;
+    std::vector<int32_t> h_counts;
+#define UAVQP_GRID_HIP(expr)                                                                     \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                    \
+            rc = UAVQP_ERR_HIP;                                                                  \
+            goto fail;                                                                           \
+        }                                                                                        \
+    } while (0)
+    {
+        if (n_obs > 0) {
+            const int nb = std::min(256, (n_obs + 255) / 256);
+            UAVQP_GRID_HIP(hipMalloc((void**)&d_part, sizeof(double) * 6 * nb));
+            hipLaunchKernelGGL(uavqp::grid_bounds_kernel, dim3(nb), dim3(256), 0, s, d_obstacles, n_obs, d_part);
+            std::vector<double> part(6 * (size_t)nb);
+            UAVQP_GRID_HIP(hipMemcpyAsync(part.data(), d_part, sizeof(double) * 6 * nb, hipMemcpyDeviceToHost, s));
+            UAVQP_GRID_HIP(hipStreamSynchronize(s));
+            for (int ax = 0; ax < 3; ++ax) { mn[ax] = INFINITY; mx[ax] = -INFINITY; }
+            for (int b = 0; b < nb; ++b)
+                for (int ax = 0; ax < 3; ++ax) {
+                    mn[ax] = std::fmin(mn[ax], part[6 * b + ax]);
+                    mx[ax] = std::fmax(mx[ax], part[6 * b + 3 + ax]);
+                }
+            for (int ax = 0; ax < 3; ++ax)
+                if (!(mn[ax] > -INFINITY) || !(mx[ax] < INFINITY) || mn[ax] != mn[ax]) {
+                    g_last_error = "obstacle cloud contains non-finite coordinates";
+                    rc = UAVQP_ERR_INVALID_ARG;
+                    goto fail;
+                }
+        }
+        // cells: at most 2^22; a cloud too large for the requested cell size gets proportionally larger cells
+        double cell = cell_size;
+        long long dims[3];
+        for (;;) {
+            long long n = 1;
+            for (int ax = 0; ax < 3; ++ax) {
+                dims[ax] = (long long)std::floor((mx[ax] - mn[ax]) / cell) + 1;
+                n *= dims[ax];
+            }
+            if (n <= (1ll << 22)) break;
+            cell *= 2.0;
+        }
+        const int ncell = (int)(dims[0] * dims[1] * dims[2]);
+        for (int ax = 0; ax < 3; ++ax) { g->view.org[ax] = mn[ax]; g->view.dim[ax] = (int)dims[ax]; }
+        g->view.inv_cell = 1.0 / cell;
+        UAVQP_GRID_HIP(hipMalloc((void**)&g->d_cell_start, sizeof(int32_t) * (size_t)(ncell + 1)));
+        UAVQP_GRID_HIP(hipMalloc((void**)&g->d_pts, sizeof(double) * 3 * (size_t)(n_obs > 0 ? n_obs : 1)));
+        UAVQP_GRID_HIP(hipMemsetAsync(g->d_cell_start, 0, sizeof(int32_t) * (size_t)(ncell + 1), s));
+        if (n_obs > 0) {
+            UAVQP_GRID_HIP(hipMalloc((void**)&d_cell_of, sizeof(int32_t) * (size_t)n_obs));
+            UAVQP_GRID_HIP(hipMalloc((void**)&d_cursor, sizeof(int32_t) * (size_t)(ncell + 1)));
+            // counts land in cell_start[c + 1] so that the host prefix leaves an exclusive scan in place
+            hipLaunchKernelGGL(uavqp::grid_count_kernel, dim3((n_obs + 255) / 256), dim3(256), 0, s, g->view, d_obstacles, n_obs,
+                               d_cell_of, g->d_cell_start + 1);
+            h_counts.resize((size_t)ncell + 1);
+            UAVQP_GRID_HIP(hipMemcpyAsync(h_counts.data(), g->d_cell_start, sizeof(int32_t) * (size_t)(ncell + 1), hipMemcpyDeviceToHost, s));
+            UAVQP_GRID_HIP(hipStreamSynchronize(s));
+            for (int c = 0; c < ncell; ++c) h_counts[c + 1] += h_counts[c];
+            UAVQP_GRID_HIP(hipMemcpyAsync(g->d_cell_start, h_counts.data(), sizeof(int32_t) * (size_t)(ncell + 1), hipMemcpyHostToDevice, s));
+            UAVQP_GRID_HIP(hipMemcpyAsync(d_cursor, h_counts.data(), sizeof(int32_t) * (size_t)(ncell + 1), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(uavqp::grid_scatter_kernel, dim3((n_obs + 255) / 256), dim3(256), 0, s, d_obstacles, n_obs, d_cell_of,
+                               d_cursor, g->d_pts);
+            UAVQP_GRID_HIP(hipGetLastError());
+            UAVQP_GRID_HIP(hipStreamSynchronize(s));
+        }
+        g->view.cell_start = g->d_cell_start;
+        g->view.pts = g->d_pts;
+    }
+    if (d_part) (void)hipFree(d_part);
+    if (d_cell_of) (void)hipFree(d_cell_of);
+    if (d_cursor) (void)hipFree(d_cursor);
+    *out_grid = g;
+    return UAVQP_OK;
+fail:
+    if (d_part) (void)hipFree(d_part);
+    if (d_cell_of) (void)hipFree(d_cell_of);
+    if (d_cursor) (void)hipFree(d_cursor);
+    (void)uavqp_obstacle_grid_destroy(nullptr, g);
+    return rc;
+#undef UAVQP_GRID_HIP
+}
+
+extern "C" int uavqp_ellipsoid_check_grid_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                                 const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
+                                                 const uavqp_grid* grid, double robot_r, double robot_h, int32_t* d_first_hit,
+                                                 uint8_t* d_flags) {
+    if (!ctx || !grid || (r != 3 && r != 4) || n_traj < 0 || n_samples < 0 || uniform_segments < 0 || !(robot_r > 0.0) || !(robot_h > 0.0))
+        return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!d_times || !d_coeff || !d_first_hit || (uniform_segments == 0 && !d_seg_offsets) || grid->device != ctx->device)
+        return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_first_hit, n_traj, (int32_t)n_samples);
+    if (n_samples == 0) return UAVQP_OK;
+    uavqp::EllipsoidGridArgs a;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.n_samples = n_samples;
+    a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.grid = grid->view;
+    a.t0 = t0; a.dt = dt; a.robot_r = robot_r; a.robot_h = robot_h; a.first_hit = d_first_hit; a.flags = d_flags;
+    const long long total = (long long)n_traj * n_samples;
+    long long grid_dim = (total + 255) / 256;
+    if (grid_dim > (long long)ctx->num_cus * 32) grid_dim = (long long)ctx->num_cus * 32;
+    if (r == 3)
+        hipLaunchKernelGGL(uavqp::ellipsoid_grid_kernel<3>, dim3((unsigned)grid_dim), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(uavqp::ellipsoid_grid_kernel<4>, dim3((unsigned)grid_dim), dim3(256), 0, ctx->stream, a);
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }

@@ -111,6 +111,27 @@ class Context:
                                                          p(clearance))
         _lib.check(rc, "uavqp_corridor_from_cloud_device")
 
+    def obstacle_grid_build(self, obstacles, n_obs, cell_size):
+        """Uniform grid over a device point cloud; returns an opaque handle (free it with obstacle_grid_destroy)."""
+        h = ctypes.c_void_p()
+        rc = _lib.lib().uavqp_obstacle_grid_build_device(self._h, obstacles if isinstance(obstacles, int) or obstacles is None else _ptr(obstacles),
+                                                         int(n_obs), float(cell_size), ctypes.byref(h))
+        _lib.check(rc, "uavqp_obstacle_grid_build_device")
+        return h
+
+    def obstacle_grid_destroy(self, grid):
+        _lib.check(_lib.lib().uavqp_obstacle_grid_destroy(self._h, grid), "uavqp_obstacle_grid_destroy")
+
+    def ellipsoid_check_grid_device(self, r, n_traj, uniform_segments, seg_offsets, times, coeff, n_samples, t0, dt,
+                                    grid, robot_r, robot_h, first_hit, flags=None):
+        """ellipsoid_check_device with the candidates taken from an obstacle grid (identical flags, no exhaustive scan)."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_ellipsoid_check_grid_device(self._h, r, n_traj, uniform_segments, p(seg_offsets), p(times), p(coeff),
+                                                          n_samples, float(t0), float(dt), grid, float(robot_r), float(robot_h),
+                                                          p(first_hit), p(flags))
+        _lib.check(rc, "uavqp_ellipsoid_check_grid_device")
+
     def capture_begin(self):
         """Start hipGraph capture of everything subsequently enqueued on the ctx stream."""
         _lib.check(_lib.lib().uavqp_capture_begin(self._h), "uavqp_capture_begin")
