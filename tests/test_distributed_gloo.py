@@ -35,7 +35,13 @@ def _worker(rank, world, port, ragged, q):
                                         loc["bc"].reshape(-1, 2, r - 1, 3))
     full = D.allgather_coeffs(torch.from_numpy(coef), numels)
     ref, _ = oracle.solve_exact_batch(r, so, np.asarray(batch["waypoints"]).reshape(-1, 3), np.asarray(batch["times"]).reshape(-1), batch["bc"])
-    q.put((rank, bool(np.array_equal(full.numpy(), ref))))
+    ok = bool(np.array_equal(full.numpy(), ref))
+    # the same step through the one-call helper (shard by segment count -> solve -> all-gather coefficients + statuses)
+    batch = dict(batch, r=r)
+    full2, status2 = D.solve_sharded(batch, lambda sh: oracle.solve_exact_batch(r, sh["seg_offsets"], sh["waypoints"], sh["times"],
+                                                                                sh["bc"].reshape(-1, 2, r - 1, 3)))
+    ok = ok and bool(np.array_equal(full2.numpy(), ref)) and status2.numel() == so.size - 1 and bool((status2 == 0).all())  # oracle: 0 = ok
+    q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -64,3 +64,29 @@ def allgather_coeffs(local_coeff, shard_numels, group=None):
     full = torch.empty(world * mx, dtype=local_coeff.dtype, device=local_coeff.device)
     dist.all_gather_into_tensor(full, padded, group=group)
     return torch.cat([full[g * mx:g * mx + shard_numels[g]] for g in range(world)])
+
+
+def solve_sharded(batch, solve_local, group=None, device=None):
+    """The whole multi-GPU step of SURVEY.md section 8-e on every rank: cut this rank's contiguous shard out of the
+    batch (balanced by segment count), solve it, all-gather coefficients and statuses.
+
+    batch        workloads.py layout (seg_offsets, waypoints, times, bc, r), identical on every rank
+    solve_local  callable(shard) -> (coeff float64 [3*2r*segments of the shard], status int32 [trajectories of the shard]);
+                 on a GPU rank:  lambda s: ctx.solve_batch_host(s["r"], s["seg_offsets"], s["waypoints"], s["times"],
+                                                                 s["bc"].reshape(-1, 2, s["r"] - 1, 3))
+    device       torch device of the gathered tensors (cuda:<local rank> for nccl = RCCL, cpu for gloo)
+    Returns (coeff, status) for the WHOLE batch in batch order, as torch tensors on `device`."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    r = int(batch["r"])
+    so = np.asarray(batch["seg_offsets"], dtype=np.int64)
+    bounds = shard_bounds_ragged(so, world)
+    shard = local_slice(batch, bounds[rank], bounds[rank + 1])
+    coef, st = solve_local(shard)
+    dev = torch.device("cpu") if device is None else device
+    numels = [3 * 2 * r * int(so[bounds[g + 1]] - so[bounds[g]]) for g in range(world)]
+    counts = [bounds[g + 1] - bounds[g] for g in range(world)]
+    full = allgather_coeffs(torch.as_tensor(np.ascontiguousarray(coef), dtype=torch.float64).to(dev), numels, group)
+    status = allgather_coeffs(torch.as_tensor(np.ascontiguousarray(st), dtype=torch.int32).to(dev), counts, group)
+    return full, status
