@@ -509,15 +509,25 @@ struct ReallocArgs {
 
 template <int R>
 __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
-    // One lane per trajectory: the whole trajectory is scaled by ONE factor.  (Stretching single segments
-    // diverges: a long segment next to short ones inherits their knot acceleration and overshoots more the
-    // longer it gets; under uniform scaling T -> sT speeds drop ~1/s and accelerations ~1/s^2.)
-    constexpr int NC = 2 * R;
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.n_traj; b += gridDim.x * blockDim.x) {
-        int s0, M;
-        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+    // The whole trajectory is scaled by ONE factor.  (Stretching single segments diverges: a long segment next to short
+    // ones inherits their knot acceleration and overshoots more the longer it gets; under uniform scaling T -> sT speeds
+    // drop ~1/s and accelerations ~1/s^2.)  Eight lanes per trajectory: sub-lane j samples segments j, j + 8, ..., the
+    // peaks are combined with three xor-shuffles (max is order-independent: same result as a single lane), every lane
+    // then scales its own segments.
+    constexpr int NC = 2 * R, LPT = 8;
+    const int sub = threadIdx.x % LPT;
+    const long long n_lanes = (long long)a.n_traj * LPT;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n_round = (n_lanes + stride - 1) / stride * stride;  // whole waves take part in the shuffles
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n_round; g += stride) {
+        const bool live = g < n_lanes;
+        const int b = live ? (int)(g / LPT) : 0;
+        int s0 = 0, M = 0;
+        if (live) {
+            if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        }
         double v2 = 0.0, a2 = 0.0;
-        for (int i = 0; i < M; ++i) {
+        for (int i = sub; i < M; i += LPT) {
             const double T = a.times[s0 + i];
             const double* __restrict__ c = a.coeff + (size_t)3 * NC * s0 + (size_t)i * NC;
             for (int s = 0; s <= a.samples; ++s) {
@@ -538,15 +548,21 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
                 a2 = fmax(a2, as);
             }
         }
+#pragma unroll
+        for (int d = 1; d < LPT; d <<= 1) {
+            v2 = fmax(v2, __shfl_xor(v2, d, 64));
+            a2 = fmax(a2, __shfl_xor(a2, d, 64));
+        }
+        if (!live) continue;
         const double ratio = fmax(sqrt(v2) / a.v_max, sqrt(sqrt(a2) / a.a_max));
         int ch = 0;
         // 1 % dead band and 2 % overshoot so that the loop settles instead of creeping towards the limit
         if (ratio > 1.01 && ratio < INFINITY) {
             const double s = fmin(1.02 * ratio, a.max_stretch);
-            for (int i = 0; i < M; ++i) a.times[s0 + i] *= s;
+            for (int i = sub; i < M; i += LPT) a.times[s0 + i] *= s;
             ch = M;
         }
-        if (a.changed) a.changed[b] = ch;
+        if (a.changed && sub == 0) a.changed[b] = ch;
     }
 }
 
@@ -1088,8 +1104,9 @@ extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, i
     a.n_traj = n_traj; a.uniform = uniform_segments; a.samples = samples_per_seg;
     a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.v_max = v_max; a.a_max = a_max;
     a.max_stretch = max_stretch; a.changed = d_changed_out;
-    int grid = (n_traj + 63) / 64;
-    if (grid > ctx->num_cus * 16) grid = ctx->num_cus * 16;
+    long long grid_ll = ((long long)n_traj * 8 + 63) / 64;  // 8 lanes per trajectory
+    if (grid_ll > (long long)ctx->num_cus * 32) grid_ll = (long long)ctx->num_cus * 32;
+    const int grid = (int)grid_ll;
     if (r == 3)
         hipLaunchKernelGGL(uavqp::realloc_kernel<3>, dim3(grid), dim3(64), 0, ctx->stream, a);
     else
