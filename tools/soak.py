@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Randomised soak of the equality and corridor solves against the CPU oracle (test infrastructure, like tests/):
+python tools/soak.py [n_draws] [seed].  Every draw: random (r, uniform|ragged, M, batch size up to 3000, time allocation,
+kernel variant, lane layout / dealing knobs); equality results vs the binary128 KKT oracle (1e-7 relative per trajectory),
+corridor results vs the KKT certificate built from the reference-formulation matrices.  Exit code 1 on the first failure."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import uav_motion_planning_amd as U  # noqa: E402
+from uav_motion_planning_amd import workloads as W  # noqa: E402
+from oracle import oracle  # noqa: E402
+from test_gpu_corridor import kkt_certificate  # noqa: E402
+
+
+def main():
+    n_draws = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    ctx = U.Context(0)
+    worst_eq = worst_stat = 0.0
+    for draw in range(n_draws):
+        r = int(rng.choice([3, 4]))
+        ragged = bool(rng.integers(0, 2))
+        n = int(rng.choice([rng.integers(1, 70), rng.integers(70, 600), rng.integers(2048, 3000)], p=[0.6, 0.3, 0.1]))
+        for k, v in (("UAVQP_GENERIC_NAX", rng.choice(["", "1", "3"])), ("UAVQP_NO_LSORT", rng.choice(["", "1"]))):
+            if v:
+                os.environ[k] = str(v)
+            else:
+                os.environ.pop(k, None)
+        if ragged:
+            b = W.ragged_batch(draw, n, r, m_lo=1, m_hi=int(rng.integers(2, 26)), seed=seed * 100000 + draw)
+            b["times"] = b["times"] * rng.uniform(0.5, 3.0, size=b["times"].shape)
+            so, uni = b["seg_offsets"], 0
+            got, st = ctx.solve_batch_host(r, so, b["waypoints"], b["times"], b["bc"])
+        else:
+            M = int(rng.integers(1, 26))
+            b = W.uniform_batch(draw, n, M, r, time_mode=str(rng.choice(["reference", "distance", "wide"])), seed=seed * 100000 + draw)
+            b["bc"] = rng.uniform(-2.0, 2.0, size=b["bc"].shape)
+            so, uni = b["seg_offsets"], M
+            spec = (2 <= M <= 12 and M != 11) if r == 4 else (M in (2, 3, 4, 5, 6, 7, 8, 10, 12, 16))
+            ctx.set_variant(int(rng.choice([0, 1, 2, 8, 16, 32])) if spec else int(rng.choice([0, 1])))
+            got, st = ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+            ctx.set_variant(0)
+        wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+        T = np.asarray(b["times"]).reshape(-1)
+        sub = np.unique(rng.integers(0, n, size=min(n, 40)))          # the oracle is slow: a sample of the batch
+        assert np.all(st == U.UAVQP_SOLVED), ("status", draw, np.unique(st))
+        for k in sub:
+            s0, s1 = int(so[k]), int(so[k + 1])
+            ref, _ = oracle.solve_exact_batch(r, np.array([0, s1 - s0], dtype=np.int32), wp[s0 + k:s1 + k + 1], T[s0:s1], b["bc"][k:k + 1])
+            g = got[3 * 2 * r * s0:3 * 2 * r * s1]
+            err = np.max(np.abs(g - ref)) / np.max(np.abs(ref))
+            worst_eq = max(worst_eq, err)
+            if not err < 1e-7:
+                print("EQUALITY FAILURE draw", draw, dict(r=r, ragged=ragged, n=n, k=int(k), M=s1 - s0, err=err), dict(os.environ))
+                return 1
+        # corridor on the same batch (boxes of random width, a few degenerate)
+        if n <= 600 and np.all(np.diff(so) <= 63):
+            h = 10.0 ** rng.uniform(-2.5, 0, size=wp.shape)
+            h[rng.random(size=wp.shape) < 0.1] = 0.0
+            lo, hi = wp - h, wp + h
+            gc, stc, itc = ctx.solve_corridor_batch_host(r, so if not uni else None, b["waypoints"], b["times"], b["bc"], lo, hi, uniform_segments=uni)
+            assert np.all(stc == U.UAVQP_SOLVED), ("corridor status", draw, np.unique(stc))
+            for k in sub[:8]:
+                s0, s1 = int(so[k]), int(so[k + 1])
+                M = s1 - s0
+                if M < 2:
+                    continue
+                c = gc[3 * 2 * r * s0:3 * 2 * r * s1].reshape(3, -1)
+                for ax in range(3):
+                    prim, stat, comp = kkt_certificate(oracle, r, M, T[s0:s1], c[ax], wp[s0 + k:s1 + k + 1, ax], b["bc"][k, 0, :, ax],
+                                                       b["bc"][k, 1, :, ax], lo[s0 + k + 1:s1 + k, ax], hi[s0 + k + 1:s1 + k, ax])
+                    worst_stat = max(worst_stat, stat)
+                    if not (prim < 1e-9 and stat < 1e-5 and comp < 1e-4):
+                        print("CORRIDOR FAILURE draw", draw, dict(r=r, ragged=ragged, n=n, k=int(k), M=M, ax=ax, prim=prim, stat=stat, comp=comp))
+                        return 1
+    print("soak ok: %d draws, seed %d, worst equality rel err %.2e, worst corridor stationarity %.2e" % (n_draws, seed, worst_eq, worst_stat))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
