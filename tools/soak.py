@@ -78,6 +78,14 @@ def main():
                     worst_stat = max(worst_stat, stat)
                     if not (prim < 1e-9 and stat < 1e-5 and comp < 1e-4):
                         print("CORRIDOR FAILURE draw", draw, dict(r=r, ragged=ragged, n=n, k=int(k), M=M, ax=ax, prim=prim, stat=stat, comp=comp))
+                        P_, A_ = oracle.assemble(r, T[s0:s1])
+                        nu = np.linalg.lstsq(A_.T, -(P_ @ c[ax]), rcond=None)[0]
+                        rows = [r + (r + 1) * i for i in range(M - 1)]
+                        Ax = A_ @ c[ax]
+                        print("  iterations", int(itc[k]), " max|nu|", np.abs(nu).max(), " T", T[s0:s1])
+                        for i, row in enumerate(rows):
+                            l_, h_ = lo[s0 + k + 1 + i, ax], hi[s0 + k + 1 + i, ax]
+                            print("  knot %2d  width %.3e  p-lo %.3e  hi-p %.3e  nu %.6e" % (i + 1, h_ - l_, Ax[row] - l_, h_ - Ax[row], nu[row]))
                         return 1
     print("soak ok: %d draws, seed %d, worst equality rel err %.2e, worst corridor stationarity %.2e" % (n_draws, seed, worst_eq, worst_stat))
     return 0
