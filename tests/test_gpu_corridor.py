@@ -261,7 +261,7 @@ def test_mid_segment_samples_by_knot_insertion(gpu_ctx, oracle):
             assert prim < 1e-9 and stat < 1e-7 and comp < 1e-6
 
 
-@pytest.mark.parametrize("r,M", [(3, 10), (4, 6)])
+@pytest.mark.parametrize("r,M", [(3, 10), (4, 6), (4, 22), (3, 30)])
 def test_corridor_stress_time_allocation_and_tiny_boxes(gpu_ctx, oracle, r, M):
     """Stress: durations in [0.2, 5] s (block entries spanning T^-7..T^-1) and boxes from 1 mm to 1 m, some degenerate.
     Every result must be feasible and pass the optimality certificate of the reference-formulation matrices
