@@ -147,12 +147,23 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # UAVQP_BENCH_BACKEND=gloo is a self-test aid: it lets several ranks share ONE GPU (RCCL refuses that) so that the
+        # rank bookkeeping of this script can be exercised on a single-GPU box; collectives then run on CPU tensors.
+        backend = os.environ.get("UAVQP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    else:
+        backend = None
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the uavqp product path has no CPU fallback")
+    if backend not in (None, "nccl"):
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend in (None, "nccl") else torch.device("cpu")
 
     r, M, B = args.order, args.segments, args.batch
     batch = W.uniform_batch(2, B, M, r, time_mode=args.time_mode, seed=W.SEED0 + 2 + 1000 * rank)
@@ -236,7 +247,7 @@ def main():
     # average time one launch occupies its stream (kernel + boundary), from the events of the timed region
     region_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) / per_slot[k] for k in range(S) if per_slot[k] > 0]))
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert int((d_st == U.UAVQP_SOLVED).sum().item()) == B, "some trajectories were not solved"
@@ -256,17 +267,18 @@ def main():
     gather = None
     if use_dist and not args.no_allgather:
         # RCCL all-gather of the solved coefficient shards over xGMI (equal shards)
-        full = torch.empty(world * d_out.numel(), dtype=torch.float64, device=dev)
+        g_src = d_out if coll_dev == dev else d_out.cpu()   # (gloo self-test: CPU tensors)
+        full = torch.empty(world * d_out.numel(), dtype=torch.float64, device=coll_dev)
         for _ in range(3):
-            dist.all_gather_into_tensor(full, d_out)
+            dist.all_gather_into_tensor(full, g_src)
         fence()
         g0 = time.perf_counter()
         n_g = 10
         for _ in range(n_g):
-            dist.all_gather_into_tensor(full, d_out)
+            dist.all_gather_into_tensor(full, g_src)
         fence()
         g_ms = (time.perf_counter() - g0) / n_g * 1e3
-        ok = bool(torch.equal(full[rank * d_out.numel():(rank + 1) * d_out.numel()], d_out))
+        ok = bool(torch.equal(full[rank * d_out.numel():(rank + 1) * d_out.numel()], g_src))
         gather = {"ms": g_ms, "bytes_per_rank_out": d_out.numel() * 8, "bytes_total": full.numel() * 8,
                   "own_shard_intact": ok,
                   "value_with_gather": world * B / (dt / args.steps + g_ms * 1e-3)}
