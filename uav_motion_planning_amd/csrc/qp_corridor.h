@@ -11,7 +11,9 @@
 // formulation converges to the same point, which is how the tests check it).
 //
 // One lane per (trajectory, axis): the active sets differ per axis, so the factorisation is not shared.
-// Sweep state lives in a lane-interleaved HBM workspace (any segment count, ragged batches).
+// Sweep state lives in an HBM workspace laid out [wave][knot][field][lane] (any segment count up to 63, ragged batches);
+// uniform batches keep the records of their last knots in LDS.  Checked against exact-rational fixtures including the
+// active sets (tests/test_corridor_golden.py), the OSQP-faithful port and a KKT certificate (tests/test_gpu_corridor.py).
 #pragma once
 #include "qp_device.h"
 
