@@ -1,0 +1,50 @@
+"""CPU: the bench.py contract, checked on the committed round-1 bench line (profiles/r01_bench4096.json -- produced by
+`python bench.py` on the MI355X box) and on the script's defaults.  No GPU, no oracle."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_every_contract_key():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench4096.json")))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert "trajectories" in d["unit"] and "trajectories/sec" in d["metric"]
+    assert str(base.get("metric", "")).lower().startswith("trajectories/sec") or "trajector" in json.dumps(base).lower()
+    assert abs(d["value"] - d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["algorithmic_bytes_per_launch"] == 4096 * 1960            # SURVEY.md section 8-d figure x units per launch
+    assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.5 * r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == d["unit"]
+
+
+def test_rocprof_summary_agrees_with_the_bench_line():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench4096.json")))
+    txt = open(os.path.join(ROOT, "profiles", "r01_bench4096_kernel_stats.csv")).read()
+    m = re.search(r'"void uavqp::solve_twisted_kernel<4, 8, 8, 8>\(uavqp::BatchArgs\)",(\d+),(\d+),([\d.]+)', txt)
+    assert m, "headline kernel missing from the rocprofv3 --stats summary"
+    avg_us = float(m.group(3)) / 1e3
+    assert abs(avg_us - d["roofline"]["kernel_ms"] * 1e3) < 0.05 * avg_us      # same kernel, same command: within 5 %
+
+
+def test_bench_defaults_follow_the_contract():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert re.search(r'"--gpus", type=int, default=1', src)
+    assert re.search(r'"--steps", type=int, default=\d+', src) and re.search(r'"--warmup", type=int, default=\d+', src)
+    assert re.search(r'"--batch", type=int, default=4096', src) and re.search(r'"--segments", type=int, default=8', src)
+    assert re.search(r'"--order", type=int, default=4', src)
+    assert "oracle" not in re.sub(r"def cpu_baseline.*?\n\n\n", "", src, flags=re.S).replace("oracle/osqp_port.c", "")  # oracle only in cpu_baseline
