@@ -216,3 +216,43 @@ def corridor_box(pt, acc, obstacles, robot_r, robot_h, h_max):
     g = lib().oracle_corridor_box(pp, pa, po, o.size // 3, ctypes.c_double(robot_r), ctypes.c_double(robot_h),
                                   ctypes.c_double(h_max), lo.ctypes.data_as(_dp), hi.ctypes.data_as(_dp))
     return float(g), lo, hi
+
+
+# ---- oracle/_ref: the reference's own assembly code (minimum_control.cpp compiled from /root/reference against the
+# stand-in headers of oracle/ref_shim/; built by `make -C oracle ref` where the reference is mounted) -------------------
+_REF_PATH = os.path.join(_HERE, "_ref", "libref_minimum_control.so")
+_ref = None
+
+
+def build_ref(reference_root="/root/reference"):
+    """Compile oracle/_ref if the reference sources are present (this container); returns True if the library exists."""
+    src = os.path.join(reference_root, "src", "planner", "traj_optimization", "src", "minimum_control.cpp")
+    if os.path.exists(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref", f"REF={reference_root}"])
+    return os.path.exists(_REF_PATH)
+
+
+def ref_available():
+    return os.path.exists(_REF_PATH)
+
+
+def ref_solve(pos_1d, bound_vel, bound_acc, time_vec):
+    """traj_optimization::MinimumControl::solve of the REFERENCE's own source (r = 3), one axis.  Returns a dict with the
+    matrices exactly as the reference assembles them (dense P [n,n], A [m,n], l, u), the settings it passes on, and the
+    coefficients of the exact KKT solve that stands in for OSQP (see ref_shim/OsqpEigen/OsqpEigen.h)."""
+    global _ref
+    if _ref is None:
+        _ref = ctypes.CDLL(_REF_PATH)
+    pos, pp = _d(pos_1d)
+    v, pv = _d(bound_vel)
+    a, pa = _d(bound_acc)
+    T, pT = _d(time_vec)
+    M = T.size
+    n, m = 6 * M, 6 + 4 * (M - 1)
+    coef, P, A, l, u = np.zeros(n), np.zeros((n, n)), np.zeros((m, n)), np.zeros(m), np.zeros(m)
+    info = np.zeros(6, dtype=np.int32)
+    eps = ctypes.c_double(0.0)
+    rc = _ref.ref_minimum_control_solve(M, pp, pv, pa, pT, coef.ctypes.data_as(_dp), P.ctypes.data_as(_dp), A.ctypes.data_as(_dp),
+                                        l.ctypes.data_as(_dp), u.ctypes.data_as(_dp), info.ctypes.data_as(_ip), ctypes.byref(eps))
+    return dict(ok=(rc == 1), rc=rc, coef=coef, P=P, A=A, l=l, u=u, n=int(info[0]), m=int(info[1]), max_iter=int(info[2]),
+                warm_start=bool(info[3]), p_inserted=int(info[4]), a_inserted=int(info[5]), eps_prim_inf=eps.value)

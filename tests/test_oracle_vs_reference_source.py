@@ -1,0 +1,70 @@
+"""CPU: the oracle's restatement of the reference's QP assembly against the reference's OWN source.
+
+oracle/_ref/libref_minimum_control.so is /root/reference/src/planner/traj_optimization/src/minimum_control.cpp compiled
+unmodified, from where it lies, against stand-in headers for the libraries that are absent from this image
+(oracle/ref_shim/: a minimal Eigen surface, an osqp-eigen facade that records what solve() hands to the solver and solves
+the all-equality QP exactly).  Built by __graft_entry__.build() / `make -C oracle ref` where /root/reference is mounted;
+the prebuilt file travels to the GPU box.  Skipped where neither exists.
+
+This pins the part of the path whose arithmetic lives in the reference repository itself -- getHessian,
+getConstraintMatrix, getBound, the solver settings (minimum_control.cpp:5-125,160-162).  The ADMM iteration lives in
+OSQP (absent, unpinned): parity stays "unpinned" for that part."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not (oracle.build_ref() or oracle.ref_available()):
+        pytest.skip("oracle/_ref not built and /root/reference not mounted")
+    return oracle
+
+
+def test_reference_source_kat_matches_exact_fixture(ref):
+    """test_qpsolve.cpp:10-17 through the reference's own solve(): the call succeeds, the settings are the ones SURVEY.md
+    8-a8 lists (warm start, eps_prim_inf 1e-3, max_iter 1000 -- also the defaults of oracle.osqp_settings()), P carries
+    BOTH triangles (27 = 9 per segment insertions, minimum_control.cpp:9-17), and the exact minimiser of the reference's
+    own data is the rational table of BASELINE.md section 4."""
+    r = ref.ref_solve([1, 2, 3, 4], [0, 0], [0, 0], [1, 1, 1])
+    assert r["ok"] and (r["n"], r["m"]) == (18, 14)
+    assert r["warm_start"] is True and r["eps_prim_inf"] == 1e-3 and r["max_iter"] == 1000
+    s = ref.osqp_settings()
+    assert s.max_iter == r["max_iter"] and s.eps_prim_inf == r["eps_prim_inf"]
+    assert r["p_inserted"] == 27 and np.array_equal(r["P"], r["P"].T)
+    exp = np.array([1, 0, 0, 190 / 51, -65 / 17, 56 / 51, 2, 70 / 51, -40 / 51, -10 / 17, 5 / 3, -2 / 3,
+                    3, 70 / 51, 40 / 51, -10 / 17, -5 / 3, 56 / 51])
+    assert np.max(np.abs(r["coef"] - exp)) < 1e-13
+    assert np.all(r["l"] == r["u"])                      # every row an equality
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 16])
+def test_oracle_assembly_equals_reference_assembly_entry_by_entry(ref, M):
+    """oracle_assemble_P / _A / oracle_bounds (r = 3) vs the matrices the reference code builds for the same inputs:
+    identical sparsity, values equal to the last bit (dyadic durations) or to 2 ulp (arbitrary durations: the reference
+    calls pow(T, k), the restatement multiplies)."""
+    rng = np.random.default_rng(100 + M)
+    for dyadic in (True, False):
+        T = rng.integers(2, 24, size=M) / 8.0 if dyadic else rng.uniform(0.2, 5.0, size=M)
+        pos = rng.uniform(-4, 4, size=M + 1)
+        vel, acc = rng.uniform(-2, 2, size=2), rng.uniform(-2, 2, size=2)
+        r = ref.ref_solve(pos, vel, acc, T)
+        assert r["ok"]
+        P, A = ref.assemble(3, T)
+        l, u = ref.bounds(3, pos, [vel[0], acc[0]], [vel[1], acc[1]])
+        assert np.array_equal(P != 0, r["P"] != 0) and np.array_equal(A != 0, r["A"] != 0)
+        if dyadic:
+            assert np.array_equal(P, r["P"]) and np.array_equal(A, r["A"])
+        else:
+            assert np.allclose(P, r["P"], rtol=4e-16, atol=0) and np.allclose(A, r["A"], rtol=4e-16, atol=0)
+        assert np.array_equal(l, r["l"]) and np.array_equal(u, r["u"])
+        assert r["a_inserted"] >= np.count_nonzero(r["A"])           # the reference also inserts explicit zeros (:55,61,64...)
+        # and the exact minimiser of the reference's own data is the oracle's
+        mine = ref.solve_exact(3, pos, [vel[0], acc[0]], [vel[1], acc[1]], T)
+        assert np.max(np.abs(mine - r["coef"])) <= 1e-9 * max(1.0, np.max(np.abs(mine)))
+
+
+def test_reference_source_rejects_nothing_and_indexes_out_of_range_for_one_waypoint(ref):
+    """with a single waypoint (no segment) the reference's getBound indexes out of range; the stand-in
+    containers are bounds-checked, so the wrapper reports the throw instead of corrupting memory."""
+    r = ref.ref_solve([1.0], [0, 0], [0, 0], [])
+    assert r["rc"] in (-1, 0)
