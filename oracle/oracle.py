@@ -256,3 +256,16 @@ def ref_solve(pos_1d, bound_vel, bound_acc, time_vec):
                                         l.ctypes.data_as(_dp), u.ctypes.data_as(_dp), info.ctypes.data_as(_ip), ctypes.byref(eps))
     return dict(ok=(rc == 1), rc=rc, coef=coef, P=P, A=A, l=l, u=u, n=int(info[0]), m=int(info[1]), max_iter=int(info[2]),
                 warm_start=bool(info[3]), p_inserted=int(info[4]), a_inserted=int(info[5]), eps_prim_inf=eps.value)
+
+
+def ref_polytraj_eval(nc, times, coef_traj, t):
+    """The reference's own PolyTraj::evaluatePos / Vel / Acc (traj_utils/poly_traj.hpp:74-168, compiled from source with
+    the stand-in Eigen) for one trajectory in the C-ABI layout; returns [3 (pos, vel, acc)][3 (xyz)]."""
+    global _ref
+    if _ref is None:
+        _ref = ctypes.CDLL(_REF_PATH)
+    T, pT = _d(times)
+    c, pc = _d(coef_traj)
+    out = np.zeros(9)
+    _ref.ref_polytraj_eval(int(nc), int(T.size), pT, pc, ctypes.c_double(t), out.ctypes.data_as(_dp))
+    return out.reshape(3, 3)

@@ -6,8 +6,10 @@
  *   evaluateVel      :122-135  v = sum_i (i+1) c_{i+1} t^i
  *   evaluateAcc      :154-167  a = sum_i (i+2)(i+1) c_{i+2} t^i
  * with the power vector built by repeated multiplication (tv[i] = tv[i-1]*t) and a plain dot product,
- * as the reference does.  PARITY UNPINNED: the reference has no recorded outputs for it either; the
- * header needs Eigen (absent), so it is restated, not compiled.
+ * as the reference does.  The reference has no recorded outputs for it; the restatement is pinned on the
+ * reference's own header instead: poly_traj.hpp compiled from where it lies against the stand-in Eigen of
+ * oracle/ref_shim/ (oracle/_ref, tests/test_oracle_vs_reference_source.py: 1e-13 at segment boundaries, the 1e-4
+ * slack and past the end).
  */
 #include <stddef.h>
 

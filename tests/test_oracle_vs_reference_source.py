@@ -68,3 +68,20 @@ def test_reference_source_rejects_nothing_and_indexes_out_of_range_for_one_waypo
     containers are bounds-checked, so the wrapper reports the throw instead of corrupting memory."""
     r = ref.ref_solve([1.0], [0, 0], [0, 0], [])
     assert r["rc"] in (-1, 0)
+
+
+def test_poly_eval_restatement_equals_reference_polytraj_header(ref):
+    """oracle/poly_eval.c vs the reference's own header-only PolyTraj (traj_utils/poly_traj.hpp:74-168) compiled against the
+    stand-in Eigen: positions, velocities and accelerations at times that exercise the segment-search rule (inside
+    segments, exactly on a boundary, boundary + 1e-4 on either side of the slack, before 0 and past the end).  1e-13
+    relative: the only difference is rounding in how the monomial powers are accumulated."""
+    rng = np.random.default_rng(7)
+    for nc, M in ((6, 1), (6, 4), (8, 7), (8, 12)):
+        T = rng.uniform(0.3, 2.5, size=M)
+        c = rng.normal(size=(3, M, nc))
+        edges = np.cumsum(T)
+        ts = np.concatenate([np.linspace(-0.7, edges[-1] + 1.5, 150), edges, edges + 1e-4, edges + 1.0001e-4, edges + 0.9999e-4, edges - 1e-9])
+        for t in ts:
+            a = ref.ref_polytraj_eval(nc, T, c, float(t))
+            b = ref.poly_eval(nc, T, c, float(t), 7)
+            assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-13, (nc, M, t)
