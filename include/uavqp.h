@@ -89,6 +89,46 @@ int uavqp_synchronize(uavqp_ctx* ctx);
  * For benchmarking/tests; results agree to rounding. */
 int uavqp_set_variant(uavqp_ctx* ctx, int variant);
 
+/* Solver settings: plain C struct, replaces the OsqpEigen settings calls of the reference
+ * (minimum_control.cpp:160-162: setWarmStart(true), setPrimalInfeasibilityTollerance(1e-3), setMaxIteration(1000))
+ * and every tuning knob of this back-end.  uavqp_default_settings fills the defaults (= the reference's three values
+ * plus this back-end's measured choices); uavqp_set_settings validates and stores a copy in the ctx, uavqp_get_settings
+ * reads it back.  Nothing on the launch path reads the environment: the UAVQP_* variables listed in INTEGRATION.md are
+ * read ONCE, by uavqp_create, as overrides of the defaults.
+ *   struct_size            sizeof(uavqp_settings) of the caller's build (versioning; must be set)
+ *   warm_start             reference: true.  The equality-constrained solve is direct (nothing to warm-start); for the
+ *                          inequality-constrained entry points it is the default of their warm_start argument semantics:
+ *                          uavqp_solve_corridor_warm_device's explicit argument wins.  Kept for API parity.
+ *   eps_prim_inf           reference: 1e-3 (OSQP's primal-infeasibility tolerance).  Stored and reported for API parity
+ *                          only: the device solvers are direct and detect an empty feasible set exactly
+ *                          (lo > hi -> UAVQP_INVALID_INPUT), no tolerance is involved.
+ *   max_iter               reference: 1000 (ADMM iterations).  Here: cap on active-set iterations of the
+ *                          inequality-constrained solves; <= 0 = automatic (8 * max_segments + 20).  Hitting it yields
+ *                          UAVQP_MAX_ITER_REACHED with a feasible, smooth trajectory (as OSQP's status of the same name).
+ *   kernel_variant         as uavqp_set_variant (0 auto)
+ *   ragged_window_sort     1: ragged batches >= 2048 are dealt to lanes by segment count inside windows (default), 0: lane order
+ *   generic_lanes_per_traj 0 auto, 1 = one lane per trajectory, 3 = one lane per (trajectory, axis)
+ *   generic_waves_per_cu   0 auto, > 0: resident waves per CU of the generic kernel
+ *   corridor_pdas_rounds   block-pivoting rounds before the single-pivot active-set phase (default 3)
+ *   realloc_dead_band      uavqp_time_reallocate_device stretches only when the limit ratio exceeds this (default 1.01)
+ *   realloc_overshoot      ... and then by overshoot * ratio (default 1.02) */
+typedef struct uavqp_settings {
+    int32_t struct_size;
+    int32_t warm_start;
+    double eps_prim_inf;
+    int32_t max_iter;
+    int32_t kernel_variant;
+    int32_t ragged_window_sort;
+    int32_t generic_lanes_per_traj;
+    int32_t generic_waves_per_cu;
+    int32_t corridor_pdas_rounds;
+    double realloc_dead_band;
+    double realloc_overshoot;
+} uavqp_settings;
+void uavqp_default_settings(uavqp_settings* out);
+int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* settings);
+int uavqp_get_settings(const uavqp_ctx* ctx, uavqp_settings* out);
+
 /* Batched solve, DEVICE pointers, asynchronous on the ctx stream.
  * Replaces, for a whole batch and 3 axes at once, MinimumControl::solve + getCoef1d
  * (minimum_control.cpp:127-192, :199-202).
@@ -100,7 +140,10 @@ int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segm
                              const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
                              const double* d_bc, double* d_coeff_out, int32_t* d_status_out);
 
-/* Same with HOST pointers: H2D copy, solve, D2H copy, synchronous.  total_segments = sum_b M_b. */
+/* Same with HOST pointers: H2D copy, solve, D2H copy, synchronous.  total_segments = sum_b M_b.
+ * The coefficients of a trajectory flagged UAVQP_INVALID_INPUT come back as zeros (the device entry leaves them
+ * untouched; the host entries clear their staging buffer first -- both host entries behave the same); a
+ * UAVQP_NON_FINITE trajectory carries the non-finite values it overflowed to. */
 int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                            const int32_t* seg_offsets, const double* waypoints, const double* times,
                            const double* bc, double* coeff_out, int32_t* status_out);
@@ -124,7 +167,7 @@ int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const double* pos_1d
  *   d_waypoints            start/end positions, and the initial guess (clipped into the box) elsewhere.
  *   d_iters_out            [n_traj] active-set iterations (max over axes), may be NULL.
  * Exact primal active-set solve in the Hermite variables; status UAVQP_MAX_ITER_REACHED
- * (max_iter = 8 M + 20 iterations) leaves a feasible, smooth, possibly sub-optimal trajectory. */
+ * (uavqp_settings.max_iter, default 8 M + 20 iterations) leaves a feasible, smooth, possibly sub-optimal trajectory. */
 int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                       const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
                                       const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
@@ -153,6 +196,7 @@ int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  * per inner solve).  The 3-axis speed |v| and acceleration |a| of the solved polynomials are sampled at
  * samples_per_seg + 1 uniform points per segment; with rho = max(|v|_peak / v_max, sqrt(|a|_peak / a_max)) over the
  * whole trajectory, if rho > 1.01 EVERY duration of that trajectory is scaled by min(max_stretch, 1.02 rho)
+ * (dead band 1.01 and overshoot 1.02 are uavqp_settings.realloc_dead_band / realloc_overshoot)
  * (never shrunk).  Scaling is per trajectory, not per segment: stretching one segment next to short ones makes
  * it overshoot more (it inherits their knot acceleration) and diverges; uniform scaling T -> sT lowers speeds
  * ~1/s and accelerations ~1/s^2.

@@ -48,3 +48,30 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower() or f == "_none_", f"{f} mentions the oracle"
+
+
+def test_settings_struct_matches_the_header_and_defaults_are_the_references():
+    """uavqp_settings: the ctypes mirror has the header's fields in the header's order and types, and
+    uavqp_default_settings (callable without a GPU) returns the three values the reference passes to OSQP
+    (minimum_control.cpp:160-162: warm start on, eps_prim_inf 1e-3; max_iter is mapped, see include/uavqp.h)."""
+    from uav_motion_planning_amd import _lib
+    src = open(os.path.join(ROOT, "include", "uavqp.h")).read()
+    body = re.search(r"typedef struct uavqp_settings \{(.*?)\} uavqp_settings;", src, flags=re.S).group(1)
+    fields = re.findall(r"^\s*(int32_t|double)\s+([a-z_]+);", body, flags=re.M)
+    ctype = {"int32_t": ctypes.c_int32, "double": ctypes.c_double}
+    assert [(n, ctype[t]) for t, n in fields] == list(_lib.Settings._fields_)
+    st = _lib.Settings()
+    _lib.lib().uavqp_default_settings(ctypes.byref(st))
+    assert st.struct_size == ctypes.sizeof(_lib.Settings)
+    assert st.warm_start == 1 and st.eps_prim_inf == 1e-3 and st.max_iter == 0
+    assert st.ragged_window_sort == 1 and st.corridor_pdas_rounds == 3
+    assert st.realloc_dead_band == 1.01 and st.realloc_overshoot == 1.02
+
+
+def test_launch_path_never_reads_the_environment():
+    """getenv appears only in uavqp_create (read once, as overrides of the default settings)."""
+    src = open(os.path.join(ROOT, "uav_motion_planning_amd", "csrc", "uavqp.hip")).read()
+    create = src[src.index('extern "C" int uavqp_create'):src.index('extern "C" int uavqp_destroy')]
+    assert src.count("getenv(") == create.count("getenv(") > 0
+    for h in ("qp_twisted.h", "qp_corridor.h", "qp_device.h", "obstacle_grid.h"):
+        assert "getenv" not in open(os.path.join(ROOT, "uav_motion_planning_amd", "csrc", h)).read()

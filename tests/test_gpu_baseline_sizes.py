@@ -1,0 +1,196 @@
+"""-m gpu: BASELINE.json configs 3, 4 and 5 at their FULL sizes (65 536 x M=16 jerk + corridor boxes; 32 768 ragged
+snap; 16 384 ragged snap through the cloud-corridor + re-allocation pipeline).
+
+The size-dependent code paths (grid-strided lanes, LDS-resident sweep state, window dealing by segment count, warm
+starts) are exactly what the small parity tests do not reach.  Two layers per config:
+  (i)  EVERY trajectory of the batch, vectorised on the host: status, box feasibility of every interior knot, equality
+       rows where the reference has equalities (minimum_control.cpp:98-125), C^(r-1) continuity, boundary derivatives;
+  (ii) >= 256 randomly drawn trajectories through the exact checkers: the binary128 KKT oracle / the optimality
+       certificate assembled from the reference-formulation matrices (oracle.assemble = minimum_control.cpp:5-96) /
+       the OSQP-faithful port with the same inequality rows at eps 1e-10.
+No reference counterpart exists for corridor rows and the re-allocation loop (SURVEY.md section 8-a'): those are pinned
+on the builder's exact-rational fixtures (tests/golden/corridor_exact.json) at small size and on the certificate here."""
+import numpy as np
+import pytest
+
+import uav_motion_planning_amd as U
+from uav_motion_planning_amd import workloads as W
+
+from test_gpu_corridor import kkt_certificate
+from test_gpu_fullsize import poly_derivs
+
+pytestmark = pytest.mark.gpu
+
+
+def ragged_groups(so):
+    """Trajectories grouped by segment count: yields (M, indices)."""
+    Ms = np.diff(so)
+    for M in np.unique(Ms):
+        yield int(M), np.nonzero(Ms == M)[0]
+
+
+def gather_group(so, idx, M, flat, per_seg, per_traj_extra=0):
+    """Rows of a flat per-segment array (per_seg values per segment, + per_traj_extra rows per trajectory for the
+    waypoint layout) of the trajectories idx (all with M segments) -> [len(idx), ...]."""
+    if per_traj_extra:   # waypoint layout: trajectory b starts at row so[b] + b and has M + 1 rows of per_seg values
+        start = (so[idx] + idx)[:, None] + np.arange(M + 1)[None, :]
+        return flat.reshape(-1, per_seg)[start]
+    start = so[idx][:, None] + np.arange(M)[None, :]
+    return flat.reshape(-1, per_seg)[start]
+
+
+def check_all_trajectories(r, so, wp, T, bc, coef, lo=None, hi=None, tol=1e-9):
+    """Layer (i): every trajectory, every knot.  wp [rows,3], T [segs], coef flat; lo/hi [rows,3] or None (equalities).
+    Returns the number of interior knots that sit on a (non-degenerate) box face."""
+    n_on_face = 0
+    scale = max(1.0, float(np.max(np.abs(coef))))
+    for M, idx in ragged_groups(so):
+        # coefficients of trajectory b: [axis][segment][2r] at 3*2r*so[b]
+        start = (3 * 2 * r * so[idx])[:, None] + np.arange(3 * 2 * r * M)[None, :]
+        c = coef[start].reshape(len(idx), 3, M, 2 * r)
+        Tg = gather_group(so, idx, M, T, 1)[..., 0]                                   # [g, M]
+        w = np.transpose(gather_group(so, idx, M, wp, 3, 1), (0, 2, 1))               # [g, 3, M+1]
+        end = poly_derivs(c, np.broadcast_to(Tg[:, None, :], c.shape[:-1]), r)        # [g,3,M,r]
+        beg = poly_derivs(c, np.zeros(c.shape[:-1]), r)
+        assert np.max(np.abs(beg[:, :, 0, 0] - w[:, :, 0])) < tol * scale              # start position
+        assert np.max(np.abs(end[:, :, -1, 0] - w[:, :, -1])) < tol * scale            # end position
+        b_ = bc[idx]                                                                   # [g,2,r-1,3]
+        assert np.max(np.abs(beg[:, :, 0, 1:] - np.transpose(b_[:, 0], (0, 2, 1)))) < tol * scale
+        assert np.max(np.abs(end[:, :, -1, 1:] - np.transpose(b_[:, 1], (0, 2, 1)))) < tol * scale
+        if M > 1:
+            assert np.max(np.abs(end[:, :, :-1, :] - beg[:, :, 1:, :])) < tol * scale  # C^(r-1) at every interior knot
+            knots = beg[:, :, 1:, 0]                                                   # [g,3,M-1]
+            if lo is None:
+                assert np.max(np.abs(knots - w[:, :, 1:-1])) < tol * scale             # the reference's waypoint rows
+            else:
+                l = np.transpose(gather_group(so, idx, M, lo, 3, 1), (0, 2, 1))[:, :, 1:-1]
+                h = np.transpose(gather_group(so, idx, M, hi, 3, 1), (0, 2, 1))[:, :, 1:-1]
+                assert np.all(knots >= l - tol * scale) and np.all(knots <= h + tol * scale)
+                wide = (h - l) > 1e-9
+                n_on_face += int((wide & ((np.abs(knots - l) < 1e-9) | (np.abs(knots - h) < 1e-9))).sum())
+    return n_on_face
+
+
+def certificate_on_sample(oracle, r, so, wp, T, bc, coef, lo, hi, sample, tol=(1e-9, 1e-7, 1e-6)):
+    worst = np.zeros(3)
+    for k in sample:
+        s0, M = int(so[k]), int(so[k + 1] - so[k])
+        rows = slice(s0 + k, s0 + k + M + 1)
+        c = coef[3 * 2 * r * s0:3 * 2 * r * (s0 + M)].reshape(3, 2 * r * M)
+        for ax in range(3):
+            prim, stat, comp = kkt_certificate(oracle, r, M, T[s0:s0 + M], c[ax], wp[rows, ax], bc[k, 0, :, ax], bc[k, 1, :, ax],
+                                               lo[rows, ax][1:M], hi[rows, ax][1:M])
+            worst = np.maximum(worst, [prim, stat, comp])
+    assert worst[0] < tol[0] and worst[1] < tol[1] and worst[2] < tol[2], worst
+    return worst
+
+
+def test_config3_full_size_corridor_parity(gpu_ctx, oracle):
+    """Config 3: 65 536 x (M = 16, r = 3), corridor boxes h ~ U(0.3, 0.8) m around every interior waypoint."""
+    r, n, M = 3, 65536, 16
+    b = W.uniform_batch(3, n, M, r, time_mode="distance")
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    so = b["seg_offsets"].astype(np.int64)
+    coef, st, it = gpu_ctx.solve_corridor_batch_host(r, None, b["waypoints"], b["times"], b["bc"], lo, hi, uniform_segments=M)
+    assert np.all(st == U.UAVQP_SOLVED), np.unique(st, return_counts=True)
+    assert it.max() <= 8 * M + 20 and it.min() >= 1
+    wp, T = b["waypoints"].reshape(-1, 3), b["times"].ravel()
+    lo_f, hi_f = lo.reshape(-1, 3), hi.reshape(-1, 3)
+    n_face = check_all_trajectories(r, so, wp, T, b["bc"], coef, lo_f, hi_f)
+    assert n_face > n            # the corridor binds: more than one active face per trajectory on average
+    rng = np.random.default_rng(3)
+    sample = np.sort(rng.choice(n, size=256, replace=False))
+    sample[:2] = [0, n - 1]      # both ends of the batch (first / last wave, last grid round)
+    certificate_on_sample(oracle, r, so, wp, T, b["bc"], coef, lo_f, hi_f, sample)
+    # OSQP-faithful port with the same rows, eps 1e-10: converges onto the same minimiser (1e-5 = what ADMM reaches)
+    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
+    sub = dict(wp=b["waypoints"][sample], T=b["times"][sample], bc=b["bc"][sample], lo=lo[sample], hi=hi[sample])
+    so_s = (np.arange(sample.size + 1) * M).astype(np.int32)
+    ref, st_ref, _ = oracle.osqp_solve_batch(r, so_s, sub["wp"], sub["T"], sub["bc"], settings=s, corr_lo=sub["lo"], corr_hi=sub["hi"], threads=8)
+    good = st_ref == oracle.PORT_SOLVED
+    assert good.mean() >= 0.9
+    g = coef.reshape(n, -1)[sample]
+    rr = ref.reshape(sample.size, -1)
+    err = np.max(np.abs(g - rr), axis=1) / np.max(np.abs(rr), axis=1)
+    assert err[good].max() < 1e-5, err[good].max()
+    # bitwise run-to-run determinism at full size
+    coef2, st2, it2 = gpu_ctx.solve_corridor_batch_host(r, None, b["waypoints"], b["times"], b["bc"], lo, hi, uniform_segments=M)
+    assert np.array_equal(coef, coef2) and np.array_equal(it, it2)
+
+
+def test_config4_full_size_ragged_parity(gpu_ctx, oracle):
+    """Config 4: 32 768 ragged (M in [4, 24]) min-snap QPs, kino-A*-like inputs; equality rows only = the reference's QP."""
+    r, n = 4, 32768
+    b = W.ragged_batch(4, n, r)
+    so = b["seg_offsets"].astype(np.int64)
+    coef, st = gpu_ctx.solve_batch_host(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+    assert np.all(st == U.UAVQP_SOLVED), np.unique(st, return_counts=True)
+    wp, T = np.asarray(b["waypoints"]).reshape(-1, 3), np.asarray(b["times"])
+    check_all_trajectories(r, so, wp, T, b["bc"], coef, tol=1e-8)
+    rng = np.random.default_rng(4)
+    sample = np.sort(rng.choice(n, size=256, replace=False))
+    sample[:2] = [0, n - 1]
+    # exact minimiser of the reference's own QP (binary128 KKT solve) on the sample, 1e-8 relative per trajectory
+    sub_so = np.zeros(sample.size + 1, dtype=np.int32)
+    sub_so[1:] = np.cumsum(np.diff(so)[sample])
+    sub_wp = np.concatenate([wp[so[k] + k:so[k + 1] + k + 1] for k in sample])
+    sub_T = np.concatenate([T[so[k]:so[k + 1]] for k in sample])
+    ref, st_ref = oracle.solve_exact_batch(r, sub_so, sub_wp, sub_T, b["bc"][sample])
+    for i, k in enumerate(sample):
+        got = coef[24 * so[k]:24 * so[k + 1]]
+        want = ref[24 * sub_so[i]:24 * sub_so[i + 1]]
+        assert np.max(np.abs(got - want)) < 1e-8 * np.max(np.abs(want)), (k, so[k + 1] - so[k])
+    # window dealing off = plain lane order: bit-identical at full size
+    gpu_ctx.set_settings(ragged_window_sort=0)
+    try:
+        coef_plain, st_plain = gpu_ctx.solve_batch_host(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+    finally:
+        gpu_ctx.set_settings(ragged_window_sort=1)
+    assert np.array_equal(coef, coef_plain) and np.array_equal(st, st_plain)
+
+
+def test_config5_full_size_pipeline_parity(oracle):
+    """Config 5: 16 384 ragged snap trajectories through the whole device pipeline -- plain solve, corridor boxes from the
+    pillar cloud (SE(3) robot ellipsoid), <= 5 x (warm-started corridor solve + time re-allocation), grid collision check.
+    Parity is per inner solve (nothing to mirror for the outer loop): the LAST inner solve must be the corridor QP's
+    minimiser for the FINAL durations and boxes."""
+    import torch
+    from uav_motion_planning_amd.pipeline import corridor_pipeline_device
+    r, n, mx = 4, 16384, 24
+    b = W.ragged_batch(5, n, r)
+    so = b["seg_offsets"]
+    wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+    first = (so[:-1] + np.arange(n)).astype(np.int64)
+    obs = W.pillar_cloud(5, keep_clear=wp[first])
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_so, d_wp, d_T, d_bc, d_obs = up(so), up(wp), up(b["times"]), up(b["bc"]), up(obs)
+    T0 = np.asarray(b["times"]).copy()
+    with U.Context(0) as ctx:
+        res = corridor_pipeline_device(ctx, r, d_so, d_wp, d_T, d_bc, d_obs, mx)
+        ctx.synchronize()
+        coef = res["coeff"].cpu().numpy()
+        st = res["status"].cpu().numpy()
+        lo, hi = res["corr_lo"].cpu().numpy(), res["corr_hi"].cpu().numpy()
+        T = d_T.cpu().numpy()
+        # a cold solve of the final problem reproduces the warm-started last round (same minimiser, 1e-9)
+        out2 = torch.zeros_like(res["coeff"])
+        st2 = torch.zeros_like(res["status"])
+        ctx.solve_corridor_device(r, n, 0, mx, d_so, d_wp, d_T, d_bc, res["corr_lo"], res["corr_hi"], out2, st2)
+        ctx.synchronize()
+        cold = out2.cpu().numpy()
+    assert res["rounds"] <= 5
+    assert np.all((st == U.UAVQP_SOLVED) | (st == U.UAVQP_MAX_ITER_REACHED))
+    assert (st == U.UAVQP_SOLVED).mean() > 0.999
+    assert np.all(T >= T0 * (1 - 1e-15)) and np.all(T <= T0 * 2.0 ** 5 * (1 + 1e-12))   # stretch-only, capped per round
+    so64 = so.astype(np.int64)
+    n_face = check_all_trajectories(r, so64, wp, T, b["bc"], coef, lo, hi, tol=1e-8)
+    assert n_face > 0
+    solved = st == U.UAVQP_SOLVED
+    rel = np.array([np.max(np.abs(coef[24 * so64[k]:24 * so64[k + 1]] - cold[24 * so64[k]:24 * so64[k + 1]])) /
+                    np.max(np.abs(cold[24 * so64[k]:24 * so64[k + 1]])) for k in range(0, n, 7) if solved[k]])
+    assert rel.max() < 1e-8, rel.max()
+    rng = np.random.default_rng(5)
+    sample = np.sort(rng.choice(np.nonzero(solved)[0], size=256, replace=False))
+    # durations span 0.3 s .. 10+ s after re-allocation: raw KKT conditioning of SURVEY App. A, hence the looser stationarity bound
+    certificate_on_sample(oracle, r, so64, wp, T, b["bc"], coef, lo, hi, sample, tol=(1e-8, 1e-6, 1e-5))

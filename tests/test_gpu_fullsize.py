@@ -169,11 +169,12 @@ def test_long_trajectories_generic_path(gpu_ctx, oracle):
         assert np.max(np.abs(got - ref)) < 1e-8 * np.max(np.abs(ref))
 
 
-def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx, monkeypatch):
+def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx):
     """Large ragged batches are dealt to the lanes in windows of 1024 trajectories by descending segment count
-    (solve_generic_kernel<R, LSORT>).  Which lane solves a trajectory must not change a single bit: compare with the
-    plain lane order (UAVQP_NO_LSORT=1) on a batch that needs two grid rounds, is not a multiple of the window, and
-    contains single-segment and over-long (flagged invalid) trajectories."""
+    (window_sort_kernel + solve_generic_kernel<R, LSORT>).  Which lane solves a trajectory must not change a single bit:
+    compare with the plain lane order (uavqp_settings.ragged_window_sort = 0) on a batch that needs two grid rounds, is
+    not a multiple of the window, and contains single-segment and over-long (flagged invalid) trajectories.  The status
+    buffer is pre-filled with 0 (no valid code): a trajectory the dealing dropped would keep it."""
     import torch
     r, n = 4, 140001
     rng = np.random.default_rng(44)
@@ -194,15 +195,24 @@ def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx, mo
         gpu_ctx.synchronize()
         return out.cpu().numpy(), st.cpu().numpy()
 
-    monkeypatch.delenv("UAVQP_NO_LSORT", raising=False)
+    assert gpu_ctx.get_settings().ragged_window_sort == 1
     c_deal, st_deal = run()
-    monkeypatch.setenv("UAVQP_NO_LSORT", "1")
-    c_plain, st_plain = run()
+    gpu_ctx.set_settings(ragged_window_sort=0)
+    try:
+        c_plain, st_plain = run()
+        gpu_ctx.set_settings(generic_lanes_per_traj=3)      # one lane per (trajectory, axis), windows of 336
+        c_plain3, st_plain3 = run()
+        gpu_ctx.set_settings(ragged_window_sort=1)
+        c_deal3, st_deal3 = run()
+    finally:
+        gpu_ctx.set_settings(ragged_window_sort=1, generic_lanes_per_traj=0)
+    assert np.array_equal(st_deal3, st_plain3) and np.array_equal(st_deal3, st_deal)
     assert np.array_equal(st_deal, st_plain)
     assert np.array_equal(st_deal == U.UAVQP_SOLVED, Ms <= 24)
     assert np.all(st_deal[Ms > 24] == U.UAVQP_INVALID_INPUT)
     valid = np.repeat(Ms <= 24, Ms * 24)
     assert np.array_equal(c_deal[valid], c_plain[valid])
+    assert np.array_equal(c_deal3[valid], c_plain3[valid])
     assert np.all(np.isfinite(c_deal[valid])) and np.all(np.isnan(c_deal[~valid]))   # invalid ones are left untouched
     # spot check: waypoint interpolation of a few trajectories from both ends of the batch
     for k in (0, 1, n // 2, n - 2, n - 1):

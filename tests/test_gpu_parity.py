@@ -71,11 +71,17 @@ def test_invalid_inputs_are_flagged_not_fatal(gpu_ctx, variant):
     T[5, 3] = np.nan
     T[6, 0] = -1.0
     gpu_ctx.set_variant(variant)
+    big = W.uniform_batch(7, 64, 4, 3)
+    gpu_ctx.solve_batch_host(3, None, big["waypoints"], big["times"], big["bc"], uniform_segments=4)   # fills the staging buffer
     got, st = gpu_ctx.solve_batch_host(3, None, b["waypoints"], T, b["bc"], uniform_segments=4)
     gpu_ctx.set_variant(0)
     assert list(st[[2, 5, 6]]) == [UAVQP_INVALID_INPUT] * 3
     assert np.all(np.delete(st, [2, 5, 6]) == UAVQP_SOLVED)
     assert np.all(np.isfinite(got))
+    # include/uavqp.h: the host entry returns ZEROS for a trajectory that is not solved -- never stale coefficients of an
+    # earlier batch from the reused staging buffer (a 64-trajectory batch has just gone through it)
+    g = got.reshape(8, -1)
+    assert np.all(g[[2, 5, 6]] == 0.0) and np.all(np.abs(np.delete(g, [2, 5, 6], axis=0)).max(axis=1) > 0.0)
 
 
 def test_randomised_shapes_and_variants_vs_oracle(gpu_ctx, oracle):

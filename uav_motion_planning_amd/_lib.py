@@ -30,6 +30,9 @@ SYMBOLS = (
     "uavqp_set_stream",
     "uavqp_synchronize",
     "uavqp_set_variant",
+    "uavqp_default_settings",
+    "uavqp_set_settings",
+    "uavqp_get_settings",
     "uavqp_solve_batch_device",
     "uavqp_solve_batch_host",
     "uavqp_solve_axis_host",
@@ -52,6 +55,15 @@ SYMBOLS = (
 
 class UavqpError(RuntimeError):
     pass
+
+
+class Settings(ctypes.Structure):
+    """uavqp_settings of include/uavqp.h (field order and types must match the header)."""
+    _fields_ = [("struct_size", ctypes.c_int32), ("warm_start", ctypes.c_int32), ("eps_prim_inf", ctypes.c_double),
+                ("max_iter", ctypes.c_int32), ("kernel_variant", ctypes.c_int32), ("ragged_window_sort", ctypes.c_int32),
+                ("generic_lanes_per_traj", ctypes.c_int32), ("generic_waves_per_cu", ctypes.c_int32),
+                ("corridor_pdas_rounds", ctypes.c_int32), ("realloc_dead_band", ctypes.c_double),
+                ("realloc_overshoot", ctypes.c_double)]
 
 
 def build(force=False):
@@ -92,6 +104,10 @@ def lib():
     L.uavqp_set_stream.argtypes = [vp, vp]
     L.uavqp_synchronize.argtypes = [vp]
     L.uavqp_set_variant.argtypes = [vp, i32]
+    L.uavqp_default_settings.argtypes = [ctypes.POINTER(Settings)]
+    L.uavqp_default_settings.restype = None
+    L.uavqp_set_settings.argtypes = [vp, ctypes.POINTER(Settings)]
+    L.uavqp_get_settings.argtypes = [vp, ctypes.POINTER(Settings)]
     L.uavqp_solve_batch_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
     L.uavqp_solve_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, ip]
     L.uavqp_solve_axis_host.argtypes = [vp, i32, i32, dp, dp, dp, dp, dp, dp, ctypes.POINTER(ctypes.c_int32)]

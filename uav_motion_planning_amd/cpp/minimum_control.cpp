@@ -25,11 +25,27 @@ bool MinimumControl::solve(Eigen::VectorXd& pos_1d,
         std::cout << "solver init failed!" << std::endl;
         return false;
     }
-    if (!ctx_ && uavqp_create(&ctx_, 0) != UAVQP_OK)
+    if (!ctx_)
     {
-        std::cout << "solver init failed! (" << uavqp_last_error() << ")" << std::endl;
-        ctx_ = nullptr;
-        return false;
+        if (uavqp_create(&ctx_, 0) != UAVQP_OK)
+        {
+            std::cout << "solver init failed! (" << uavqp_last_error() << ")" << std::endl;
+            ctx_ = nullptr;
+            return false;
+        }
+        // the three settings the reference passes to its solver (minimum_control.cpp:160-162)
+        uavqp_settings st;
+        uavqp_default_settings(&st);
+        st.warm_start = 1;       // solver_.settings()->setWarmStart(true)
+        st.eps_prim_inf = 1e-3;  // setPrimalInfeasibilityTollerance(1e-3)
+        st.max_iter = 1000;      // setMaxIteration(1000)
+        if (uavqp_set_settings(ctx_, &st) != UAVQP_OK)
+        {
+            std::cout << "solver init failed!" << std::endl;
+            uavqp_destroy(ctx_);
+            ctx_ = nullptr;
+            return false;
+        }
     }
     std::vector<double> pos(seg_num + 1), tv(seg_num), coef(2 * order_ * seg_num);
     for (int i = 0; i <= seg_num; i++) pos[i] = pos_1d[i];

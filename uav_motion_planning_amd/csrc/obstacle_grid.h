@@ -129,7 +129,7 @@ struct CorridorRow {
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) p[ax] = a.waypoints[(size_t)g * 3 + ax];
         double acc[3] = {0.0, 0.0, 0.0};
-        if (a.coeff) {
+        if (a.coeff && M >= 1) {  // a zero-segment trajectory (flagged invalid by the solver) has no polynomial: hover attitude
             // acceleration at the knot: start of segment k (2 c_2), or the end of the last segment for k = M
             const int seg = k < M ? k : M - 1;
 #pragma unroll
@@ -236,6 +236,10 @@ __global__ __launch_bounds__(256) void ellipsoid_grid_kernel(EllipsoidGridArgs a
         const int s = (int)(g - (long long)b * a.n_samples);
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        if (M < 1) {  // zero-segment trajectory (flagged invalid by the solver): nothing to sample, reported collision-free
+            if (a.flags) a.flags[g] = 0;
+            continue;
+        }
         const double* __restrict__ T = a.times + s0;
         double t = a.t0 + s * a.dt;
         int idx = 0;

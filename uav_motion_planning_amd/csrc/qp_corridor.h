@@ -20,7 +20,7 @@
 namespace uavqp {
 
 struct CorridorArgs {
-    int n_traj, uniform, max_segments, max_iter;
+    int n_traj, uniform, max_segments, max_iter, pdas_rounds;
     const int32_t* seg_offsets;
     const double* waypoints;
     const double* times;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(Corr
         pin |= eqmask;
 
         int it = 0;
-        int pdas_left = 3;  // PDAS_ITERS (measured on config 3: 3 rounds 13.8 mean iterations, 0 rounds 17.5, 10 rounds 15.7)
+        int pdas_left = a.pdas_rounds;  // default 3 (measured on config 3: 3 rounds 13.8 mean iterations, 0 rounds 17.5, 10 rounds 15.7)
         bool converged = (M == 1);
         bool final_pass = false;  // max_iter hit: one last solve with every position pinned at the feasible iterate
         // pending update of z, applied by the next forward sweep (zmode 0: none; 1: block-pivot round; 2: partial step

@@ -29,6 +29,7 @@ struct BatchArgs {
     double* coeff;
     int32_t* status;
     double* ws;     // forward-sweep workspace (generic kernel)
+    const int32_t* perm;  // ragged dealing (generic kernel, LSORT): lane slot -> trajectory
     double* dummy;  // 1 KiB sink for the predicated-off stores of the specialised kernel
 #ifdef UAVQP_PHASE_TIMING
     long long* stamps;  // debug: s_memtime stamps of wave 0 (tools/ubench only)
@@ -48,84 +49,81 @@ struct BatchArgs {
 //          E_k is stored once per trajectory (by the x lane, in its own slot) and read by all three lanes from that
 //          slot: same wave, program order, so the hand-off needs no fence.
 // ---------------------------------------------------------------------------------------------------
-// LSORT (ragged batches): every group of 16 consecutive single-wave workgroups shares a window of 16 x IPW consecutive
-// trajectories (IPW = trajectories per wave: 64 or 21) and deals them out by descending segment count -- workgroup q of
-// the group takes ranks [IPW q, IPW (q + 1)) -- so that the lanes of one wave run sweeps of nearly equal length while
-// the window stays contiguous in memory (a GLOBAL sort by M was measured at 157 -> 244 us on config 4: it destroys the
-// locality the strided per-lane accesses live on).  Each workgroup runs the same counting sort of the window's counts
-// in LDS (one wave, 256 bins) and keeps its own IPW entries; the order inside a bin is whatever the LDS atomics give --
-// it only decides WHICH lane solves a trajectory, never the result.
+// LSORT (ragged batches): every window of 16 x IPW consecutive trajectories (IPW = trajectories per wave: 64 or 21) is
+// dealt to 16 consecutive single-wave workgroups by descending segment count -- workgroup q of the group takes ranks
+// [IPW q, IPW (q + 1)) -- so that the lanes of one wave run sweeps of nearly equal length while the window stays
+// contiguous in memory (a GLOBAL sort by M was measured at 157 -> 244 us on config 4: it destroys the locality the
+// strided per-lane accesses live on).  The dealing is a permutation `perm` of the batch, written ONCE per window by
+// window_sort_kernel (one workgroup per window, LDS counting sort); the solve kernel only reads it.  The order inside a
+// bin is whatever the LDS atomics of that one sort give: it decides WHICH lane solves a trajectory, never the result, and
+// since every trajectory index is written to exactly one slot of perm, none can be solved twice or dropped.
+template <int WIN>
+__global__ __launch_bounds__(256) void window_sort_kernel(const int32_t* __restrict__ seg_offsets, int n_traj, int32_t* __restrict__ perm) {
+    constexpr int KPT = (WIN + 255) / 256;  // keys per thread
+    __shared__ int s_cnt[256];
+    __shared__ int s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int base = blockIdx.x * WIN;
+    int key[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int w = j * 256 + tid, t = base + w;
+        int Mt = -1;
+        if (w < WIN && t < n_traj) {
+            Mt = seg_offsets[t + 1] - seg_offsets[t];
+            Mt = Mt < 0 ? 0 : (Mt > 255 ? 255 : Mt);
+        }
+        key[j] = Mt;
+    }
+    s_cnt[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+        if (key[j] >= 0) atomicAdd(&s_cnt[255 - key[j]], 1);  // bin 0 = longest
+    __syncthreads();
+    // exclusive prefix over the 256 bins: wave scan + the totals of the waves in front
+    const int c = s_cnt[tid];
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int run = incl - c;
+    for (int q = 0; q < wv; ++q) run += s_wave[q];
+    s_cnt[tid] = run;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+        if (key[j] >= 0) {
+            const int pos = atomicAdd(&s_cnt[255 - key[j]], 1);
+            perm[base + pos] = base + j * 256 + tid;
+        }
+}
+
 template <int R, bool LSORT, int NAX>
 __global__ __launch_bounds__(64) void solve_generic_kernel(BatchArgs a) {
     constexpr int ND = R - 1, NC = 2 * R, F = ND * ND + NAX * ND;
     constexpr int LPI = 3 / NAX;              // lanes per trajectory
     constexpr int IPW = 64 / LPI;             // trajectories per wave (64 or 21)
-    constexpr int GRP = 16, WIN = GRP * IPW;  // LSORT window
-    constexpr int KPL = (WIN + 63) / 64;      // keys per lane
     const int lane = threadIdx.x;
     const int ax0 = NAX == 1 ? lane % 3 : 0;
     const int item = lane / LPI;
     const bool lane_used = item < IPW;   // NAX = 1: lane 63 idles
     // workspace [wave][interior knot][field][lane]: a wave's record of one knot is F consecutive 512-byte rows
     const int kmax = a.max_segments > 1 ? a.max_segments - 1 : 1;
-    double* __restrict__ ws = a.ws + (size_t)blockIdx.x * kmax * F * 64 + lane;
-    const double* __restrict__ wsE = ws - ax0;  // the x lane's slot holds E for the whole trajectory
+    // (no __restrict__: for the x lane ws and wsE are the same address)
+    double* ws = a.ws + (size_t)blockIdx.x * kmax * F * 64 + lane;
+    const double* wsE = ws - ax0;  // the x lane's slot holds E for the whole trajectory
     constexpr size_t wstride = 64;
-    __shared__ int s_cnt[LSORT ? 256 : 1];   // per bin: count, then running fill position
-    __shared__ int s_mine[LSORT ? 64 : 1];
-
-    const int n_items = gridDim.x * IPW;  // LSORT: the host rounds the grid to a multiple of GRP
+    const int n_items = gridDim.x * IPW;  // LSORT: the host rounds the grid to a multiple of 16 (whole windows per round)
     const int n_round = (a.n_traj + n_items - 1) / n_items;
     for (int round = 0; round < n_round; ++round) {
         int b = lane_used ? round * n_items + blockIdx.x * IPW + item : a.n_traj;
         if constexpr (LSORT) {
-            const int q = blockIdx.x % GRP;
-            const int base = round * n_items + (blockIdx.x - q) * IPW;  // first trajectory of the group's window
-            int key[KPL];
-#pragma unroll
-            for (int j = 0; j < KPL; ++j) {
-                const int w = j * 64 + lane;
-                const int t = base + w;
-                int Mt = -1;
-                if (w < WIN && t < a.n_traj) {
-                    Mt = a.seg_offsets[t + 1] - a.seg_offsets[t];
-                    Mt = Mt < 0 ? 0 : (Mt > 255 ? 255 : Mt);
-                }
-                key[j] = Mt;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s_cnt[4 * lane + j] = 0;
-            s_mine[lane] = -1;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < KPL; ++j)
-                if (key[j] >= 0) atomicAdd(&s_cnt[255 - key[j]], 1);  // bin 0 = longest
-            __syncthreads();
-            // exclusive prefix over the 256 bins: 4 bins per lane + a wave scan
-            int c[4], tot = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { c[j] = s_cnt[4 * lane + j]; tot += c[j]; }
-            int incl = tot;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int up = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += up;
-            }
-            int run = incl - tot;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { s_cnt[4 * lane + j] = run; run += c[j]; }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < KPL; ++j)
-                if (key[j] >= 0) {
-                    const int pos = atomicAdd(&s_cnt[255 - key[j]], 1);
-                    if (pos / IPW == q) s_mine[pos % IPW] = j * 64 + lane;
-                }
-            __syncthreads();
-            const int mine = lane_used ? s_mine[item] : -1;
-            __syncthreads();  // before the next round clears s_mine
-            b = mine >= 0 ? base + mine : a.n_traj;
+            if (b < a.n_traj) b = a.perm[b];  // dealt by segment count inside the window (window_sort_kernel)
         }
         if (b >= a.n_traj) continue;
         int s0, M;
@@ -433,12 +431,22 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(EllipsoidArgs a) {
     const long long total = (long long)a.n_traj * a.n_samples;
     const long long n_round = (total + 255) / 256 * 256;  // every thread of a block joins the LDS tile loads
     for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n_round; g += (long long)gridDim.x * 256) {
-        const bool live = g < total;
+        bool live = g < total;
         int b = 0, s = 0;
         double p[3] = {0, 0, 0}, b1[3] = {1, 0, 0}, b2[3] = {0, 1, 0}, b3[3] = {0, 0, 1};
+        bool empty = false;  // zero-segment trajectory (flagged invalid by the solver): nothing to sample, reported collision-free
         if (live) {
             b = (int)(g / a.n_samples);
             s = (int)(g - (long long)b * a.n_samples);
+            int s0, M;
+            if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+            empty = M < 1;
+        }
+        if (live && empty) {
+            if (a.flags) a.flags[g] = 0;
+            live = false;  // still joins the LDS tile loads below
+        }
+        if (live) {
             int s0, M;
             if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
             const double* __restrict__ T = a.times + s0;
@@ -504,6 +512,7 @@ struct ReallocArgs {
     double* times;
     const double* coeff;
     double v_max, a_max, max_stretch;
+    double dead_band, overshoot;  // uavqp_settings.realloc_dead_band / realloc_overshoot
     int32_t* changed;
 };
 
@@ -556,9 +565,9 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
         if (!live) continue;
         const double ratio = fmax(sqrt(v2) / a.v_max, sqrt(sqrt(a2) / a.a_max));
         int ch = 0;
-        // 1 % dead band and 2 % overshoot so that the loop settles instead of creeping towards the limit
-        if (ratio > 1.01 && ratio < INFINITY) {
-            const double s = fmin(1.02 * ratio, a.max_stretch);
+        // dead band (default 1 %) and overshoot (default 2 %) so that the loop settles instead of creeping towards the limit
+        if (ratio > a.dead_band && ratio < INFINITY) {
+            const double s = fmin(a.overshoot * ratio, a.max_stretch);
             for (int i = sub; i < M; i += LPT) a.times[s0 + i] *= s;
             ch = M;
         }
@@ -610,10 +619,13 @@ struct uavqp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int variant = 0;
-    int tile_override = 0;  // UAVQP_TILE=16|32 (tuning aid)
+    int tile_override = 0;  // fixed tile shape of the specialised kernel (variants 8 / 16 / 32 / 64)
+    uavqp_settings settings{};
     int num_cus = 256;
     double* ws = nullptr;
     size_t ws_bytes = 0;
+    int32_t* perm = nullptr;  // ragged dealing permutation (window_sort_kernel)
+    size_t perm_count = 0;
     double* dummy = nullptr;
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
@@ -629,7 +641,46 @@ struct uavqp_ctx {
         }                                                                                        \
     } while (0)
 
-extern "C" const char* uavqp_version(void) { return "uavqp 0.1.0 (gfx950, float64)"; }
+extern "C" const char* uavqp_version(void) { return "uavqp 0.2.0 (gfx950, float64)"; }
+
+extern "C" void uavqp_default_settings(uavqp_settings* out) {
+    if (!out) return;
+    std::memset(out, 0, sizeof(*out));
+    out->struct_size = (int32_t)sizeof(uavqp_settings);
+    out->warm_start = 1;        // minimum_control.cpp:160
+    out->eps_prim_inf = 1e-3;   // minimum_control.cpp:161
+    out->max_iter = 0;          // automatic (8 M + 20); the reference's 1000 ADMM iterations (:162) map to an active-set cap
+    out->kernel_variant = 0;
+    out->ragged_window_sort = 1;
+    out->generic_lanes_per_traj = 0;
+    out->generic_waves_per_cu = 0;
+    out->corridor_pdas_rounds = 3;
+    out->realloc_dead_band = 1.01;
+    out->realloc_overshoot = 1.02;
+}
+
+static int apply_variant(uavqp_ctx* ctx, int variant);
+
+extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
+    if (!ctx || !st || st->struct_size != (int32_t)sizeof(uavqp_settings)) return UAVQP_ERR_INVALID_ARG;
+    if (!(st->eps_prim_inf >= 0.0) || !(st->realloc_dead_band >= 1.0) || !(st->realloc_overshoot >= 1.0) || !(st->realloc_dead_band < INFINITY) ||
+        !(st->realloc_overshoot < INFINITY) || st->corridor_pdas_rounds < 0 || st->corridor_pdas_rounds > 64 ||
+        (st->generic_lanes_per_traj != 0 && st->generic_lanes_per_traj != 1 && st->generic_lanes_per_traj != 3) || st->generic_waves_per_cu < 0 ||
+        st->generic_waves_per_cu > 32)
+        return UAVQP_ERR_INVALID_ARG;
+    const int rc = apply_variant(ctx, st->kernel_variant);
+    if (rc != UAVQP_OK) return rc;
+    ctx->settings = *st;
+    ctx->settings.warm_start = st->warm_start ? 1 : 0;
+    ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_get_settings(const uavqp_ctx* ctx, uavqp_settings* out) {
+    if (!ctx || !out) return UAVQP_ERR_INVALID_ARG;
+    *out = ctx->settings;
+    return UAVQP_OK;
+}
 extern "C" const char* uavqp_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
@@ -668,9 +719,21 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
         delete ctx;
         return UAVQP_ERR_ALLOC;
     }
+    // The environment is read HERE, once, as overrides of the defaults (tuning aids); nothing on the
+    // launch path calls getenv.
+    uavqp_default_settings(&ctx->settings);
     if (const char* e = std::getenv("UAVQP_TILE")) {
         const int t = std::atoi(e);
-        if (t == 8 || t == 16 || t == 32 || t == 64) ctx->tile_override = t;
+        if (t == 8 || t == 16 || t == 32 || t == 64) {
+            (void)apply_variant(ctx, t);
+            ctx->settings.kernel_variant = t;
+        }
+    }
+    if (std::getenv("UAVQP_NO_LSORT")) ctx->settings.ragged_window_sort = 0;
+    if (const char* e = std::getenv("UAVQP_GENERIC_NAX")) ctx->settings.generic_lanes_per_traj = std::atoi(e) == 3 ? 1 : 3;
+    if (const char* e = std::getenv("UAVQP_GENERIC_WPC")) {
+        const int w = std::atoi(e);
+        if (w > 0 && w <= 32) ctx->settings.generic_waves_per_cu = w;
     }
     *out_ctx = ctx;
     return UAVQP_OK;
@@ -681,6 +744,7 @@ extern "C" int uavqp_destroy(uavqp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->perm) (void)hipFree(ctx->perm);
     if (ctx->dummy) (void)hipFree(ctx->dummy);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -700,8 +764,7 @@ extern "C" int uavqp_synchronize(uavqp_ctx* ctx) {
     return UAVQP_OK;
 }
 
-extern "C" int uavqp_set_variant(uavqp_ctx* ctx, int variant) {
-    if (!ctx) return UAVQP_ERR_INVALID_ARG;
+static int apply_variant(uavqp_ctx* ctx, int variant) {
     if (variant == 8 || variant == 16 || variant == 32 || variant == 64) {  // specialised kernel with a fixed tile shape
         ctx->variant = 2;
         ctx->tile_override = variant;
@@ -711,6 +774,13 @@ extern "C" int uavqp_set_variant(uavqp_ctx* ctx, int variant) {
     ctx->variant = variant;
     ctx->tile_override = 0;
     return UAVQP_OK;
+}
+
+extern "C" int uavqp_set_variant(uavqp_ctx* ctx, int variant) {
+    if (!ctx) return UAVQP_ERR_INVALID_ARG;
+    const int rc = apply_variant(ctx, variant);
+    if (rc == UAVQP_OK) ctx->settings.kernel_variant = variant;
+    return rc;
 }
 
 static int ensure_ws(uavqp_ctx* ctx, size_t bytes) {
@@ -790,9 +860,10 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     // (measured, r = 4: M = 14 24 -> 18 us, M = 24 40 -> 29 us up to 4096 trajectories) -- and one per trajectory (3 axes
     // share the factorisation, a third of the E traffic) once the batch is throughput-bound (cross-over at ~8192;
     // 32768 x M = 14: 50 vs 76 us).  Ragged batches of some size deal windows of 16 waves' trajectories by segment count.
-    const bool lsort = uniform_segments == 0 && n_traj >= 2048 && !std::getenv("UAVQP_NO_LSORT");
+    const bool lsort = uniform_segments == 0 && n_traj >= 2048 && ctx->settings.ragged_window_sort;
     int nax = n_traj <= 32 * ctx->num_cus ? 1 : 3;
-    if (const char* e = std::getenv("UAVQP_GENERIC_NAX")) nax = std::atoi(e) == 3 ? 3 : 1;
+    if (ctx->settings.generic_lanes_per_traj == 1) nax = 3;       // one lane per trajectory carries all three axes
+    else if (ctx->settings.generic_lanes_per_traj == 3) nax = 1;  // one lane per (trajectory, axis)
     const int ipw = nax == 3 ? 64 : 21;
     const int block = 64;
     int grid = (n_traj + ipw - 1) / ipw;
@@ -801,7 +872,7 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     // tools/generic_grid_probe.py: 65536 x M=14: 111 us at 1 wave/CU vs 141 us at 8; 262144: 524 vs 640 us; r = 3, M = 20,
     // 262144: 625 vs 920 us); up to 128 trajectories per CU two waves per CU run the batch in a single round (49 vs 58 us).
     int waves_per_cu = nax == 3 ? (n_traj <= 128 * ctx->num_cus ? 2 : 1) : 12;
-    if (const char* e = std::getenv("UAVQP_GENERIC_WPC")) waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : waves_per_cu;
+    if (ctx->settings.generic_waves_per_cu > 0) waves_per_cu = ctx->settings.generic_waves_per_cu;
     const int max_grid = ctx->num_cus * waves_per_cu;
     if (grid > max_grid) grid = max_grid;
     if (lsort) grid = (grid + 15) / 16 * 16;
@@ -810,6 +881,23 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     int rc = ensure_ws(ctx, ws_bytes);
     if (rc != UAVQP_OK) return rc;
     a.ws = ctx->ws;
+    a.perm = nullptr;
+    if (lsort) {
+        // dealing permutation: one counting sort per window of 16 waves' trajectories (see window_sort_kernel)
+        if ((size_t)n_traj > ctx->perm_count) {
+            UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->perm) UAVQP_HIP(hipFree(ctx->perm));
+            ctx->perm = nullptr;
+            ctx->perm_count = 0;
+            UAVQP_HIP(hipMalloc((void**)&ctx->perm, sizeof(int32_t) * (size_t)n_traj));
+            ctx->perm_count = (size_t)n_traj;
+        }
+        const int win = 16 * ipw;
+        const int n_win = (n_traj + win - 1) / win;
+        if (nax == 3) hipLaunchKernelGGL((uavqp::window_sort_kernel<1024>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
+        else hipLaunchKernelGGL((uavqp::window_sort_kernel<336>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
+        a.perm = ctx->perm;
+    }
 #define UAVQP_GENERIC(RR)                                                                                                   \
     do {                                                                                                                    \
         if (nax == 3) {                                                                                                     \
@@ -883,6 +971,9 @@ extern "C" int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uni
     UAVQP_HIP(hipMemcpyAsync(d_wp, waypoints, sizeof(double) * 3 * (size_t)(total_seg + n_traj), hipMemcpyHostToDevice, s));
     if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(d_t, times, sizeof(double) * (size_t)total_seg, hipMemcpyHostToDevice, s));
     UAVQP_HIP(hipMemcpyAsync(d_bc, bc, sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3, hipMemcpyHostToDevice, s));
+    // the kernels leave failed trajectories unwritten and the staging buffer is reused: clear it, so that a failed
+    // trajectory comes back as zeros (never as another batch's coefficients)
+    if (total_seg > 0) UAVQP_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * 3 * 2 * r * (size_t)total_seg, s));
     rc = uavqp_solve_batch_device(ctx, r, n_traj, uniform_segments, Mmax, d_off, d_wp, d_t, d_bc, d_out, d_st);
     if (rc != UAVQP_OK) return rc;
     if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(coeff_out, d_out, sizeof(double) * 3 * 2 * r * (size_t)total_seg, hipMemcpyDeviceToHost, s));
@@ -993,7 +1084,8 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     const int Mmax = uniform_segments > 0 ? uniform_segments : max_segments;
     uavqp::CorridorArgs a;
     a.active = (unsigned long long*)d_active_set; a.warm = warm_start ? 1 : 0;
-    a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax; a.max_iter = 8 * Mmax + 20;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax; a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 8 * Mmax + 20;
+    a.pdas_rounds = ctx->settings.corridor_pdas_rounds;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.coeff = d_coeff_out; a.status = d_status_out; a.iters = d_iters_out;
     const int block = 64;
@@ -1104,6 +1196,7 @@ extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, i
     a.n_traj = n_traj; a.uniform = uniform_segments; a.samples = samples_per_seg;
     a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.v_max = v_max; a.a_max = a_max;
     a.max_stretch = max_stretch; a.changed = d_changed_out;
+    a.dead_band = ctx->settings.realloc_dead_band; a.overshoot = ctx->settings.realloc_overshoot;
     long long grid_ll = ((long long)n_traj * 8 + 63) / 64;  // 8 lanes per trajectory
     if (grid_ll > (long long)ctx->num_cus * 32) grid_ll = (long long)ctx->num_cus * 32;
     const int grid = (int)grid_ll;

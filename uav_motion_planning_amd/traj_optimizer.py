@@ -61,6 +61,22 @@ class Context:
     def synchronize(self):
         _lib.check(_lib.lib().uavqp_synchronize(self._h), "uavqp_synchronize")
 
+    def get_settings(self):
+        """Current uavqp_settings of this ctx (a _lib.Settings ctypes struct)."""
+        st = _lib.Settings()
+        _lib.check(_lib.lib().uavqp_get_settings(self._h, ctypes.byref(st)), "uavqp_get_settings")
+        return st
+
+    def set_settings(self, **fields):
+        """Update fields of the ctx's uavqp_settings (reference: minimum_control.cpp:160-162 sets warm_start,
+        eps_prim_inf, max_iter on its OsqpEigen solver), e.g. set_settings(max_iter=1000, ragged_window_sort=0)."""
+        st = self.get_settings()
+        for k, v in fields.items():
+            if not hasattr(st, k):
+                raise AttributeError(f"uavqp_settings has no field {k!r}")
+            setattr(st, k, v)
+        _lib.check(_lib.lib().uavqp_set_settings(self._h, ctypes.byref(st)), "uavqp_set_settings")
+
     def eval_batch_device(self, r, n_traj, uniform_segments, seg_offsets, times, coeff, n_samples, t0, dt, what, out):
         """Batched PolyTraj::evaluatePos/Vel/Acc on the grid t0 + s*dt (device buffers, asynchronous)."""
         def p(x):
@@ -244,6 +260,8 @@ class MinimumControl:
             return False
         if self._ctx is None:
             self._ctx = Context(self._device)  # raises UavqpError without libuavqp.so / without a GPU
+            # the three settings the reference passes to its solver (minimum_control.cpp:160-162)
+            self._ctx.set_settings(warm_start=1, eps_prim_inf=1e-3, max_iter=1000)
         rc, st, coef = self._ctx.solve_axis_host(self._r, pos, bound_vel, bound_acc, tv, bound_jerk)
         if rc != _lib.UAVQP_OK:
             print("solver init failed!")
@@ -321,6 +339,8 @@ class TrajOptimizer:
         bc = self._bc if self._bc is not None else np.zeros((n_traj, 2, self._r - 1, 3))
         if self._ctx is None:
             self._ctx = Context(self._device)  # raises UavqpError without libuavqp.so / without a GPU
+            # the three settings the reference passes to its solver (minimum_control.cpp:160-162)
+            self._ctx.set_settings(warm_start=1, eps_prim_inf=1e-3, max_iter=1000)
         if self._lo is not None:
             self._coef, self.status, self.iterations = self._ctx.solve_corridor_batch_host(
                 self._r, self._so, self._wp, self._T, bc, self._lo, self._hi)
