@@ -10,10 +10,24 @@
 // released -- no ADMM tolerance, the result is the QP's minimiser to rounding (OSQP in the reference
 // formulation converges to the same point, which is how the tests check it).
 //
-// One lane per (trajectory, axis): the active sets differ per axis, so the factorisation is not shared.
-// Sweep state lives in an HBM workspace laid out [wave][knot][field][lane] (any segment count up to 63, ragged batches);
-// uniform batches keep the records of their last knots in LDS.  Checked against exact-rational fixtures including the
-// active sets (tests/test_corridor_golden.py), the OSQP-faithful port and a KKT certificate (tests/test_gpu_corridor.py).
+// Round-2 layout (round 1 kept the sweep state of every knot in an HBM workspace and moved 26-38x the algorithmic bytes):
+//   * TWO lanes per (trajectory, axis) problem -- "twisted" two-sided block elimination, as in qp_twisted.h: lane L eliminates
+//     the knots 1..c-1 in the forward direction, lane R the time-reversed problem (derivative d picks up (-1)^d, positions and
+//     their bounds are unchanged) from knot M-1 down to c+1 with the SAME instruction stream; the two partial Schur
+//     complements of the meeting knot c = ceil(M/2) are exchanged through DPP (lane ^ 1), both lanes solve it and
+//     back-substitute their own half.  Half the sequential depth, half the per-lane state.
+//   * the per-knot sweep state (LDL' factors, h_k / x_k, the feasible iterate z_k) of the first NT own knots of a lane lives
+//     in LDS: 8 knots x 10 doubles x 64 lanes = 40 KiB per single-wave workgroup for r = 3, i.e. FOUR waves per CU = one per
+//     SIMD with the whole state of a 16-segment problem on chip (config 3: no workspace traffic at all).  Longer halves keep
+//     the remaining knots in an HBM workspace [wave][own knot][field][lane] as before (r = 4: NT = 5).
+//   * persistent waves pull problems from a global work counter: a lane pair that has converged hands over its Hermite solution
+//     and takes the next problem at once, so a wave no longer runs as long as its slowest lane (mean 11 iterations per problem,
+//     19.4 mean over the waves' maxima on config 3).  Lane pairs of one wave are therefore at different iterations of different
+//     problems; every iteration is the same instruction stream (one forward, one backward sweep), so nothing diverges.
+//   * the solver writes the HERMITE solution (r doubles per interior knot and axis); corridor_emit_kernel turns it into the
+//     reference's monomial coefficients with one lane per (trajectory, axis, segment), fully coalesced.
+// Checked against exact-rational fixtures including the active sets (tests/test_corridor_golden.py), the OSQP-faithful port and
+// a KKT certificate (tests/test_gpu_corridor.py), at BASELINE sizes in tests/test_gpu_baseline_sizes.py.
 #pragma once
 #include "qp_device.h"
 
@@ -30,9 +44,13 @@ struct CorridorArgs {
     double* coeff;
     int32_t* status;  // pre-filled with UAVQP_SOLVED; failing axes atomicMin their code in
     int32_t* iters;   // pre-filled with 0; atomicMax over axes (may be null)
-    double* ws;
-    unsigned long long* active;  // [n_traj][3][2] working set in/out (may be null)
-    int warm;                    // read `active` as the initial working set
+    double* ws;       // HBM part of the sweep state: [wave][own knot beyond NT][field][lane] (null when every half fits LDS)
+    int ws_knots;     // own knots per lane held in the workspace
+    double* xsol;     // [waypoint row][axis][r]: Hermite solution at the interior knots (hand-off to corridor_emit_kernel)
+    unsigned int* queue;           // work counter, zeroed before the launch
+    const int32_t* order;          // optional dealing order of the trajectories (null = index order)
+    unsigned long long* active;    // [n_traj][3][2] working set in/out (may be null)
+    int warm;                      // read `active` as the initial working set
 };
 
 // r x r blocks of one segment including the position component (index 0):
@@ -64,502 +82,739 @@ __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     if (i < n) p[i] = v;
 }
 
-// r = 3 is held to 2 waves per SIMD (256 registers, some scratch): the sweeps are chains of dependent
-// operations, a second wave fills the gaps (measured on config 3: 4.30 ms at 1 wave, 3.25 ms at 2, 4.19 ms at 3).
-//
-// Every active-set iteration is exactly ONE forward and ONE backward pass over the knots; everything else is
-// folded into them, and every HBM access of a pass is issued one knot ahead of its use:
+__device__ __forceinline__ int swap_pair_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ unsigned long long swap_pair_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)swap_pair_i((int)(unsigned)v), hi = (unsigned)swap_pair_i((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+constexpr int corridor_lds_knots(int R) { return R == 3 ? 8 : 5; }
+
+// wave-uniform maximum of a small non-negative per-lane integer (< 64): six ballots
+__device__ __forceinline__ int wave_max_small(int v) {
+    int r = 0;
+#pragma unroll
+    for (int bit = 5; bit >= 0; --bit) {
+        const int t = r | (1 << bit);
+        if (__ballot(v >= t) != 0ull) r = t;
+    }
+    return r;
+}
+
+__device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
+
+// Every active-set iteration is exactly ONE forward and ONE backward pass over the own knots of a lane; everything else is
+// folded into them, and every state access of a pass is issued one knot ahead of its use:
 //   * the update of the feasible iterate z decided by the previous iteration (block-pivot clip, partial step of
 //     the ratio test, full step) is applied lazily in the forward sweep, one knot ahead of the elimination;
 //   * the decisions of the iteration -- block-pivot sets, ratio test over the free positions, multipliers of the
 //     active bounds (row 0 of the unmasked block row, finished one knot late when x_{k-1} appears) -- are
-//     accumulated in the backward sweep.
-// (The first version ran these as separate loops of dependent HBM round trips: 2-3x the time of the sweeps.)
-template <int R>
-struct SegRow0 {
-    // what the multiplier of knot j needs from a segment s: e11[c] = B11_s[0][c], e01r[c] = B01_s[0][c], e01c[c] = B01_s[c][0]
-    double e11[R], e01r[R], e01c[R];
-};
-
-template <int R, int LDS_KNOTS>
-__global__ __launch_bounds__(64, R == 3 ? 2 : 1) void solve_corridor_kernel(CorridorArgs a) {
-    constexpr int ND = R - 1, NC = 2 * R;
-    // Prefetch distance is ONE knot.  Two was measured and is worse: the second record buffer pushes the r = 4 kernel
-    // (256 VGPRs + AGPR spills already) over the edge -- config 5's corridor solve 2.83 ms at distance 1, 3.4 ms at 2.
-    // sweep state per interior knot: LDL' factors of S_k (strict lower triangle + inverse pivots), x_k (first h_k,
-    // overwritten by the solution in the backward sweep) and the current position iterate z_k.  E_k = S_k^-1 M_k is
-    // NOT stored: it is re-derived from the factors where needed (the kernel is bound by this HBM traffic).
+//     accumulated in the backward sweep and combined across the lane pair.
+// Own frame of a lane: own knot j = 0 is its boundary knot (knot 0 for L, knot M for R), own knot m is the meeting knot
+// (m_L = ceil(M/2), m_R = floor(M/2)); own segment j joins own knots j and j+1.  Working-set masks are kept in ORIGINAL knot
+// numbering (bit k = interior waypoint k) and are identical in both lanes of a pair.
+//
+// The lane pairs of a wave work on different problems at different iterations, and on ragged batches on halves of different
+// length, so every data-dependent choice (pinned or free, which z update is pending, ...) is a SELECT, not a branch: the knot
+// steps are single basic blocks the scheduler can interleave freely -- with one wave per SIMD nothing else hides a stall.
+// Sweeps are aligned at the MEETING knot: state slot s holds own knot m - s, the forward sweep of a shorter half starts late,
+// the backward sweep ends early; slot numbers (and with them the LDS-or-workspace test, slot < NT) are wave-uniform.
+// WS: some halves are longer than NT knots, their far slots live in the HBM workspace (one uniform branch per record access);
+// WS = false compiles every such test away (config 3: the whole state is in LDS).
+template <int R, bool WS>
+__global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
+    constexpr int ND = R - 1;
+    constexpr int NT = corridor_lds_knots(R);
+    // sweep state per own knot: LDL' factors of S_j (strict lower triangle + inverse pivots), x_j (first h_j,
+    // overwritten by the solution in the backward sweep) and the current position iterate z_j.  E_j = S_j^-1 M_j is
+    // NOT stored: it is re-derived from the factors where needed.
     constexpr int NL = R * (R - 1) / 2;
     constexpr int F_L = 0, F_DI = NL, F_X = NL + R, F_Z = NL + 2 * R, F = NL + 2 * R + 1;
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_slots = gridDim.x * blockDim.x;
-    // workspace: [wave][interior knot][field][lane] -- a wave's record of one knot is F consecutive 512-byte rows (one
-    // page, not F pages a batch-stride apart: the sweeps are latency-bound, TLB and DRAM-row locality matter)
-    const int kmax = (a.uniform > 0 ? a.uniform : a.max_segments) - 1;
-    double* __restrict__ ws = a.ws + (size_t)(slot >> 6) * (size_t)(kmax > 1 ? kmax : 1) * F * 64 + (slot & 63);
-    // The records of the last NT interior knots of a UNIFORM batch live in LDS instead (the forward sweep writes them
-    // last, the backward sweep reads them first): NT of M-1 knots less HBM traffic for the bandwidth-bound large batch
-    // (config 3: 4 of 15).  Ragged batches keep everything in HBM (NT = 0 instantiation): lanes of one wave would diverge on the test, and
-    // the tests alone cost the latency-bound ragged case 30 % (config 5: 2.76 -> 3.61 ms when they were left in).
-    constexpr int NT = LDS_KNOTS;
-    __shared__ double s_rec[NT > 0 ? NT * F * 64 : 1];
-    // knots k >= lds_from are in LDS; the ragged instantiation (NT = 0) compiles every test below away
-    const int lds_from = NT > 0 ? a.uniform - NT : 0;
-    const int lane = threadIdx.x & 63;
-    auto G = [&](int k, int f) -> double& { return ws[((size_t)(k - 1) * F + f) * 64]; };        // interior knot k = 1..M-1
-    auto S = [&](int k, int f) -> double& { return s_rec[((k - lds_from) * F + f) * 64 + lane]; };
-    auto ld_xz = [&](int k, double& x0, double& z) {
-        if (NT > 0 && k >= lds_from) { x0 = S(k, F_X); z = S(k, F_Z); } else { x0 = G(k, F_X); z = G(k, F_Z); }
+    __shared__ double s_rec[NT * F * 64];
+    const int lane = threadIdx.x;
+    const int isR = lane & 1;
+    double* const ws = a.ws + (size_t)blockIdx.x * (size_t)a.ws_knots * F * 64 + lane;  // only touched for slots >= NT
+    // record accessors: slot s is wave-uniform, so "LDS or workspace" is ONE scalar branch per record, not one per field
+    auto in_lds = [&](int s) -> bool { return !WS || s < NT; };
+    auto L = [&](int s, int f) -> double& { return s_rec[(s * F + f) * 64 + lane]; };
+    auto G = [&](int s, int f) -> double& { return ws[((size_t)(s - NT) * F + f) * 64]; };
+    auto ld_xz = [&](int s, double& x, double& z) {
+        if (in_lds(s)) { x = L(s, F_X); z = L(s, F_Z); } else { x = G(s, F_X); z = G(s, F_Z); }
     };
-    auto st_z = [&](int k, double z) { if (NT > 0 && k >= lds_from) S(k, F_Z) = z; else G(k, F_Z) = z; };
+    auto ld_rec = [&](int s, double (&r)[F]) {
+        if (in_lds(s)) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) r[f] = L(s, f);
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) r[f] = G(s, f);
+        }
+    };
+    auto st_x = [&](int s, const double (&x)[R]) {
+        if (in_lds(s)) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) L(s, F_X + q) = x[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) G(s, F_X + q) = x[q];
+        }
+    };
+    auto st_xz = [&](int s, const double (&x)[R], double z) {
+        st_x(s, x);
+        if (in_lds(s)) L(s, F_Z) = z; else G(s, F_Z) = z;
+    };
+    auto st_rec = [&](int s, const SmallLDL<R>& ldl, const double (&h)[R], double z) {
+        double r[F];
+        int f = 0;
+#pragma unroll
+        for (int i = 1; i < R; ++i)
+#pragma unroll
+            for (int c = 0; c < i; ++c) r[F_L + (f++)] = ldl.l[i][c];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { r[F_DI + i] = ldl.dinv[i]; r[F_X + i] = h[i]; }
+        r[F_Z] = z;
+        if (in_lds(s)) {
+#pragma unroll
+            for (int q = 0; q < F; ++q) L(s, q) = r[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < F; ++q) G(s, q) = r[q];
+        }
+    };
 
     const long long total = (long long)a.n_traj * 3;
-    for (long long g = slot; g < total; g += n_slots) {
-        const int b = (int)(g / 3), ax = (int)(g - 3LL * b);
-        int s0, M;
-        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
-        const size_t row0 = (size_t)(s0 + b);
-        const double* __restrict__ wp = a.waypoints + 3 * row0 + ax;  // stride 3 per knot
-        const double* __restrict__ lo = a.corr_lo + 3 * row0 + ax;
-        const double* __restrict__ hi = a.corr_hi + 3 * row0 + ax;
-        const double* __restrict__ T = a.times + s0;
-        const double* __restrict__ bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
-        double* __restrict__ out = a.coeff + (size_t)3 * NC * s0 + (size_t)ax * NC * M;
+    bool queue_empty = false;
 
-        bool ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;  // pin masks are 64-bit
-        if (ok)
-            for (int i = 0; i < M; ++i) ok = ok && (T[i] > 0.0) && (T[i] < INFINITY);
-        if (ok)
-            for (int k = 1; k < M; ++k) ok = ok && (lo[3 * k] <= hi[3 * k]);
-        if (!ok) {
-            atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
+    // ---- state of the problem this lane pair works on (identical in both lanes unless noted)
+    long long g = -1;            // problem = 3 * trajectory + axis, -1: none
+    int b = 0, M = 0, m = 0;     // m: own knots up to and including the meeting knot (lane-specific for odd M)
+    long long base3 = 0;         // bounds / Hermite solution of ORIGINAL knot k of this axis at index base3 + 3 k
+    int s0 = 0;                  // first segment of the trajectory in `times`
+    double x0[R];                // Hermite data of the own boundary knot, own frame (lane-specific)
+#pragma unroll
+    for (int i = 0; i < R; ++i) x0[i] = 0.0;
+    unsigned long long eqmask = 0ull, pin = 0ull, upper = 0ull;
+    int it = 0, pdas_left = 0;
+    bool final_pass = false;
+    // pending update of z, applied by the next forward sweep (zmode 0: none; 1: block-pivot round; 2: partial step
+    // of length zalpha blocked at knot zblock; 3: full step; 4: first sweep of a problem -- z from the clipped initial guess)
+    int zmode = 0, zblock = -1;
+    bool zblock_upper = false;
+    unsigned long long zpin = 0ull;
+    double zalpha = 1.0;
+
+    // original knot of own knot j / duration of own segment j, indices clamped into the trajectory (speculative loads of the
+    // branch-free sweeps stay in bounds; their values are discarded by the selects)
+    auto korig = [&](int j) -> int {
+        const int jc = j < 0 ? 0 : (j > M ? M : j);
+        return isR ? M - jc : jc;
+    };
+    auto bit = [&](unsigned long long mask, int k) -> bool { return (mask >> (k & 63)) & 1ull; };
+
+    for (;;) {
+        // ================= hand out problems to the free lane pairs =================
+        {
+            const bool need = g < 0;
+            const unsigned long long needm = __ballot(need);
+            if (needm != 0ull && !queue_empty) {
+                const int npairs = __popcll(needm) >> 1;
+                const int leader = (int)__builtin_ctzll(needm);
+                unsigned int qb = 0;
+                if (lane == leader) qb = atomicAdd(a.queue, (unsigned int)npairs);
+                qb = __shfl(qb, leader, 64);
+                if ((long long)qb + npairs >= total) queue_empty = true;
+                if (need) {
+                    const int rank = __popcll(needm & ((1ull << lane) - 1ull)) >> 1;  // pairs in front of this one
+                    const long long q = (long long)qb + rank;
+                    if (q < total) {
+                        const int bq = (int)(q / 3), ax = (int)(q - 3LL * bq);
+                        const int bn = a.order ? a.order[bq] : bq;
+                        int sn, Mn;
+                        if (a.uniform > 0) { Mn = a.uniform; sn = bn * Mn; } else { sn = a.seg_offsets[bn]; Mn = a.seg_offsets[bn + 1] - sn; }
+                        const long long basen = 3LL * ((long long)sn + bn) + ax;
+                        const double* wp = a.waypoints + basen;  // stride 3 per knot
+                        const double* lo = a.corr_lo + basen;
+                        const double* hi = a.corr_hi + basen;
+                        const double* T = a.times + sn;
+                        const double* bc = a.bc + (size_t)bn * 2 * ND * 3 + ax;
+                        bool ok = (Mn >= 1) && (a.uniform > 0 || Mn <= a.max_segments) && Mn <= 63;  // pin masks are 64-bit
+                        if (ok)
+                            for (int i = 0; i < Mn; ++i) ok = ok && (T[i] > 0.0) && (T[i] < INFINITY);
+                        if (ok)
+                            for (int k = 1; k < Mn; ++k) ok = ok && (lo[3 * k] <= hi[3 * k]);
+                        if (!ok) {
+                            if (!isR) atomicMin(&a.status[bn], (int32_t)UAVQP_INVALID_INPUT);
+                        } else if (Mn == 1) {
+                            // no interior knot: nothing to solve, the emission kernel builds the segment from the boundary data
+                            if (!isR && a.active) { a.active[2 * (3LL * bn + ax)] = 0ull; a.active[2 * (3LL * bn + ax) + 1] = 0ull; }
+                        } else {
+                            b = bn; M = Mn; s0 = sn; base3 = basen;
+                            g = 3LL * b + ax;
+                            m = isR ? M / 2 : (M + 1) / 2;
+                            // own boundary knot in the own frame: derivative d of the reversed problem picks up (-1)^d
+                            x0[0] = isR ? wp[3 * M] : wp[0];
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) {
+                                const double v = bc[((isR ? ND : 0) + d) * 3];
+                                x0[d + 1] = (isR && ((d & 1) == 0)) ? -v : v;
+                            }
+                            // permanent pins (lo == hi: a true equality row, as in the reference) and the first working set.
+                            // A warm start only supplies that set (bounds guessed active sit on their bound); wrong guesses
+                            // are repaired by the iterations below like any other intermediate working set.
+                            eqmask = 0ull; pin = 0ull; upper = 0ull;
+                            unsigned long long wpin = 0ull, wupper = 0ull;
+                            if (a.active && a.warm) { wpin = a.active[2 * g]; wupper = a.active[2 * g + 1]; }
+                            for (int k = 1; k < M; ++k) {
+                                const double l = lo[3 * k], h = hi[3 * k];
+                                if (l == h) eqmask |= 1ull << k;
+                                else if ((wpin >> k) & 1ull) {
+                                    pin |= 1ull << k;
+                                    if ((wupper >> k) & 1ull) upper |= 1ull << k;
+                                }
+                            }
+                            pin |= eqmask;
+                            // the first forward sweep (zmode 4) turns x = waypoint into the initial feasible iterate z
+                            for (int s = 0; s < m; ++s) {   // slot s = own knot m - s (lane-specific trip count: not a sweep)
+                                const double w = wp[3 * (isR ? M - (m - s) : (m - s))];
+                                if (in_lds(s)) { L(s, F_X) = w; L(s, F_Z) = 0.0; } else { G(s, F_X) = w; G(s, F_Z) = 0.0; }
+                            }
+                            it = 0;
+                            pdas_left = a.pdas_rounds;
+                            final_pass = false;
+                            zmode = 4; zblock = -1; zblock_upper = false; zpin = pin; zalpha = 1.0;
+                        }
+                    }
+                }
+            }
+        }
+        const bool act = g >= 0;
+        if (__ballot(act) == 0ull) {
+            if (queue_empty) break;
             continue;
         }
-        double x0[R], xM[R];
-        x0[0] = wp[0];
-        xM[0] = wp[3 * M];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            x0[d + 1] = bc[d * 3];
-            xM[d + 1] = bc[(ND + d) * 3];
-        }
+        const int mm = act ? m : 0;              // own knots of this lane: a free lane sweeps nothing
+        const int mmax = wave_max_small(mm);     // the wave sweeps as long as its longest half
+        const int off = mmax - mm;
 
-        // ---- initial feasible point and permanent pins (lo == hi: a true equality row, as in the reference)
-        // A warm start only supplies the first working set (bounds guessed active sit on their bound); wrong guesses
-        // are repaired by the iterations below like any other intermediate working set.
-        unsigned long long eqmask = 0ull, pin = 0ull, upper = 0ull;
-        unsigned long long wpin = 0ull, wupper = 0ull;
-        if (a.active && a.warm) {
-            wpin = a.active[2 * g];
-            wupper = a.active[2 * g + 1];
-        }
-        for (int k = 1; k < M; ++k) {
-            const double l = lo[3 * k], h = hi[3 * k];
-            double z = wp[3 * k];
-            z = z < l ? l : (z > h ? h : z);
-            if (l == h) {
-                eqmask |= 1ull << k;
-            } else if ((wpin >> k) & 1ull) {
-                const bool up = (wupper >> k) & 1ull;
-                z = up ? h : l;
-                pin |= 1ull << k;
-                if (up) upper |= 1ull << k;
-            }
-            st_z(k, z);
-        }
-        pin |= eqmask;
+        const double* const LO = a.corr_lo + base3;
+        const double* const HI = a.corr_hi + base3;
+        const double* const TT = a.times + s0;
+        // slot s <-> original knot kbase + ksign s, original segment of own segment (m - s) = tbase + ksign s
+        const int ksign = isR ? 1 : -1, kbase = isR ? M - mm : mm, tbase = isR ? M - 1 - mm : mm;
+        auto kslot = [&](int s) -> int { return kbase + ksign * s; };
+        auto kclamp = [&](int k) -> int { return min(max(k, 0), M); };                 // v_med3: speculative loads stay in bounds
+        auto tclamp = [&](int t) -> int { return max(min(t, M - 1), 0); };
+        // working-set masks in SLOT order (bit s = own knot m - s): the sweeps test them with wave-uniform shift counts
+        auto toslot = [&](unsigned long long msk) -> unsigned long long {
+            return isR ? (msk >> ((M - mm) & 63)) : (__brevll(msk) >> ((63 - mm) & 63));
+        };
+        auto fromslot = [&](unsigned long long msk) -> unsigned long long {
+            return isR ? (msk << ((M - mm) & 63)) : __brevll(msk << ((63 - mm) & 63));
+        };
+        const unsigned long long s_pin = toslot(pin), s_zpin = toslot(zpin), s_eq = toslot(eqmask), s_up = toslot(upper);
+        const int zslot = act ? (isR ? zblock - (M - mm) : mm - zblock) : -1;  // slot of the blocking knot (negative / beyond m: the other half's)
 
-        int it = 0;
-        int pdas_left = a.pdas_rounds;  // default 3 (measured on config 3: 3 rounds 13.8 mean iterations, 0 rounds 17.5, 10 rounds 15.7)
-        bool converged = (M == 1);
-        bool final_pass = false;  // max_iter hit: one last solve with every position pinned at the feasible iterate
-        // pending update of z, applied by the next forward sweep (zmode 0: none; 1: block-pivot round; 2: partial step
-        // of length zalpha blocked at knot zblock; 3: full step)
-        int zmode = 0, zblock = -1;
-        bool zblock_upper = false;
-        unsigned long long zpin = 0ull;
-        double zalpha = 1.0;
-        auto znew = [&](int k, double x0old, double zold, double l, double h) -> double {
-            const bool zp = (zpin >> k) & 1ull;
-            const double clipped = x0old < l ? l : (x0old > h ? h : x0old);
-            double z = zold;
-            if (zmode == 1) {
-                // every (newly) pinned position sits on its bound, the free ones keep a feasible iterate for the safe
-                // phase: the clipped subspace minimiser
-                z = zp ? (((eqmask >> k) & 1ull) ? zold : (((upper >> k) & 1ull) ? h : l)) : clipped;
-            } else if (zmode == 2) {
-                z = zp ? zold : (k == zblock ? (zblock_upper ? h : l) : zold + zalpha * (x0old - zold));
-            } else if (zmode == 3) {
-                z = zp ? zold : clipped;
-            }
-            return z;
+        // z update of the knot in slot s (znew of the header comment), select form.
+        //   1: block-pivot round -- every (newly) pinned position sits on its bound, the free ones keep a feasible iterate for the
+        //      safe phase: the clipped subspace minimiser;  2: partial step, the blocking knot lands on its bound;  3: full step;
+        //   4: first sweep -- x0old is the waypoint; equality rows and free positions start at the clipped waypoint, bounds guessed
+        //      active by a warm start at that bound;  0: nothing pending
+        const bool m14 = (zmode == 1) || (zmode == 4), m2 = zmode == 2, m0 = zmode == 0, m4 = zmode == 4;
+        auto znew = [&](int s, double x0old, double zold, double l, double h) -> double {
+            const bool zp = (s_zpin >> s) & 1ull, eq = (s_eq >> s) & 1ull, up = (s_up >> s) & 1ull;
+            const double clipped = fmin(fmax(x0old, l), h);
+            const double bound = up ? h : l;
+            const bool usebound = zp & !eq & m14;   // (bitwise on purpose: no short-circuit control flow in the sweeps)
+            const bool useold = m0 | (zp & !usebound & !m4);
+            const double step = (s == zslot) ? (zblock_upper ? h : l) : zold + zalpha * (x0old - zold);
+            const double freeval = m2 ? step : clipped;
+            return usebound ? bound : (useold ? zold : freeval);
         };
 
-        while (!converged) {
-            // ================= forward sweep: lazy z update + pinned block elimination =================
-            {
-                FullBlocks<R> sa;
-                sa.build(T[0]);
-                SmallLDL<R> lprev;
-                double hprev[R];
-                // raw fields of knot k+1 (old x[0], old z, bounds) are in flight while knot k is eliminated
-                double zp_ = 0.0, zc, zn = 0.0;
-                double nx0 = 0.0, nz = 0.0, nl = 0.0, nh = 0.0, Tn;  // knot k+1
+        // ================= forward sweep: lazy z update + pinned block elimination of own knots 1..m-1 =================
+        // Trip u works on own knot j = u - off - 1 (slot mmax - u + 1): (1) z of knot j+1 from the raw fields fetched one trip
+        // earlier, (2) fetch of the raw fields (old x[0], old z, bounds) of knot j+2 and of the next duration, (3) elimination of
+        // knot j (j >= 1).  The fetches of (2) are issued AFTER everything of the previous trip has been consumed (the waits the
+        // compiler places for those would otherwise cover the fresh loads too) and have the whole of (3) to land.
+        FullBlocks<R> sa;
+        SmallLDL<R> lprev;
+        double hprev[R];
+        double zp_ = 0.0, zc = 0.0, zn = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            hprev[i] = 0.0;
+            lprev.dinv[i] = 1.0;
+#pragma unroll
+            for (int c = 0; c < R; ++c) { lprev.l[i][c] = 0.0; sa.B11[i][c] = (i == c) ? 1.0 : 0.0; sa.B01[i][c] = 0.0; }
+        }
+        {
+            double rx = 0.0, rz = 0.0, rl = 0.0, rh = 0.0;
+            double Tn = TT[tclamp(tbase + ksign * (mmax + 1))];
+            for (int u = 0; u <= mmax; ++u) {
+                const int j = u - off - 1;
+                const int sj = mmax - u + 1;  // slot of own knot j; j + 1 <-> sj - 1, j + 2 <-> sj - 2
+                // (1)
+                const double Tcur = Tn;
                 {
-                    double fx, fz;
-                    ld_xz(1, fx, fz);
-                    zc = znew(1, fx, fz, lo[3], hi[3]);
+                    const double zv = znew(sj - 1, rx, rz, rl, rh);
+                    zn = (j >= 0) ? zv : zn;
                 }
-                if (M > 2) { ld_xz(2, nx0, nz); nl = lo[6]; nh = hi[6]; }
-                Tn = T[1];
-                for (int k = 1; k < M; ++k) {
-                    FullBlocks<R> sb;
-                    sb.build(Tn);
-                    if (k + 1 < M) zn = znew(k + 1, nx0, nz, nl, nh);
-                    if (k + 2 < M) { ld_xz(k + 2, nx0, nz); nl = lo[3 * (k + 2)]; nh = hi[3 * (k + 2)]; }
-                    if (k + 1 < M) Tn = T[k + 1];
-                    st_z(k, zc);
-                    const bool pk = (pin >> k) & 1ull;
-                    const bool pprev = (k > 1) && ((pin >> (k - 1)) & 1ull);
-                    const bool pnext = (k < M - 1) && ((pin >> (k + 1)) & 1ull);
+                __builtin_amdgcn_sched_barrier(0);
+                // (2)
+                Tn = TT[tclamp(tbase + ksign * (sj - 1))];   // own segment j + 1 = m - (sj - 1)
+                if (sj >= 2) ld_xz(sj - 2, rx, rz);
+                {
+                    const int k2 = 3 * kclamp(kslot(sj - 2));
+                    rl = LO[k2];
+                    rh = HI[k2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // (3)
+                FullBlocks<R> sb;
+                sb.build(Tcur);
+                if (u >= 2 && j >= 1) {   // (u >= 2: uniform; j >= 1: the halves that have started)
+                    const bool first = (j == 1);
+                    const bool pk = (s_pin >> sj) & 1ull;
+                    const bool pprev = !first & (bool)((s_pin >> (sj + 1)) & 1ull);
+                    const bool pnext = (s_pin >> (sj - 1)) & 1ull;  // own knot j+1 <= m: an interior knot (the meeting knot at the latest)
                     double D[R][R], rhs[R];
+                    // what is KNOWN of the previous knot: all of it for the boundary knot, its position when pinned, nothing else
+                    double kn[R];
+                    kn[0] = first ? x0[0] : (pprev ? zp_ : 0.0);
+#pragma unroll
+                    for (int c = 1; c < R; ++c) kn[c] = first ? x0[c] : 0.0;
+                    const double znm = pnext ? zn : 0.0, zcm = pk ? zc : 0.0;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        rhs[i] = 0.0;
+                        double acc = -sb.B01[i][0] * znm;
+#pragma unroll
+                        for (int c = 0; c < R; ++c) acc -= sa.B01[c][i] * kn[c];
+                        rhs[i] = acc;
 #pragma unroll
                         for (int c = 0; c < R; ++c) D[i][c] = sa.B11[i][c] + sb.B00(i, c);
                     }
-                    if (k == 1) {
 #pragma unroll
-                        for (int i = 0; i < R; ++i)
-#pragma unroll
-                            for (int c = 0; c < R; ++c) rhs[i] -= sa.B01[c][i] * x0[c];
-                    } else if (pprev) {
-#pragma unroll
-                        for (int i = 0; i < R; ++i) rhs[i] -= sa.B01[0][i] * zp_;
+                    for (int i = 1; i < R; ++i) {
+                        rhs[i] -= D[i][0] * zcm;
+                        D[i][0] = pk ? 0.0 : D[i][0];
                     }
-                    if (k == M - 1) {
+                    D[0][0] = pk ? 1.0 : D[0][0];
+                    rhs[0] = pk ? zc : rhs[0];
+                    // masked coupling block between (j-1, j) and E = S_{j-1}^-1 Mp from the previous factors (all zero for j = 1)
+                    double Mp[R][R], Ep[R][R];
 #pragma unroll
-                        for (int i = 0; i < R; ++i)
+                    for (int i = 0; i < R; ++i)
 #pragma unroll
-                            for (int c = 0; c < R; ++c) rhs[i] -= sb.B01[i][c] * xM[c];
-                    } else if (pnext) {
+                        for (int c = 0; c < R; ++c) Mp[i][c] = (first | (pprev & (i == 0)) | (pk & (c == 0))) ? 0.0 : sa.B01[i][c];
 #pragma unroll
-                        for (int i = 0; i < R; ++i) rhs[i] -= sb.B01[i][0] * zn;
+                    for (int c = 0; c < R; ++c) {
+                        double col[R];
+#pragma unroll
+                        for (int i = 0; i < R; ++i) col[i] = Mp[i][c];
+                        lprev.solve(col);
+#pragma unroll
+                        for (int i = 0; i < R; ++i) Ep[i][c] = col[i];
                     }
-                    if (pk) {
 #pragma unroll
-                        for (int i = 1; i < R; ++i) {
-                            rhs[i] -= D[i][0] * zc;
-                            D[i][0] = 0.0;
-                            D[0][i] = 0.0;
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int q = 0; q < R; ++q) {
+#pragma unroll
+                            for (int c = 0; c <= i; ++c) D[i][c] -= Mp[q][i] * Ep[q][c];
+                            rhs[i] -= Mp[q][i] * hprev[q];
                         }
-                        D[0][0] = 1.0;
-                        rhs[0] = zc;
-                    }
-                    if (k > 1) {
-                        // masked coupling block between (k-1, k) and E = S_{k-1}^-1 Mp from the previous factors
-                        double Mp[R][R], Ep[R][R];
-#pragma unroll
-                        for (int i = 0; i < R; ++i)
-#pragma unroll
-                            for (int c = 0; c < R; ++c) Mp[i][c] = ((pprev && i == 0) || (pk && c == 0)) ? 0.0 : sa.B01[i][c];
-#pragma unroll
-                        for (int c = 0; c < R; ++c) {
-                            double col[R];
-#pragma unroll
-                            for (int i = 0; i < R; ++i) col[i] = Mp[i][c];
-                            lprev.solve(col);
-#pragma unroll
-                            for (int i = 0; i < R; ++i) Ep[i][c] = col[i];
-                        }
-#pragma unroll
-                        for (int i = 0; i < R; ++i)
-#pragma unroll
-                            for (int q = 0; q < R; ++q) {
-#pragma unroll
-                                for (int c = 0; c <= i; ++c) D[i][c] -= Mp[q][i] * Ep[q][c];
-                                rhs[i] -= Mp[q][i] * hprev[q];
-                            }
-                    }
                     SmallLDL<R> ldl;
                     ldl.factor(D);
                     ldl.solve(rhs);
-                    auto put = [&](auto&& at) {   // factors + h of knot k, straight from the registers they were computed in
-                        int f = 0;
-#pragma unroll
-                        for (int i = 1; i < R; ++i)
-#pragma unroll
-                            for (int c = 0; c < i; ++c) at(F_L + (f++)) = ldl.l[i][c];
-#pragma unroll
-                        for (int i = 0; i < R; ++i) {
-                            at(F_DI + i) = ldl.dinv[i];
-                            at(F_X + i) = rhs[i];
-                        }
-                    };
-                    if (NT > 0 && k >= lds_from) put([&](int q) -> double& { return S(k, q); });
-                    else put([&](int q) -> double& { return G(k, q); });
+                    st_rec(sj, ldl, rhs, zc);  // factors + h + z of knot j
 #pragma unroll
                     for (int i = 0; i < R; ++i) hprev[i] = rhs[i];
                     lprev = ldl;
-                    sa = sb;
-                    zp_ = zc;
-                    zc = zn;
                 }
+                sa = sb;
+                zp_ = zc;
+                zc = zn;
             }
-            zmode = 0;
+        }
+        zmode = 0;
 
-            // ================= backward sweep: x_k = h_k - S_k^-1 (M_k x_{k+1}) + the decisions of this iteration ======
-            // The record of knot k-1 (factors, h, z) and its bounds are fetched while knot k is processed.
-            const bool pdas = pdas_left > 0;
-            unsigned long long npin = eqmask, nupper = 0ull;  // block-pivot round
-            double alpha = 1.0, worst = 0.0;                    // ratio test / worst wrong-signed multiplier
-            int block = -1, rel = -1;
-            bool block_upper = false;
+        // ================= meeting knot (own knot m, slot 0): own partial Schur complement, exchange, solve =================
+        // sa = blocks of the last own segment m-1, lprev / hprev = factors and h of own knot m-1, zp_ / zc = z of knots m-1 / m.
+        double xn[R];  // solution at the meeting knot, own frame
+        const bool pc = act && (s_pin & 1ull);
+        {
+            const bool first = (mm <= 1);
+            const bool pprev = !first & (bool)((s_pin >> 1) & 1ull);
+            double P[R][R], q[R], kn[R];
+            kn[0] = first ? x0[0] : (pprev ? zp_ : 0.0);
+#pragma unroll
+            for (int c = 1; c < R; ++c) kn[c] = first ? x0[c] : 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < R; ++c) acc -= sa.B01[c][i] * kn[c];
+                q[i] = acc;
+#pragma unroll
+                for (int c = 0; c < R; ++c) P[i][c] = sa.B11[i][c];
+            }
+            double Mp[R][R], Ep[R][R];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int c = 0; c < R; ++c) Mp[i][c] = (first | (pprev & (i == 0)) | (pc & (c == 0))) ? 0.0 : sa.B01[i][c];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                double col[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) col[i] = Mp[i][c];
+                lprev.solve(col);
+#pragma unroll
+                for (int i = 0; i < R; ++i) Ep[i][c] = col[i];
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int qq = 0; qq < R; ++qq) {
+#pragma unroll
+                    for (int c = 0; c <= i; ++c) P[i][c] -= Mp[qq][i] * Ep[qq][c];
+                    q[i] -= Mp[qq][i] * hprev[qq];
+                }
+            // S = P_own + F P_other F,  rhs = q_own + F q_other,  F = diag((-1)^d): the partner's frame is the reversed one
+            double S[R][R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+#pragma unroll
+                for (int c = 0; c <= i; ++c) {
+                    const double o = swap_pair(P[i][c]);
+                    S[i][c] = P[i][c] + (((i + c) & 1) ? -o : o);
+                }
+#pragma unroll
+                for (int c = i + 1; c < R; ++c) S[i][c] = 0.0;  // upper triangle is never read
+                const double o = swap_pair(q[i]);
+                xn[i] = q[i] + ((i & 1) ? -o : o);
+            }
+            const double zcm = pc ? zc : 0.0;
+#pragma unroll
+            for (int i = 1; i < R; ++i) {
+                xn[i] -= S[i][0] * zcm;
+                S[i][0] = pc ? 0.0 : S[i][0];
+            }
+            S[0][0] = pc ? 1.0 : S[0][0];
+            xn[0] = pc ? zc : xn[0];
+            SmallLDL<R> ldl;
+            ldl.factor(S);
+            ldl.solve(xn);
+            if (act) st_xz(0, xn, zc);
+        }
+
+        // ================= backward sweep: x_j = h_j - S_j^-1 (M_j x_{j+1}) + the decisions of this iteration ======
+        // Trip i works on own knot j = m - 1 - i (slot i + 1; j = 0: the boundary knot, j < 0: this half is finished); the
+        // record of knot j-1 (factors, h, z) and its bounds are fetched while knot j is processed.  Decisions are gathered in
+        // SLOT numbering and translated to original knot numbers afterwards.
+        constexpr int NONE = 1 << 30;
+        unsigned long long np_s = 0ull, nu_s = 0ull;       // block-pivot round (slot order)
+        double alpha = 1.0, worst = 0.0;                    // ratio test / worst wrong-signed multiplier
+        int block = NONE, rel = NONE;                       // ORIGINAL knot numbers; ties go to the lowest knot
+        bool block_upper = false;
+        {
+            {   // free meeting knot outside its box?  (both lanes of the pair take the same decision)
+                const int kc = kclamp(kslot(0));
+                const double lk = LO[3 * kc], hk = HI[3 * kc], ph = xn[0];
+                const bool below = ph < lk - 1e-12 * (1.0 + fabs(lk));
+                const bool above = !below & (ph > hk + 1e-12 * (1.0 + fabs(hk)));
+                const bool v = act & !pc & (below | above);
+                np_s |= (unsigned long long)v;
+                nu_s |= (unsigned long long)(v & above);
+                const double al = ((above ? hk : lk) - zc) / (ph - zc);
+                alpha = v ? al : alpha;
+                block = v ? kc : block;
+                block_upper = v ? above : block_upper;
+            }
+            double nx[F], nl, nh, Tn;       // record of the knot processed next
+            double lamA = 0.0, magA = 0.0;  // part of knot (j+1)'s multiplier known before x_j is
+#pragma unroll
+            for (int f = 0; f < F; ++f) nx[f] = 0.0;
+            if (mmax >= 2) ld_rec(1, nx);
             {
-                double xn[R], nx[F], nl, nh, Tn;  // record of the knot processed next
-                double lamA = 0.0, magA = 0.0;  // part of knot (k+1)'s multiplier known before x_k is
-#pragma unroll
-                for (int f = 0; f < F; ++f) nx[f] = (NT > 0 && M - 1 >= lds_from) ? S(M - 1, f) : G(M - 1, f);
-                nl = lo[3 * (M - 1)];
-                nh = hi[3 * (M - 1)];
-                Tn = T[M - 1];
-#pragma unroll
-                for (int i = 0; i < R; ++i) xn[i] = xM[i];
-                for (int k = M - 1; k >= 0; --k) {
-                    // segment k: inverse powers of its duration, coupling block B01 and the row-0 pieces
-                    const double itv = fast_rcp(Tn);
-                    double ip[2 * R];
-                    ip[0] = 1.0;
-#pragma unroll
-                    for (int j = 1; j < 2 * R; ++j) ip[j] = ip[j - 1] * itv;
-                    SegRow0<R> s0r;
-#pragma unroll
-                    for (int c = 0; c < R; ++c) {
-                        const double p = ip[2 * R - 1 - c];
-                        s0r.e11[c] = p * Tab<R>::W(0, c);
-                        s0r.e01r[c] = -p * Tab<R>::V(0, c);
-                        s0r.e01c[c] = -p * Tab<R>::V(c, 0);
-                    }
-                    double x[R];
-                    double zk = 0.0, lk = 0.0, hk = 0.0;
-                    if (k >= 1) {
-                        double cur[F];
-#pragma unroll
-                        for (int f = 0; f < F; ++f) cur[f] = nx[f];
-                        lk = nl;
-                        hk = nh;
-                        zk = cur[F_Z];
-                        if (k >= 2) {
-                            if (NT > 0 && k - 1 >= lds_from) {
-#pragma unroll
-                                for (int f = 0; f < F; ++f) nx[f] = S(k - 1, f);
-                            } else {
-#pragma unroll
-                                for (int f = 0; f < F; ++f) nx[f] = G(k - 1, f);
-                            }
-                            nl = lo[3 * (k - 1)];
-                            nh = hi[3 * (k - 1)];
-                        }
-                        Tn = T[k - 1];
-#pragma unroll
-                        for (int i = 0; i < R; ++i) x[i] = cur[F_X + i];
-                        if (k < M - 1) {
-                            const bool pk = (pin >> k) & 1ull;
-                            const bool pnext = (pin >> (k + 1)) & 1ull;
-                            double t[R];
-#pragma unroll
-                            for (int i = 0; i < R; ++i) {
-                                double acc = 0.0;
-#pragma unroll
-                                for (int c = 0; c < R; ++c) {
-                                    const double m = -ip[2 * R - 1 - i - c] * Tab<R>::V(i, c);  // B01 of segment k
-                                    acc += (((pk && i == 0) || (pnext && c == 0)) ? 0.0 : m) * xn[c];
-                                }
-                                t[i] = acc;
-                            }
-                            SmallLDL<R> ldl;
-                            {
-                                int f = 0;
-#pragma unroll
-                                for (int i = 1; i < R; ++i)
-#pragma unroll
-                                    for (int c = 0; c < i; ++c) ldl.l[i][c] = cur[F_L + (f++)];
-                            }
-#pragma unroll
-                            for (int i = 0; i < R; ++i) ldl.dinv[i] = cur[F_DI + i];
-                            ldl.solve(t);
-#pragma unroll
-                            for (int i = 0; i < R; ++i) x[i] -= t[i];
-                            if (NT > 0 && k >= lds_from) {
-#pragma unroll
-                                for (int i = 0; i < R; ++i) S(k, F_X + i) = x[i];
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < R; ++i) G(k, F_X + i) = x[i];
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < R; ++i) x[i] = x0[i];
-                    }
-                    // ---- multiplier of knot j = k+1, now that x_k is known: d(cost)/d p_j (up to the factor 2), row 0 of
-                    // the unmasked block row;  lower bound active: need lam >= 0, upper: lam <= 0
-                    if (k + 1 <= M - 1) {
-                        const int j = k + 1;
-                        double lam = lamA, mag = magA;
-#pragma unroll
-                        for (int c = 0; c < R; ++c) {
-                            const double t1 = s0r.e01c[c] * x[c], t2 = s0r.e11[c] * xn[c];
-                            lam += t1 + t2;
-                            mag += fabs(t1) + fabs(t2);
-                        }
-                        const bool pj = (pin >> j) & 1ull, ej = (eqmask >> j) & 1ull, uj = (upper >> j) & 1ull;
-                        const double viol = uj ? lam : -lam;
-                        const bool wrong = viol > 1e-13 * mag;  // rounding of lam is a few ulp of mag; 1e-11 let a 4e-4-relative wrong-signed multiplier pass on T^-7-scaled blocks (tools/soak.py, seed 11)
-                        if (pj && !ej) {
-                            if (!wrong) {  // multiplier has the right sign: stays active in a block-pivot round
-                                npin |= 1ull << j;
-                                if (uj) nupper |= 1ull << j;
-                            } else if (viol > worst || (viol == worst && rel >= 0)) {  // ties: the lowest knot, as an ascending scan
-                                worst = viol;
-                                rel = j;
-                            }
-                        }
-                    }
-                    if (k >= 1) {
-                        // ---- first half of knot k's multiplier (needs x_k and x_{k+1} only)
-                        lamA = 0.0;
-                        magA = 0.0;
-#pragma unroll
-                        for (int c = 0; c < R; ++c) {
-                            const double t2 = ((c & 1) ? -s0r.e11[c] : s0r.e11[c]) * x[c], t3 = s0r.e01r[c] * xn[c];
-                            lamA += t2 + t3;
-                            magA += fabs(t2) + fabs(t3);
-                        }
-                        // ---- free position: outside its box?
-                        if (!((pin >> k) & 1ull)) {
-                            const double ph = x[0];
-                            const bool below = ph < lk - 1e-12 * (1.0 + fabs(lk));
-                            const bool above = !below && (ph > hk + 1e-12 * (1.0 + fabs(hk)));
-                            if (below || above) {
-                                npin |= 1ull << k;
-                                if (above) nupper |= 1ull << k;
-                                const double al = ((above ? hk : lk) - zk) / (ph - zk);
-                                if (al < alpha || (al == alpha && block >= 0)) { alpha = al; block = k; block_upper = above; }
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < R; ++i) xn[i] = x[i];
-                    }
-                }
+                const int k1 = 3 * kclamp(kslot(1));
+                nl = LO[k1];
+                nh = HI[k1];
+                Tn = TT[tclamp(tbase + ksign)];   // own segment m - 1
             }
-            if (final_pass) break;
+            for (int i = 0; i < mmax; ++i) {
+                const int j = mm - 1 - i;
+                const bool on = j >= 0, interior = j >= 1;
+                double cur[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) cur[f] = nx[f];
+                const double lk = nl, hk = nh, zk = cur[F_Z], Tcur = Tn;
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 2 < mmax) ld_rec(i + 2, nx);   // uniform: slot i + 2 = own knot j - 1
+                {
+                    const int k1 = 3 * kclamp(kslot(i + 2));
+                    nl = LO[k1];
+                    nh = HI[k1];
+                    Tn = TT[tclamp(tbase + ksign * (i + 2))];   // own segment j - 1 = m - (i + 2)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // own segment j: inverse powers of its duration and the row-0 pieces of its blocks
+                const double itv = fast_rcp(Tcur);
+                double ip[2 * R];
+                ip[0] = 1.0;
+#pragma unroll
+                for (int q = 1; q < 2 * R; ++q) ip[q] = ip[q - 1] * itv;
+                double e11[R], e01r[R], e01c[R];  // B11_s[0][c], B01_s[0][c], B01_s[c][0]
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const double p = ip[2 * R - 1 - c];
+                    e11[c] = p * Tab<R>::W(0, c);
+                    e01r[c] = -p * Tab<R>::V(0, c);
+                    e01c[c] = -p * Tab<R>::V(c, 0);
+                }
+                const bool pk = (s_pin >> (i + 1)) & 1ull;      // own knot j
+                const bool pj = (s_pin >> i) & 1ull;            // own knot j + 1
+                // x_j for an interior knot (speculative for j <= 0: discarded below)
+                double x[R];
+                {
+                    double t[R];
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int c = 0; c < R; ++c) {
+                            const double mv = -ip[2 * R - 1 - q - c] * Tab<R>::V(q, c);  // B01 of own segment j
+                            acc += (((pk & (q == 0)) | (pj & (c == 0))) ? 0.0 : mv) * xn[c];
+                        }
+                        t[q] = acc;
+                    }
+                    SmallLDL<R> ldl;
+                    {
+                        int f = 0;
+#pragma unroll
+                        for (int q = 1; q < R; ++q)
+#pragma unroll
+                            for (int c = 0; c < q; ++c) ldl.l[q][c] = cur[F_L + (f++)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < R; ++q) ldl.dinv[q] = cur[F_DI + q];
+                    ldl.solve(t);
+#pragma unroll
+                    for (int q = 0; q < R; ++q) x[q] = interior ? cur[F_X + q] - t[q] : x0[q];
+                }
+                if (interior) st_x(i + 1, x);
+                // ---- multiplier of own knot j+1, now that x_j is known: d(cost)/d p (up to the factor 2), row 0 of
+                // the unmasked block row;  lower bound active: need lam >= 0, upper: lam <= 0.  For the meeting knot (first
+                // trip) the other half of the row comes from the partner lane (a scalar: frame-independent).
+                double own = 0.0, omag = 0.0;
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const double t1 = e01c[c] * x[c], t2 = e11[c] * xn[c];
+                    own += t1 + t2;
+                    omag += fabs(t1) + fabs(t2);
+                }
+                if (i == 0) {
+                    lamA = swap_pair(own);
+                    magA = swap_pair(omag);
+                }
+                {
+                    const int kj = kslot(i);
+                    const double lam = lamA + own, mag = magA + omag;
+                    const bool ej = (s_eq >> i) & 1ull, uj = (s_up >> i) & 1ull;
+                    const double viol = uj ? lam : -lam;
+                    // rounding of lam is a few ulp of mag; 1e-11 let a 4e-4-relative wrong-signed multiplier pass on T^-7-scaled
+                    // blocks (tools/soak.py, seed 11)
+                    const bool wrong = viol > 1e-13 * mag;
+                    const bool cand = on & pj & !ej;
+                    const bool keep = cand & !wrong;   // multiplier has the right sign: stays active in a block-pivot round
+                    np_s |= (unsigned long long)keep << i;
+                    nu_s |= (unsigned long long)(keep & uj) << i;
+                    const bool take = cand & wrong & ((viol > worst) | ((viol == worst) & (kj < rel)));
+                    worst = take ? viol : worst;
+                    rel = take ? kj : rel;
+                }
+                // ---- first half of own knot j's multiplier (needs x_j and x_{j+1} only)
+                lamA = 0.0;
+                magA = 0.0;
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const double t2 = ((c & 1) ? -e11[c] : e11[c]) * x[c], t3 = e01r[c] * xn[c];
+                    lamA += t2 + t3;
+                    magA += fabs(t2) + fabs(t3);
+                }
+                {   // ---- free position: outside its box?
+                    const int kk = kslot(i + 1);
+                    const double ph = x[0];
+                    const bool below = ph < lk - 1e-12 * (1.0 + fabs(lk));
+                    const bool above = !below & (ph > hk + 1e-12 * (1.0 + fabs(hk)));
+                    const bool v = interior & !pk & (below | above);
+                    np_s |= (unsigned long long)v << (i + 1);
+                    nu_s |= (unsigned long long)(v & above) << (i + 1);
+                    const double al = ((above ? hk : lk) - zk) / (ph - zk);
+                    const bool take = v & ((al < alpha) | ((al == alpha) & (kk < block)));
+                    alpha = take ? al : alpha;
+                    block = take ? kk : block;
+                    block_upper = take ? above : block_upper;
+                }
+#pragma unroll
+                for (int q = 0; q < R; ++q) xn[q] = x[q];
+            }
+        }
+        // ---- combine the decisions of the two halves (identical values in both lanes afterwards)
+        unsigned long long npin = eqmask | fromslot(np_s), nupper = fromslot(nu_s);
+        {
+            npin |= swap_pair_u64(npin);
+            nupper |= swap_pair_u64(nupper);
+            const double oa = swap_pair(alpha), ow = swap_pair(worst);
+            const int ob = swap_pair_i(block), obu = swap_pair_i(block_upper ? 1 : 0), orl = swap_pair_i(rel);
+            if (oa < alpha || (oa == alpha && ob < block)) { alpha = oa; block = ob; block_upper = obu != 0; }
+            if (ow > worst || (ow == worst && orl < rel)) { worst = ow; rel = orl; }
+        }
 
-            // ================= block-pivoting warm-up (primal-dual active set) =================
-            // The first iterations change the whole working set at once: every free position outside its box is
-            // pinned at the violated bound, every pinned one whose multiplier has the wrong sign is released.
-            // It usually identifies the active set in 2-3 solves (vs one change per solve) but is not monotone, so
-            // after PDAS_ITERS rounds the safe single-pivot method below takes over from the clipped (feasible) point.
-            if (pdas) {
+        bool done = false;
+        if (act) {
+            if (final_pass) {
+                done = true;
+            } else if (pdas_left > 0) {
+                // ---- block-pivoting warm-up (primal-dual active set): the first iterations change the whole working set at
+                // once: every free position outside its box is pinned at the violated bound, every pinned one whose multiplier
+                // has the wrong sign is released.  It usually identifies the active set in 2-3 solves (vs one change per solve)
+                // but is not monotone, so after pdas_rounds rounds the safe single-pivot method takes over from the clipped
+                // (feasible) point.
                 ++it;
                 if (npin == pin && nupper == upper) {  // KKT point: free positions feasible, all multipliers right
-                    converged = true;
-                    continue;
+                    done = true;
+                } else {
+                    --pdas_left;
+                    zmode = 1;
+                    zpin = npin;
+                    pin = npin;
+                    upper = nupper;
+                    if (it >= a.max_iter) { pin = ~0ull; final_pass = true; }
                 }
-                --pdas_left;
-                zmode = 1;
-                zpin = npin;
-                pin = npin;
-                upper = nupper;
-                if (it >= a.max_iter) { pin = ~0ull; final_pass = true; }
-                continue;
-            }
-
-            // ================= safe phase: primal active set, one change per solve =================
-            if (block >= 0) {
-                // partial step to the first blocking bound, which joins the working set
-                zmode = 2;
-                zpin = pin;
-                zblock = block;
-                zblock_upper = block_upper;
-                zalpha = alpha < 0.0 ? 0.0 : alpha;
-                pin |= 1ull << block;
-                if (block_upper) upper |= 1ull << block; else upper &= ~(1ull << block);
             } else {
-                // full step: free positions move to the subspace minimiser; release the worst wrong-signed multiplier
-                if (rel < 0) {
+                // ---- safe phase: primal active set, one change per solve
+                bool converged = false;
+                if (block != NONE) {
+                    // partial step to the first blocking bound, which joins the working set
+                    zmode = 2;
+                    zpin = pin;
+                    zblock = block;
+                    zblock_upper = block_upper;
+                    zalpha = alpha < 0.0 ? 0.0 : alpha;
+                    pin |= 1ull << block;
+                    if (block_upper) upper |= 1ull << block; else upper &= ~(1ull << block);
+                } else if (rel == NONE) {
                     converged = true;
                 } else {
+                    // full step: free positions move to the subspace minimiser; release the worst wrong-signed multiplier
                     zmode = 3;
                     zpin = pin;
                     pin &= ~(1ull << rel);
                 }
-            }
-            ++it;
-            if (!converged && it >= a.max_iter) {
-                pin = ~0ull;  // freeze the feasible iterate, re-solve the derivatives only
-                final_pass = true;
+                ++it;
+                if (converged) done = true;
+                else if (it >= a.max_iter) {
+                    pin = ~0ull;  // freeze the feasible iterate, re-solve the derivatives only
+                    final_pass = true;
+                }
             }
         }
 
-        // ================= emission (record of knot k-1 in flight while segment k is written) =================
-        double xe[R];
+        // ================= a finished pair hands over its Hermite solution and frees its slot =================
+        if (__ballot(done) != 0ull) {
+            for (int s = 0; s < mmax; ++s) {   // slot s = own knot m - s
+                const int j = mm - s;
+                if (done && j >= 1 && (s > 0 || !isR)) {  // the meeting knot is written by the L lane
+                    const int kk = korig(j);
+                    double rec[F], xs[R];
+                    ld_rec(s, rec);
 #pragma unroll
-        for (int i = 0; i < R; ++i) xe[i] = xM[i];
-        bool finite = true;
-        double nxs[R + 1], Tn = T[M - 1];
-        if (M >= 2) {
+                    for (int q = 0; q < R; ++q) xs[q] = rec[F_X + q];
+                    if (bit(pin, kk)) xs[0] = rec[F_Z];  // pinned positions: exact bound value
+                    double* o = a.xsol + (base3 + 3LL * kk) * R;
 #pragma unroll
-            for (int i = 0; i < R; ++i) nxs[i] = (NT > 0 && M - 1 >= lds_from) ? S(M - 1, F_X + i) : G(M - 1, F_X + i);
-            nxs[R] = (NT > 0 && M - 1 >= lds_from) ? S(M - 1, F_Z) : G(M - 1, F_Z);
-        }
-        for (int k = M - 1; k >= 0; --k) {
-            double xs[R];
-            const double Tk = Tn;
-            if (k == 0) {
-#pragma unroll
-                for (int i = 0; i < R; ++i) xs[i] = x0[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < R; ++i) xs[i] = nxs[i];
-                if (!final_pass && ((pin >> k) & 1ull)) xs[0] = nxs[R];  // pinned positions: exact bound value
-                if (k >= 2) {
-                    if (NT > 0 && k - 1 >= lds_from) {
-#pragma unroll
-                        for (int i = 0; i < R; ++i) nxs[i] = S(k - 1, F_X + i);
-                        nxs[R] = S(k - 1, F_Z);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < R; ++i) nxs[i] = G(k - 1, F_X + i);
-                        nxs[R] = G(k - 1, F_Z);
-                    }
+                    for (int q = 0; q < R; ++q) o[q] = (isR && (q & 1)) ? -xs[q] : xs[q];  // back to the original frame
                 }
-                Tn = T[k - 1];
             }
-            double ys[ND], ye[ND], c[NC];
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                ys[d] = xs[d + 1];
-                ye[d] = xe[d + 1];
+            if (done && !isR) {
+                if (final_pass) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
+                if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
+                if (a.active) {
+                    const unsigned long long valid = ((1ull << M) - 2ull);  // bits 1..M-1 (M >= 2 here)
+                    const unsigned long long fin = final_pass ? 0ull : (pin & ~eqmask & valid);
+                    a.active[2 * g] = fin;
+                    a.active[2 * g + 1] = upper & fin;
+                }
             }
-            segment_coeffs<R>(xs[0], ys, xe[0], ye, Tk, fast_rcp(Tk), c);
-            double* o = out + (size_t)k * NC;
-#pragma unroll
-            for (int j = 0; j < NC; ++j) o[j] = c[j];
-            finite = finite && (fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY);
-#pragma unroll
-            for (int i = 0; i < R; ++i) xe[i] = xs[i];
+            if (done) { g = -1; m = 0; }
         }
-        if (!finite) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
-        else if (final_pass) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
-        if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
-        if (a.active) {
-            const unsigned long long valid = M >= 2 ? ((1ull << M) - 2ull) : 0ull;  // bits 1..M-1
-            const unsigned long long fin = final_pass ? 0ull : (pin & ~eqmask & valid);
-            a.active[2 * g] = fin;
-            a.active[2 * g + 1] = upper & fin;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Hermite solution -> monomial coefficients (ascending powers, segment-local time: the reference's coef_1d_ layout,
+// minimum_control.cpp:186).  One lane per (trajectory, axis, segment): lane e writes the e-th 2r-coefficient chunk of
+// the output, so consecutive lanes write consecutive 48- / 64-byte chunks.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void corridor_emit_kernel(CorridorArgs a, long long total_chunks) {
+    constexpr int ND = R - 1, NC = 2 * R;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total_chunks; e += (long long)gridDim.x * blockDim.x) {
+        int b, s0, M;
+        if (a.uniform > 0) {
+            M = a.uniform;
+            b = (int)(e / (3LL * M));
+            s0 = b * M;
+        } else {
+            // chunk e belongs to the trajectory b with 3 seg_offsets[b] <= e < 3 seg_offsets[b+1]
+            int lo_b = 0, hi_b = a.n_traj - 1;
+            while (lo_b < hi_b) {
+                const int mid = (lo_b + hi_b + 1) >> 1;
+                if (3LL * a.seg_offsets[mid] <= e) lo_b = mid; else hi_b = mid - 1;
+            }
+            b = lo_b;
+            s0 = a.seg_offsets[b];
+            M = a.seg_offsets[b + 1] - s0;
         }
+        const int st = a.status[b];
+        if (st == UAVQP_INVALID_INPUT || M < 1) continue;  // left untouched
+        const int rem = (int)(e - 3LL * s0), ax = rem / M, k = rem - ax * M;
+        const size_t row0 = (size_t)(s0 + b);
+        const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+        double p0, p1, ys[ND], ye[ND];
+        if (k == 0) {
+            p0 = a.waypoints[3 * row0 + ax];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) ys[d] = bc[d * 3];
+        } else {
+            const double* x = a.xsol + (3 * (row0 + k) + ax) * R;
+            p0 = x[0];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) ys[d] = x[d + 1];
+        }
+        if (k == M - 1) {
+            p1 = a.waypoints[3 * (row0 + M) + ax];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) ye[d] = bc[(ND + d) * 3];
+        } else {
+            const double* x = a.xsol + (3 * (row0 + k + 1) + ax) * R;
+            p1 = x[0];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) ye[d] = x[d + 1];
+        }
+        const double Tk = a.times[s0 + k];
+        double c[NC];
+        segment_coeffs<R>(p0, ys, p1, ye, Tk, fast_rcp(Tk), c);
+        double* o = a.coeff + (size_t)e * NC;
+        if ((reinterpret_cast<uintptr_t>(a.coeff) & 15u) == 0) {  // uniform: 16-byte stores unless the caller passed an odd view
+#pragma unroll
+            for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(o + q) = make_double2(c[q], c[q + 1]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) o[q] = c[q];
+        }
+        if (!((fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY))) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
     }
 }
 

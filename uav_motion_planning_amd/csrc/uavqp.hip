@@ -1088,29 +1088,52 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     a.pdas_rounds = ctx->settings.corridor_pdas_rounds;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.coeff = d_coeff_out; a.status = d_status_out; a.iters = d_iters_out;
-    const int block = 64;
-    long long lanes = 3LL * n_traj;
-    long long grid = (lanes + block - 1) / block;
-    const long long max_grid = (long long)ctx->num_cus * 8;  // measured on config 3: 2 waves/CU 3.68 ms, 4: 2.30, 6: 2.02, 8: 2.01
+    // Persistent single-wave workgroups, one per SIMD (the sweep state of a lane pair lives in LDS: 4 x 40 KiB per CU),
+    // 32 problems in flight per wave, refilled from the work counter.
+    const long long pairs = 3LL * n_traj;
+    long long grid = (pairs + 31) / 32;
+    const long long max_grid = (long long)ctx->num_cus * 4;
     if (grid > max_grid) grid = max_grid;
-    const int F = r * (r - 1) / 2 + 2 * r + 1;  // must match solve_corridor_kernel's state layout
-    const size_t ws_bytes = sizeof(double) * (size_t)(Mmax > 1 ? Mmax - 1 : 1) * F * (size_t)grid * block;
-    int rc = ensure_ws(ctx, ws_bytes);
+    const int NT = uavqp::corridor_lds_knots(r);
+    const int F = r * (r - 1) / 2 + 2 * r + 1;  // must match corridor_solve_kernel's state layout
+    const int own_max = (Mmax + 1) / 2;        // own knots of the longer half, meeting knot included
+    const int ws_knots = own_max > NT ? own_max - NT : 0;
+    long long rows = 0;                        // waypoint rows of the batch
+    if (uniform_segments > 0) rows = (long long)n_traj * (uniform_segments + 1);
+    else {
+        // sum(M_b) + n_traj: the last CSR offset is only known on the device; the caller's coefficient buffer bounds it, but the
+        // cheap exact way is a 4-byte read-back once per call (synchronous on the ctx stream, like the obstacle grid build)
+        int32_t last = 0;
+        UAVQP_HIP(hipMemcpyAsync(&last, d_seg_offsets + n_traj, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+        if (last < 0) return UAVQP_ERR_INVALID_ARG;
+        rows = (long long)last + n_traj;
+    }
+    const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
+    const size_t b_queue = 256;
+    const size_t b_state = sizeof(double) * (size_t)ws_knots * F * (size_t)grid * 64;
+    int rc = ensure_ws(ctx, b_xsol + b_queue + b_state);
     if (rc != UAVQP_OK) return rc;
-    a.ws = ctx->ws;
+    a.coeff = d_coeff_out;
+    a.xsol = ctx->ws;
+    a.queue = (unsigned int*)((char*)ctx->ws + b_xsol);
+    a.ws = ws_knots > 0 ? (double*)((char*)ctx->ws + b_xsol + b_queue) : nullptr;
+    a.ws_knots = ws_knots;
+    a.order = nullptr;
+    UAVQP_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
     if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
-    // uniform batches keep the sweep state of their last 4 (r = 3) / 5 (r = 4) knots in LDS; ragged ones all in HBM
+    const long long chunks = 3LL * (rows - n_traj);  // (trajectory, axis, segment) triples
+    long long egrid = (chunks + 255) / 256;
+    if (egrid > (long long)ctx->num_cus * 16) egrid = (long long)ctx->num_cus * 16;
     if (r == 3) {
-        if (uniform_segments > 0)
-            hipLaunchKernelGGL((uavqp::solve_corridor_kernel<3, 4>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((uavqp::solve_corridor_kernel<3, 0>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+        if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        if (chunks > 0) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<3>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, a, chunks);
     } else {
-        if (uniform_segments > 0)
-            hipLaunchKernelGGL((uavqp::solve_corridor_kernel<4, 5>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((uavqp::solve_corridor_kernel<4, 0>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+        if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        if (chunks > 0) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<4>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, a, chunks);
     }
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
