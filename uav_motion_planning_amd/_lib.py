@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libuavqp.so")
+# UAVQP_LIB_PATH: development aid for A/B runs of alternative builds of the same source (tools/); the product loads the in-tree library
+LIB_PATH = os.environ.get("UAVQP_LIB_PATH") or os.path.join(_PKG, "libuavqp.so")
 
 UAVQP_OK = 0
 UAVQP_ERR_INVALID_ARG = -1

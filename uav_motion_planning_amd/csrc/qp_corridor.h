@@ -47,11 +47,25 @@ struct CorridorArgs {
     double* ws;       // HBM part of the sweep state: [wave][own knot beyond NT][field][lane] (null when every half fits LDS)
     int ws_knots;     // own knots per lane held in the workspace
     double* xsol;     // [waypoint row][axis][r]: Hermite solution at the interior knots (hand-off to corridor_emit_kernel)
+    unsigned long long* desc;      // [n_traj][3]: bit 0 = solve this problem (valid, M >= 2), bits 1..M-1 = equality rows (corridor_prep_kernel)
     unsigned int* queue;           // work counter, zeroed before the launch
     const int32_t* order;          // optional dealing order of the trajectories (null = index order)
     unsigned long long* active;    // [n_traj][3][2] working set in/out (may be null)
     int warm;                      // read `active` as the initial working set
+#ifdef UAVQP_CORRIDOR_TIMING
+    long long* stamps;             // debug build only (tools/): cycles per section of wave 0 -> [refill, forward, meeting, backward, decide, hand-over, iterations]
+#endif
 };
+
+#ifdef UAVQP_CORRIDOR_TIMING
+#define UAVQP_CT_DECL long long ct_acc[7] = {0, 0, 0, 0, 0, 0, 0}; long long ct_t = __builtin_readcyclecounter();
+#define UAVQP_CT(k) do { const long long n_ = __builtin_readcyclecounter(); ct_acc[k] += n_ - ct_t; ct_t = n_; } while (0)
+#define UAVQP_CT_FLUSH do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.stamps) for (int k_ = 0; k_ < 7; ++k_) a.stamps[k_] = ct_acc[k_]; } while (0)
+#else
+#define UAVQP_CT_DECL
+#define UAVQP_CT(k) do {} while (0)
+#define UAVQP_CT_FLUSH do {} while (0)
+#endif
 
 // r x r blocks of one segment including the position component (index 0):
 //   B11 end/end = T^(a+b+1-2R) W[a][b],  B00 start/start = (-1)^(a+b) B11,  B01 start/end = -T^(a+b+1-2R) V[a][b]
@@ -86,6 +100,36 @@ __device__ __forceinline__ int swap_pair_i(int v) { return __builtin_amdgcn_mov_
 __device__ __forceinline__ unsigned long long swap_pair_u64(unsigned long long v) {
     const unsigned lo = (unsigned)swap_pair_i((int)(unsigned)v), hi = (unsigned)swap_pair_i((int)(unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
+}
+
+// One lane per (trajectory, axis): validation of the inputs and the permanent pins (lo == hi: a true equality row, as in the
+// reference), once per solve and off the solver's critical path -- a persistent wave that takes a new problem must not stall
+// the other 31 problems of the wave behind serial validation loads.
+__global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
+    const long long total = (long long)a.n_traj * 3;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(q / 3), ax = (int)(q - 3LL * b);
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        const long long base3 = 3LL * ((long long)s0 + b) + ax;
+        const double* lo = a.corr_lo + base3;
+        const double* hi = a.corr_hi + base3;
+        const double* T = a.times + s0;
+        bool ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;  // pin masks are 64-bit
+        unsigned long long eq = 0ull;
+        if (ok) {
+            for (int i = 0; i < M; ++i) ok = ok & (T[i] > 0.0) & (T[i] < INFINITY);
+            for (int k = 1; k < M; ++k) {
+                const double l = lo[3 * k], h = hi[3 * k];
+                ok = ok & (l <= h);
+                eq |= (unsigned long long)(l == h) << k;
+            }
+        }
+        if (!ok) atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
+        // no interior knot (M = 1): nothing to solve, the emission kernel builds the segment from the boundary data
+        if (ok && M == 1 && a.active) { a.active[2 * q] = 0ull; a.active[2 * q + 1] = 0ull; }
+        a.desc[q] = (ok && M >= 2) ? (eq | 1ull) : 0ull;
+    }
 }
 
 constexpr int corridor_lds_knots(int R) { return R == 3 ? 8 : 5; }
@@ -125,11 +169,15 @@ template <int R, bool WS>
 __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
     constexpr int ND = R - 1;
     constexpr int NT = corridor_lds_knots(R);
-    // sweep state per own knot: LDL' factors of S_j (strict lower triangle + inverse pivots), x_j (first h_j,
-    // overwritten by the solution in the backward sweep) and the current position iterate z_j.  E_j = S_j^-1 M_j is
-    // NOT stored: it is re-derived from the factors where needed.
-    constexpr int NL = R * (R - 1) / 2;
-    constexpr int F_L = 0, F_DI = NL, F_X = NL + R, F_Z = NL + 2 * R, F = NL + 2 * R + 1;
+    // sweep state per own knot: LDL' factors of S_j (strict lower triangle + inverse pivots: R (R + 1) / 2 numbers), x_j (first
+    // h_j, overwritten by the solution in the backward sweep) and the current position iterate z_j.  E_j = S_j^-1 M_j is NOT
+    // stored: it is re-derived where needed.  (Explicit inverses -- cofactors / 2 x 2 blocks instead of the factorisation, one
+    // reciprocal on the dependency chain -- were measured: no faster, 1.693 vs 1.701 ms on config 3, and the 4 x 4 case lost
+    // the 1e-10 agreement with the exact-rational fixtures.)
+    using Inv = SmallLDL<R>;
+    using IP = LDLPack<R>;
+    constexpr int NE = IP::NE;
+    constexpr int F_I = 0, F_X = NE, F_Z = NE + R, F = NE + R + 1;
     __shared__ double s_rec[NT * F * 64];
     const int lane = threadIdx.x;
     const int isR = lane & 1;
@@ -163,15 +211,13 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
         st_x(s, x);
         if (in_lds(s)) L(s, F_Z) = z; else G(s, F_Z) = z;
     };
-    auto st_rec = [&](int s, const SmallLDL<R>& ldl, const double (&h)[R], double z) {
-        double r[F];
-        int f = 0;
+    auto st_rec = [&](int s, const Inv& inv, const double (&h)[R], double z) {
+        double r[F], e[NE];
+        IP::get(inv, e);
 #pragma unroll
-        for (int i = 1; i < R; ++i)
+        for (int i = 0; i < NE; ++i) r[F_I + i] = e[i];
 #pragma unroll
-            for (int c = 0; c < i; ++c) r[F_L + (f++)] = ldl.l[i][c];
-#pragma unroll
-        for (int i = 0; i < R; ++i) { r[F_DI + i] = ldl.dinv[i]; r[F_X + i] = h[i]; }
+        for (int i = 0; i < R; ++i) r[F_X + i] = h[i];
         r[F_Z] = z;
         if (in_lds(s)) {
 #pragma unroll
@@ -184,6 +230,7 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
 
     const long long total = (long long)a.n_traj * 3;
     bool queue_empty = false;
+    UAVQP_CT_DECL
 
     // ---- state of the problem this lane pair works on (identical in both lanes unless noted)
     long long g = -1;            // problem = 3 * trajectory + axis, -1: none
@@ -229,58 +276,38 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                     if (q < total) {
                         const int bq = (int)(q / 3), ax = (int)(q - 3LL * bq);
                         const int bn = a.order ? a.order[bq] : bq;
+                        const long long gn = 3LL * bn + ax;
+                        // everything a new problem needs is fetched by INDEPENDENT loads (one round trip); validation and
+                        // the equality rows come ready-made from corridor_prep_kernel
+                        const unsigned long long dsc = a.desc[gn];
                         int sn, Mn;
                         if (a.uniform > 0) { Mn = a.uniform; sn = bn * Mn; } else { sn = a.seg_offsets[bn]; Mn = a.seg_offsets[bn + 1] - sn; }
-                        const long long basen = 3LL * ((long long)sn + bn) + ax;
-                        const double* wp = a.waypoints + basen;  // stride 3 per knot
-                        const double* lo = a.corr_lo + basen;
-                        const double* hi = a.corr_hi + basen;
-                        const double* T = a.times + sn;
-                        const double* bc = a.bc + (size_t)bn * 2 * ND * 3 + ax;
-                        bool ok = (Mn >= 1) && (a.uniform > 0 || Mn <= a.max_segments) && Mn <= 63;  // pin masks are 64-bit
-                        if (ok)
-                            for (int i = 0; i < Mn; ++i) ok = ok && (T[i] > 0.0) && (T[i] < INFINITY);
-                        if (ok)
-                            for (int k = 1; k < Mn; ++k) ok = ok && (lo[3 * k] <= hi[3 * k]);
-                        if (!ok) {
-                            if (!isR) atomicMin(&a.status[bn], (int32_t)UAVQP_INVALID_INPUT);
-                        } else if (Mn == 1) {
-                            // no interior knot: nothing to solve, the emission kernel builds the segment from the boundary data
-                            if (!isR && a.active) { a.active[2 * (3LL * bn + ax)] = 0ull; a.active[2 * (3LL * bn + ax) + 1] = 0ull; }
-                        } else {
-                            b = bn; M = Mn; s0 = sn; base3 = basen;
-                            g = 3LL * b + ax;
+                        unsigned long long wpin = 0ull, wupper = 0ull;
+                        if (a.active && a.warm) { wpin = a.active[2 * gn]; wupper = a.active[2 * gn + 1]; }
+                        if (dsc & 1ull) {
+                            b = bn; M = Mn; s0 = sn;
+                            base3 = 3LL * ((long long)sn + bn) + ax;
+                            g = gn;
                             m = isR ? M / 2 : (M + 1) / 2;
+                            const double* bc = a.bc + (size_t)bn * 2 * ND * 3 + ax;
                             // own boundary knot in the own frame: derivative d of the reversed problem picks up (-1)^d
-                            x0[0] = isR ? wp[3 * M] : wp[0];
+                            x0[0] = a.waypoints[base3 + (isR ? 3 * M : 0)];
 #pragma unroll
                             for (int d = 0; d < ND; ++d) {
                                 const double v = bc[((isR ? ND : 0) + d) * 3];
                                 x0[d + 1] = (isR && ((d & 1) == 0)) ? -v : v;
                             }
-                            // permanent pins (lo == hi: a true equality row, as in the reference) and the first working set.
-                            // A warm start only supplies that set (bounds guessed active sit on their bound); wrong guesses
-                            // are repaired by the iterations below like any other intermediate working set.
-                            eqmask = 0ull; pin = 0ull; upper = 0ull;
-                            unsigned long long wpin = 0ull, wupper = 0ull;
-                            if (a.active && a.warm) { wpin = a.active[2 * g]; wupper = a.active[2 * g + 1]; }
-                            for (int k = 1; k < M; ++k) {
-                                const double l = lo[3 * k], h = hi[3 * k];
-                                if (l == h) eqmask |= 1ull << k;
-                                else if ((wpin >> k) & 1ull) {
-                                    pin |= 1ull << k;
-                                    if ((wupper >> k) & 1ull) upper |= 1ull << k;
-                                }
-                            }
-                            pin |= eqmask;
-                            // the first forward sweep (zmode 4) turns x = waypoint into the initial feasible iterate z
-                            for (int s = 0; s < m; ++s) {   // slot s = own knot m - s (lane-specific trip count: not a sweep)
-                                const double w = wp[3 * (isR ? M - (m - s) : (m - s))];
-                                if (in_lds(s)) { L(s, F_X) = w; L(s, F_Z) = 0.0; } else { G(s, F_X) = w; G(s, F_Z) = 0.0; }
-                            }
+                            // permanent pins and the first working set.  A warm start only supplies that set (bounds guessed
+                            // active sit on their bound); wrong guesses are repaired by the iterations below like any other
+                            // intermediate working set.
+                            const unsigned long long valid = (1ull << M) - 2ull;  // bits 1..M-1
+                            eqmask = dsc & valid;
+                            pin = eqmask | (wpin & valid);
+                            upper = wupper & wpin & valid & ~eqmask;
                             it = 0;
                             pdas_left = a.pdas_rounds;
                             final_pass = false;
+                            // the first forward sweep (zmode 4) makes the initial feasible iterate z from the waypoints
                             zmode = 4; zblock = -1; zblock_upper = false; zpin = pin; zalpha = 1.0;
                         }
                     }
@@ -288,6 +315,7 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
             }
         }
         const bool act = g >= 0;
+        UAVQP_CT(0);
         if (__ballot(act) == 0ull) {
             if (queue_empty) break;
             continue;
@@ -299,6 +327,7 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
         const double* const LO = a.corr_lo + base3;
         const double* const HI = a.corr_hi + base3;
         const double* const TT = a.times + s0;
+        const double* const WP = a.waypoints + base3;
         // slot s <-> original knot kbase + ksign s, original segment of own segment (m - s) = tbase + ksign s
         const int ksign = isR ? 1 : -1, kbase = isR ? M - mm : mm, tbase = isR ? M - 1 - mm : mm;
         auto kslot = [&](int s) -> int { return kbase + ksign * s; };
@@ -317,11 +346,12 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
         // z update of the knot in slot s (znew of the header comment), select form.
         //   1: block-pivot round -- every (newly) pinned position sits on its bound, the free ones keep a feasible iterate for the
         //      safe phase: the clipped subspace minimiser;  2: partial step, the blocking knot lands on its bound;  3: full step;
-        //   4: first sweep -- x0old is the waypoint; equality rows and free positions start at the clipped waypoint, bounds guessed
+        //   4: first sweep -- x0old is the waypoint w; equality rows and free positions start at the clipped waypoint, bounds guessed
         //      active by a warm start at that bound;  0: nothing pending
         const bool m14 = (zmode == 1) || (zmode == 4), m2 = zmode == 2, m0 = zmode == 0, m4 = zmode == 4;
-        auto znew = [&](int s, double x0old, double zold, double l, double h) -> double {
+        auto znew = [&](int s, double xold, double zold, double l, double h, double w) -> double {
             const bool zp = (s_zpin >> s) & 1ull, eq = (s_eq >> s) & 1ull, up = (s_up >> s) & 1ull;
+            const double x0old = m4 ? w : xold;   // first sweep of a problem: the slot still holds the previous problem's record
             const double clipped = fmin(fmax(x0old, l), h);
             const double bound = up ? h : l;
             const bool usebound = zp & !eq & m14;   // (bitwise on purpose: no short-circuit control flow in the sweeps)
@@ -337,18 +367,20 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
         // knot j (j >= 1).  The fetches of (2) are issued AFTER everything of the previous trip has been consumed (the waits the
         // compiler places for those would otherwise cover the fresh loads too) and have the whole of (3) to land.
         FullBlocks<R> sa;
-        SmallLDL<R> lprev;
+        // The own boundary knot plays the part of an eliminated knot with S^-1 = 0 (nothing free) and h = its Hermite data: the first
+        // interior knot then needs no special case (E = 0, the coupling moves to the right-hand side through h).
+        Inv lprev;
+        IP::zero(lprev);
         double hprev[R];
         double zp_ = 0.0, zc = 0.0, zn = 0.0;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            hprev[i] = 0.0;
-            lprev.dinv[i] = 1.0;
+            hprev[i] = x0[i];
 #pragma unroll
-            for (int c = 0; c < R; ++c) { lprev.l[i][c] = 0.0; sa.B11[i][c] = (i == c) ? 1.0 : 0.0; sa.B01[i][c] = 0.0; }
+            for (int c = 0; c < R; ++c) { sa.B11[i][c] = (i == c) ? 1.0 : 0.0; sa.B01[i][c] = 0.0; }
         }
         {
-            double rx = 0.0, rz = 0.0, rl = 0.0, rh = 0.0;
+            double rx = 0.0, rz = 0.0, rl = 0.0, rh = 0.0, rw = 0.0;
             double Tn = TT[tclamp(tbase + ksign * (mmax + 1))];
             for (int u = 0; u <= mmax; ++u) {
                 const int j = u - off - 1;
@@ -356,7 +388,7 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                 // (1)
                 const double Tcur = Tn;
                 {
-                    const double zv = znew(sj - 1, rx, rz, rl, rh);
+                    const double zv = znew(sj - 1, rx, rz, rl, rh, rw);
                     zn = (j >= 0) ? zv : zn;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -367,29 +399,21 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                     const int k2 = 3 * kclamp(kslot(sj - 2));
                     rl = LO[k2];
                     rh = HI[k2];
+                    rw = WP[k2];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // (3)
                 FullBlocks<R> sb;
                 sb.build(Tcur);
                 if (u >= 2 && j >= 1) {   // (u >= 2: uniform; j >= 1: the halves that have started)
-                    const bool first = (j == 1);
                     const bool pk = (s_pin >> sj) & 1ull;
-                    const bool pprev = !first & (bool)((s_pin >> (sj + 1)) & 1ull);
+                    const bool pprev = (j > 1) & (bool)((s_pin >> (sj + 1)) & 1ull);   // (j = 1: the boundary knot, all of it known through h)
                     const bool pnext = (s_pin >> (sj - 1)) & 1ull;  // own knot j+1 <= m: an interior knot (the meeting knot at the latest)
                     double D[R][R], rhs[R];
-                    // what is KNOWN of the previous knot: all of it for the boundary knot, its position when pinned, nothing else
-                    double kn[R];
-                    kn[0] = first ? x0[0] : (pprev ? zp_ : 0.0);
-#pragma unroll
-                    for (int c = 1; c < R; ++c) kn[c] = first ? x0[c] : 0.0;
-                    const double znm = pnext ? zn : 0.0, zcm = pk ? zc : 0.0;
+                    const double znm = pnext ? zn : 0.0, zcm = pk ? zc : 0.0, zpm = pprev ? zp_ : 0.0;
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        double acc = -sb.B01[i][0] * znm;
-#pragma unroll
-                        for (int c = 0; c < R; ++c) acc -= sa.B01[c][i] * kn[c];
-                        rhs[i] = acc;
+                        rhs[i] = -sb.B01[i][0] * znm - sa.B01[0][i] * zpm;   // known positions of pinned neighbours
 #pragma unroll
                         for (int c = 0; c < R; ++c) D[i][c] = sa.B11[i][c] + sb.B00(i, c);
                     }
@@ -399,13 +423,12 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                         D[i][0] = pk ? 0.0 : D[i][0];
                     }
                     D[0][0] = pk ? 1.0 : D[0][0];
-                    rhs[0] = pk ? zc : rhs[0];
-                    // masked coupling block between (j-1, j) and E = S_{j-1}^-1 Mp from the previous factors (all zero for j = 1)
+                    // masked coupling block between (j-1, j) and E = S_{j-1}^-1 Mp from the previous inverse
                     double Mp[R][R], Ep[R][R];
 #pragma unroll
                     for (int i = 0; i < R; ++i)
 #pragma unroll
-                        for (int c = 0; c < R; ++c) Mp[i][c] = (first | (pprev & (i == 0)) | (pk & (c == 0))) ? 0.0 : sa.B01[i][c];
+                        for (int c = 0; c < R; ++c) Mp[i][c] = ((pprev & (i == 0)) | (pk & (c == 0))) ? 0.0 : sa.B01[i][c];
 #pragma unroll
                     for (int c = 0; c < R; ++c) {
                         double col[R];
@@ -423,10 +446,11 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                             for (int c = 0; c <= i; ++c) D[i][c] -= Mp[q][i] * Ep[q][c];
                             rhs[i] -= Mp[q][i] * hprev[q];
                         }
-                    SmallLDL<R> ldl;
+                    rhs[0] = pk ? zc : rhs[0];   // pinned: row 0 of the system is the identity
+                    Inv ldl;
                     ldl.factor(D);
                     ldl.solve(rhs);
-                    st_rec(sj, ldl, rhs, zc);  // factors + h + z of knot j
+                    st_rec(sj, ldl, rhs, zc);  // factors, h, z of knot j
 #pragma unroll
                     for (int i = 0; i < R; ++i) hprev[i] = rhs[i];
                     lprev = ldl;
@@ -437,24 +461,19 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
             }
         }
         zmode = 0;
+        UAVQP_CT(1);
 
         // ================= meeting knot (own knot m, slot 0): own partial Schur complement, exchange, solve =================
         // sa = blocks of the last own segment m-1, lprev / hprev = factors and h of own knot m-1, zp_ / zc = z of knots m-1 / m.
         double xn[R];  // solution at the meeting knot, own frame
         const bool pc = act && (s_pin & 1ull);
         {
-            const bool first = (mm <= 1);
-            const bool pprev = !first & (bool)((s_pin >> 1) & 1ull);
-            double P[R][R], q[R], kn[R];
-            kn[0] = first ? x0[0] : (pprev ? zp_ : 0.0);
-#pragma unroll
-            for (int c = 1; c < R; ++c) kn[c] = first ? x0[c] : 0.0;
+            const bool pprev = (mm > 1) & (bool)((s_pin >> 1) & 1ull);
+            double P[R][R], q[R];
+            const double zpm = pprev ? zp_ : 0.0;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                double acc = 0.0;
-#pragma unroll
-                for (int c = 0; c < R; ++c) acc -= sa.B01[c][i] * kn[c];
-                q[i] = acc;
+                q[i] = -sa.B01[0][i] * zpm;
 #pragma unroll
                 for (int c = 0; c < R; ++c) P[i][c] = sa.B11[i][c];
             }
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
 #pragma unroll
             for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int c = 0; c < R; ++c) Mp[i][c] = (first | (pprev & (i == 0)) | (pc & (c == 0))) ? 0.0 : sa.B01[i][c];
+                for (int c = 0; c < R; ++c) Mp[i][c] = ((pprev & (i == 0)) | (pc & (c == 0))) ? 0.0 : sa.B01[i][c];
 #pragma unroll
             for (int c = 0; c < R; ++c) {
                 double col[R];
@@ -502,37 +521,29 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
             }
             S[0][0] = pc ? 1.0 : S[0][0];
             xn[0] = pc ? zc : xn[0];
-            SmallLDL<R> ldl;
+            Inv ldl;
             ldl.factor(S);
             ldl.solve(xn);
             if (act) st_xz(0, xn, zc);
         }
 
+        UAVQP_CT(2);
         // ================= backward sweep: x_j = h_j - S_j^-1 (M_j x_{j+1}) + the decisions of this iteration ======
-        // Trip i works on own knot j = m - 1 - i (slot i + 1; j = 0: the boundary knot, j < 0: this half is finished); the
-        // record of knot j-1 (factors, h, z) and its bounds are fetched while knot j is processed.  Decisions are gathered in
-        // SLOT numbering and translated to original knot numbers afterwards.
+        // Trip i computes x of own knot j = m - 1 - i (slot i + 1; j = 0: the boundary knot, j < 0: this half is finished) -- the
+        // only loop-carried chain -- and, independent of it and ONE KNOT LATE, evaluates what the previous trips left complete:
+        // the multiplier of knot j + 2 (slot i - 1), the first half of knot j + 1's, and the box test of the free position of
+        // knot j + 1 (slot i).  A dependent FP64 result takes ~40 cycles: the two strands of a trip interleave, each hides the
+        // other's latency.  The record of knot j-1 (inverse, h, z) and its bounds are fetched while knot j is processed.
+        // Decisions are gathered in SLOT numbering and translated to original knot numbers afterwards.  The ratio test keeps the
+        // step length as a fraction (an / ad, both >= 0) and compares by cross-multiplication: one division per iteration
+        // instead of one per knot on the chain.
         constexpr int NONE = 1 << 30;
         unsigned long long np_s = 0ull, nu_s = 0ull;       // block-pivot round (slot order)
-        double alpha = 1.0, worst = 0.0;                    // ratio test / worst wrong-signed multiplier
+        double an = 1.0, ad = 1.0, worst = 0.0;             // ratio test (alpha = an / ad) / worst wrong-signed multiplier
         int block = NONE, rel = NONE;                       // ORIGINAL knot numbers; ties go to the lowest knot
         bool block_upper = false;
         {
-            {   // free meeting knot outside its box?  (both lanes of the pair take the same decision)
-                const int kc = kclamp(kslot(0));
-                const double lk = LO[3 * kc], hk = HI[3 * kc], ph = xn[0];
-                const bool below = ph < lk - 1e-12 * (1.0 + fabs(lk));
-                const bool above = !below & (ph > hk + 1e-12 * (1.0 + fabs(hk)));
-                const bool v = act & !pc & (below | above);
-                np_s |= (unsigned long long)v;
-                nu_s |= (unsigned long long)(v & above);
-                const double al = ((above ? hk : lk) - zc) / (ph - zc);
-                alpha = v ? al : alpha;
-                block = v ? kc : block;
-                block_upper = v ? above : block_upper;
-            }
             double nx[F], nl, nh, Tn;       // record of the knot processed next
-            double lamA = 0.0, magA = 0.0;  // part of knot (j+1)'s multiplier known before x_j is
 #pragma unroll
             for (int f = 0; f < F; ++f) nx[f] = 0.0;
             if (mmax >= 2) ld_rec(1, nx);
@@ -542,9 +553,21 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                 nh = HI[k1];
                 Tn = TT[tclamp(tbase + ksign)];   // own segment m - 1
             }
-            for (int i = 0; i < mmax; ++i) {
+            // what the delayed strand works on: x of the last two knots, row-0 pieces of the segment between them, box and z of
+            // the later one (starts with the meeting knot)
+            double xnn[R], pe11[R], pe01r[R], pe01c[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) { xnn[q] = 0.0; pe11[q] = 0.0; pe01r[q] = 0.0; pe01c[q] = 0.0; }
+            double plk, phk, pzk = zc;
+            {
+                const int kc = 3 * kclamp(kslot(0));
+                plk = LO[kc];
+                phk = HI[kc];
+            }
+            double lamA = 0.0, magA = 0.0;  // part of a knot's multiplier known one trip before the rest
+            for (int i = 0; i <= mmax; ++i) {
                 const int j = mm - 1 - i;
-                const bool on = j >= 0, interior = j >= 1;
+                const bool interior = j >= 1;
                 double cur[F];
 #pragma unroll
                 for (int f = 0; f < F; ++f) cur[f] = nx[f];
@@ -558,6 +581,7 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                     Tn = TT[tclamp(tbase + ksign * (i + 2))];   // own segment j - 1 = m - (i + 2)
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // ---------------- strand 1: x_j (speculative for j <= 0 and in the extra last trip: discarded) ----------------
                 // own segment j: inverse powers of its duration and the row-0 pieces of its blocks
                 const double itv = fast_rcp(Tcur);
                 double ip[2 * R];
@@ -574,7 +598,6 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                 }
                 const bool pk = (s_pin >> (i + 1)) & 1ull;      // own knot j
                 const bool pj = (s_pin >> i) & 1ull;            // own knot j + 1
-                // x_j for an interior knot (speculative for j <= 0: discarded below)
                 double x[R];
                 {
                     double t[R];
@@ -588,87 +611,103 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                         }
                         t[q] = acc;
                     }
-                    SmallLDL<R> ldl;
+                    Inv ldl;
                     {
-                        int f = 0;
+                        double e[NE];
 #pragma unroll
-                        for (int q = 1; q < R; ++q)
-#pragma unroll
-                            for (int c = 0; c < q; ++c) ldl.l[q][c] = cur[F_L + (f++)];
+                        for (int q = 0; q < NE; ++q) e[q] = cur[F_I + q];
+                        IP::set(ldl, e);
                     }
-#pragma unroll
-                    for (int q = 0; q < R; ++q) ldl.dinv[q] = cur[F_DI + q];
                     ldl.solve(t);
 #pragma unroll
                     for (int q = 0; q < R; ++q) x[q] = interior ? cur[F_X + q] - t[q] : x0[q];
                 }
                 if (interior) st_x(i + 1, x);
-                // ---- multiplier of own knot j+1, now that x_j is known: d(cost)/d p (up to the factor 2), row 0 of
-                // the unmasked block row;  lower bound active: need lam >= 0, upper: lam <= 0.  For the meeting knot (first
-                // trip) the other half of the row comes from the partner lane (a scalar: frame-independent).
-                double own = 0.0, omag = 0.0;
-#pragma unroll
-                for (int c = 0; c < R; ++c) {
-                    const double t1 = e01c[c] * x[c], t2 = e11[c] * xn[c];
-                    own += t1 + t2;
-                    omag += fabs(t1) + fabs(t2);
-                }
-                if (i == 0) {
-                    lamA = swap_pair(own);
-                    magA = swap_pair(omag);
-                }
+                // ---------------- strand 2 (one knot late): xn = x of knot j + 1, xnn = x of knot j + 2, pe* = the segment between ----
+                const bool d_on = (i >= 1) & (j >= -1), d_interior = (i >= 1) & (j >= 0);
                 {
-                    const int kj = kslot(i);
+                    // multiplier of own knot j + 2: d(cost)/d p (up to the factor 2), row 0 of the unmasked block row; lower bound
+                    // active: need lam >= 0, upper: lam <= 0.  For the meeting knot (i = 1) the other half of the row comes from
+                    // the partner lane (a scalar: frame-independent).
+                    double t1[R], t2[R];
+#pragma unroll
+                    for (int c = 0; c < R; ++c) { t1[c] = pe01c[c] * xn[c]; t2[c] = pe11[c] * xnn[c]; }
+                    double own = t1[0] + t2[0], omag = fabs(t1[0]) + fabs(t2[0]);
+#pragma unroll
+                    for (int c = 1; c < R; ++c) { own += t1[c] + t2[c]; omag += fabs(t1[c]) + fabs(t2[c]); }
+                    const double so = swap_pair(own), sm = swap_pair(omag);
+                    lamA = (i == 1) ? so : lamA;
+                    magA = (i == 1) ? sm : magA;
+                    const int s2 = i >= 1 ? i - 1 : 0;   // slot of own knot j + 2
+                    const int kj = kslot(s2);
                     const double lam = lamA + own, mag = magA + omag;
-                    const bool ej = (s_eq >> i) & 1ull, uj = (s_up >> i) & 1ull;
+                    const bool p2 = (s_pin >> s2) & 1ull, ej = (s_eq >> s2) & 1ull, uj = (s_up >> s2) & 1ull;
                     const double viol = uj ? lam : -lam;
                     // rounding of lam is a few ulp of mag; 1e-11 let a 4e-4-relative wrong-signed multiplier pass on T^-7-scaled
                     // blocks (tools/soak.py, seed 11)
                     const bool wrong = viol > 1e-13 * mag;
-                    const bool cand = on & pj & !ej;
+                    const bool cand = d_on & p2 & !ej;
                     const bool keep = cand & !wrong;   // multiplier has the right sign: stays active in a block-pivot round
-                    np_s |= (unsigned long long)keep << i;
-                    nu_s |= (unsigned long long)(keep & uj) << i;
+                    np_s |= (unsigned long long)keep << s2;
+                    nu_s |= (unsigned long long)(keep & uj) << s2;
                     const bool take = cand & wrong & ((viol > worst) | ((viol == worst) & (kj < rel)));
                     worst = take ? viol : worst;
                     rel = take ? kj : rel;
                 }
-                // ---- first half of own knot j's multiplier (needs x_j and x_{j+1} only)
-                lamA = 0.0;
-                magA = 0.0;
+                {   // first half of own knot (j + 1)'s multiplier: its right-hand segment (needs x_{j+1} and x_{j+2} only)
+                    double t2[R], t3[R];
 #pragma unroll
-                for (int c = 0; c < R; ++c) {
-                    const double t2 = ((c & 1) ? -e11[c] : e11[c]) * x[c], t3 = e01r[c] * xn[c];
-                    lamA += t2 + t3;
-                    magA += fabs(t2) + fabs(t3);
+                    for (int c = 0; c < R; ++c) { t2[c] = ((c & 1) ? -pe11[c] : pe11[c]) * xn[c]; t3[c] = pe01r[c] * xnn[c]; }
+                    double la = t2[0] + t3[0], ma = fabs(t2[0]) + fabs(t3[0]);
+#pragma unroll
+                    for (int c = 1; c < R; ++c) { la += t2[c] + t3[c]; ma += fabs(t2[c]) + fabs(t3[c]); }
+                    lamA = la;
+                    magA = ma;
                 }
-                {   // ---- free position: outside its box?
-                    const int kk = kslot(i + 1);
-                    const double ph = x[0];
-                    const bool below = ph < lk - 1e-12 * (1.0 + fabs(lk));
-                    const bool above = !below & (ph > hk + 1e-12 * (1.0 + fabs(hk)));
-                    const bool v = interior & !pk & (below | above);
-                    np_s |= (unsigned long long)v << (i + 1);
-                    nu_s |= (unsigned long long)(v & above) << (i + 1);
-                    const double al = ((above ? hk : lk) - zk) / (ph - zk);
-                    const bool take = v & ((al < alpha) | ((al == alpha) & (kk < block)));
-                    alpha = take ? al : alpha;
+                {   // free position of own knot j + 1 (slot i): outside its box?
+                    const int kk = kslot(i);
+                    const double ph = xn[0];
+                    const bool pfree = !((s_pin >> i) & 1ull);
+                    const bool below = ph < plk - 1e-12 * (1.0 + fabs(plk));
+                    const bool above = !below & (ph > phk + 1e-12 * (1.0 + fabs(phk)));
+                    const bool v = ((i == 0) ? (act & !pc) : d_interior) & pfree & (below | above);
+                    np_s |= (unsigned long long)v << i;
+                    nu_s |= (unsigned long long)(v & above) << i;
+                    const double num = fabs((above ? phk : plk) - pzk), den = fabs(ph - pzk);   // step to the bound / full step
+                    const double lhs = num * ad, rhs_ = an * den;                                 // num / den < an / ad ?
+                    const bool take = v & ((lhs < rhs_) | ((lhs == rhs_) & (kk < block)));
+                    an = take ? num : an;
+                    ad = take ? den : ad;
                     block = take ? kk : block;
                     block_upper = take ? above : block_upper;
                 }
+                // ---------------- rotate ----------------
 #pragma unroll
-                for (int q = 0; q < R; ++q) xn[q] = x[q];
+                for (int q = 0; q < R; ++q) {
+                    xnn[q] = xn[q];
+                    xn[q] = x[q];
+                    pe11[q] = e11[q];
+                    pe01r[q] = e01r[q];
+                    pe01c[q] = e01c[q];
+                }
+                plk = lk;
+                phk = hk;
+                pzk = zk;
             }
         }
+        UAVQP_CT(3);
         // ---- combine the decisions of the two halves (identical values in both lanes afterwards)
         unsigned long long npin = eqmask | fromslot(np_s), nupper = fromslot(nu_s);
+        double alpha = 1.0;
         {
             npin |= swap_pair_u64(npin);
             nupper |= swap_pair_u64(nupper);
-            const double oa = swap_pair(alpha), ow = swap_pair(worst);
+            const double oan = swap_pair(an), oad = swap_pair(ad), ow = swap_pair(worst);
             const int ob = swap_pair_i(block), obu = swap_pair_i(block_upper ? 1 : 0), orl = swap_pair_i(rel);
-            if (oa < alpha || (oa == alpha && ob < block)) { alpha = oa; block = ob; block_upper = obu != 0; }
+            const double lhs = oan * ad, rhs_ = an * oad;
+            if (lhs < rhs_ || (lhs == rhs_ && ob < block)) { an = oan; ad = oad; block = ob; block_upper = obu != 0; }
             if (ow > worst || (ow == worst && orl < rel)) { worst = ow; rel = orl; }
+            alpha = an / ad;   // (an = ad = 1 when nothing blocks)
         }
 
         bool done = false;
@@ -721,6 +760,10 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
             }
         }
 
+        UAVQP_CT(4);
+#ifdef UAVQP_CORRIDOR_TIMING
+        ct_acc[6] += 1;
+#endif
         // ================= a finished pair hands over its Hermite solution and frees its slot =================
         if (__ballot(done) != 0ull) {
             for (int s = 0; s < mmax; ++s) {   // slot s = own knot m - s
@@ -749,7 +792,9 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
             }
             if (done) { g = -1; m = 0; }
         }
+        UAVQP_CT(5);
     }
+    UAVQP_CT_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -177,6 +177,39 @@ struct SymInv<3> {
     }
 };
 
+// packed access to the N (N + 1) / 2 numbers of a SmallLDL (strict lower triangle of L, inverse pivots): sweep-state records
+template <int N>
+struct LDLPack {
+    static constexpr int NE = N * (N + 1) / 2;
+    static __device__ __forceinline__ void get(const SmallLDL<N>& v, double (&o)[NE]) {
+        int f = 0;
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+#pragma unroll
+            for (int c = 0; c < i; ++c) o[f++] = v.l[i][c];
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[f++] = v.dinv[i];
+    }
+    static __device__ __forceinline__ void set(SmallLDL<N>& v, const double (&o)[NE]) {
+        int f = 0;
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+#pragma unroll
+            for (int c = 0; c < i; ++c) v.l[i][c] = o[f++];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v.dinv[i] = o[f++];
+    }
+    // "S^-1 = 0": solve() returns the zero vector (a knot with nothing free)
+    static __device__ __forceinline__ void zero(SmallLDL<N>& v) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            v.dinv[i] = 0.0;
+#pragma unroll
+            for (int c = 0; c < N; ++c) v.l[i][c] = 0.0;
+        }
+    }
+};
+
 // Monomial coefficients (ascending powers, segment-local time: the reference's coef_1d_ layout,
 // minimum_control.cpp:186) of one segment of one axis from its Hermite data.
 //   ys / ye : derivatives 1..R-1 at the segment start / end;  p0 / p1 : positions.

@@ -624,6 +624,7 @@ struct uavqp_ctx {
     int num_cus = 256;
     double* ws = nullptr;
     size_t ws_bytes = 0;
+    void* dbg_queue = nullptr;  // (debug builds) where the last corridor solve kept its work counter
     int32_t* perm = nullptr;  // ragged dealing permutation (window_sort_kernel)
     size_t perm_count = 0;
     double* dummy = nullptr;
@@ -1095,7 +1096,7 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     const long long max_grid = (long long)ctx->num_cus * 4;
     if (grid > max_grid) grid = max_grid;
     const int NT = uavqp::corridor_lds_knots(r);
-    const int F = r * (r - 1) / 2 + 2 * r + 1;  // must match corridor_solve_kernel's state layout
+    const int F = r * (r + 1) / 2 + r + 1;  // must match corridor_solve_kernel's state layout
     const int own_max = (Mmax + 1) / 2;        // own knots of the longer half, meeting knot included
     const int ws_knots = own_max > NT ? own_max - NT : 0;
     long long rows = 0;                        // waypoint rows of the batch
@@ -1111,21 +1112,32 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     }
     const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
     const size_t b_queue = 256;
+    const size_t b_desc = align256(sizeof(unsigned long long) * 3 * (size_t)n_traj);
     const size_t b_state = sizeof(double) * (size_t)ws_knots * F * (size_t)grid * 64;
-    int rc = ensure_ws(ctx, b_xsol + b_queue + b_state);
+    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_state);
     if (rc != UAVQP_OK) return rc;
     a.coeff = d_coeff_out;
     a.xsol = ctx->ws;
     a.queue = (unsigned int*)((char*)ctx->ws + b_xsol);
-    a.ws = ws_knots > 0 ? (double*)((char*)ctx->ws + b_xsol + b_queue) : nullptr;
+    ctx->dbg_queue = a.queue;
+    a.desc = (unsigned long long*)((char*)ctx->ws + b_xsol + b_queue);
+    a.ws = ws_knots > 0 ? (double*)((char*)ctx->ws + b_xsol + b_queue + b_desc) : nullptr;
     a.ws_knots = ws_knots;
     a.order = nullptr;
+#ifdef UAVQP_CORRIDOR_TIMING
+    a.stamps = (long long*)((char*)a.queue + 64);   // debug build: section cycles of wave 0, read back by uavqp_debug_corridor_stamps
+#endif
     UAVQP_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
     if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
     const long long chunks = 3LL * (rows - n_traj);  // (trajectory, axis, segment) triples
     long long egrid = (chunks + 255) / 256;
     if (egrid > (long long)ctx->num_cus * 16) egrid = (long long)ctx->num_cus * 16;
+    {
+        long long pgrid = (pairs + 255) / 256;
+        if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
+        hipLaunchKernelGGL(uavqp::corridor_prep_kernel, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
+    }
     if (r == 3) {
         if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
@@ -1138,6 +1150,16 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }
+
+#ifdef UAVQP_CORRIDOR_TIMING
+// debug build only (tools/corridor_sections.py): cycles wave 0 of the last corridor solve spent per section
+extern "C" int uavqp_debug_corridor_stamps(uavqp_ctx* ctx, long long* out7) {
+    if (!ctx || !out7 || !ctx->ws) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    UAVQP_HIP(hipMemcpy(out7, (char*)ctx->dbg_queue + 64, 7 * sizeof(long long), hipMemcpyDeviceToHost));
+    return UAVQP_OK;
+}
+#endif
 
 extern "C" int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                                  const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
