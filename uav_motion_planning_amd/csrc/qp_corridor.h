@@ -102,6 +102,42 @@ __device__ __forceinline__ unsigned long long swap_pair_u64(unsigned long long v
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Dealing order of a RAGGED batch: trajectories by descending segment count (global counting sort: histogram, scan, scatter).
+// A wave sweeps as long as its longest half, so problems of similar length should share a wave; and the longest problems --
+// which also need the most iterations -- start first instead of stretching the tail of the launch.  The order inside a bin is
+// whatever the atomics give: it decides which lane pair solves a problem, never its result.
+__global__ __launch_bounds__(256) void seg_hist_kernel(const int32_t* __restrict__ seg_offsets, int n_traj, int* __restrict__ hist) {
+    __shared__ int s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n_traj; b += gridDim.x * blockDim.x) {
+        int M = seg_offsets[b + 1] - seg_offsets[b];
+        M = M < 0 ? 0 : (M > 255 ? 255 : M);
+        atomicAdd(&s_h[M], 1);
+    }
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void seg_scan_kernel(const int* __restrict__ hist, int* __restrict__ cursor) {
+    __shared__ int s_c[256];
+    s_c[threadIdx.x] = hist[255 - threadIdx.x];   // position t <-> segment count 255 - t: longest first
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; ++t) { const int c = s_c[t]; s_c[t] = run; run += c; }
+    }
+    __syncthreads();
+    cursor[255 - threadIdx.x] = s_c[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void seg_scatter_kernel(const int32_t* __restrict__ seg_offsets, int n_traj, int* __restrict__ cursor,
+                                                          int32_t* __restrict__ order) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < n_traj; b += gridDim.x * blockDim.x) {
+        int M = seg_offsets[b + 1] - seg_offsets[b];
+        M = M < 0 ? 0 : (M > 255 ? 255 : M);
+        order[atomicAdd(&cursor[M], 1)] = b;
+    }
+}
+
 // One lane per (trajectory, axis): validation of the inputs and the permanent pins (lo == hi: a true equality row, as in the
 // reference), once per solve and off the solver's critical path -- a persistent wave that takes a new problem must not stall
 // the other 31 problems of the wave behind serial validation loads.
@@ -770,11 +806,17 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                 const int j = mm - s;
                 if (done && j >= 1 && (s > 0 || !isR)) {  // the meeting knot is written by the L lane
                     const int kk = korig(j);
-                    double rec[F], xs[R];
-                    ld_rec(s, rec);
+                    double xs[R], zs;
+                    if (in_lds(s)) {
 #pragma unroll
-                    for (int q = 0; q < R; ++q) xs[q] = rec[F_X + q];
-                    if (bit(pin, kk)) xs[0] = rec[F_Z];  // pinned positions: exact bound value
+                        for (int q = 0; q < R; ++q) xs[q] = L(s, F_X + q);
+                        zs = L(s, F_Z);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < R; ++q) xs[q] = G(s, F_X + q);
+                        zs = G(s, F_Z);
+                    }
+                    if (bit(pin, kk)) xs[0] = zs;  // pinned positions: exact bound value
                     double* o = a.xsol + (base3 + 3LL * kk) * R;
 #pragma unroll
                     for (int q = 0; q < R; ++q) o[q] = (isR && (q & 1)) ? -xs[q] : xs[q];  // back to the original frame

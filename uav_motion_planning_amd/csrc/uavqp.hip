@@ -1113,17 +1113,32 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
     const size_t b_queue = 256;
     const size_t b_desc = align256(sizeof(unsigned long long) * 3 * (size_t)n_traj);
+    const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort;
+    const size_t b_order = deal_by_length ? align256(sizeof(int32_t) * (size_t)n_traj) + 2048 : 0;   // order + histogram + cursors
     const size_t b_state = sizeof(double) * (size_t)ws_knots * F * (size_t)grid * 64;
-    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_state);
+    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state);
     if (rc != UAVQP_OK) return rc;
     a.coeff = d_coeff_out;
     a.xsol = ctx->ws;
     a.queue = (unsigned int*)((char*)ctx->ws + b_xsol);
     ctx->dbg_queue = a.queue;
     a.desc = (unsigned long long*)((char*)ctx->ws + b_xsol + b_queue);
-    a.ws = ws_knots > 0 ? (double*)((char*)ctx->ws + b_xsol + b_queue + b_desc) : nullptr;
+    a.ws = ws_knots > 0 ? (double*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order) : nullptr;
     a.ws_knots = ws_knots;
     a.order = nullptr;
+    if (deal_by_length) {
+        char* po = (char*)ctx->ws + b_xsol + b_queue + b_desc;
+        int32_t* d_order = (int32_t*)po;
+        int* d_hist = (int*)(po + b_order - 2048);
+        int* d_cursor = d_hist + 256;
+        UAVQP_HIP(hipMemsetAsync(d_hist, 0, 256 * sizeof(int), ctx->stream));
+        int sg = (n_traj + 255) / 256;
+        if (sg > ctx->num_cus * 4) sg = ctx->num_cus * 4;
+        hipLaunchKernelGGL(uavqp::seg_hist_kernel, dim3(sg), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, d_hist);
+        hipLaunchKernelGGL(uavqp::seg_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_hist, d_cursor);
+        hipLaunchKernelGGL(uavqp::seg_scatter_kernel, dim3(sg), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, d_cursor, d_order);
+        a.order = d_order;
+    }
 #ifdef UAVQP_CORRIDOR_TIMING
     a.stamps = (long long*)((char*)a.queue + 64);   // debug build: section cycles of wave 0, read back by uavqp_debug_corridor_stamps
 #endif
