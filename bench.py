@@ -5,13 +5,23 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path (uavqp_solve_batch_device: assembly + factorisation + solve +
-coefficient write-back for all 3 axes) over one batch of synthetic waypoints already resident in HBM.
-Workload at N=1: BASELINE.json configs[1] -- 4096 independent 8-segment 7th-order (min-snap) 3-axis
-trajectories, synthetic A*-like waypoints (uav_motion_planning_amd/workloads.py, seed 20260925+2).
-N>1: every rank solves its own 4096-trajectory shard (weak scaling, no data-path collective in the
-timed loop); the RCCL all-gather of the solved coefficient shards is run and timed separately and
-reported under "allgather" (DESIGN.md section 7).
+A "step" = one pass of the hot path (uavqp_solve_batch_device: assembly + factorisation + solve + coefficient write-back for
+all 3 axes) over one batch of synthetic waypoints already resident in HBM.
+
+--config 2 (default; BASELINE.json configs[1], the configuration the metric is quoted on): 4096 independent 8-segment
+  7th-order (min-snap) 3-axis trajectories per GPU, synthetic A*-like waypoints (workloads.py, seed 20260925+2).  N > 1: every
+  rank solves its own 4096-trajectory shard (weak scaling, no data-path collective in the timed loop).
+--config 4 (BASELINE.json configs[3]): ONE batch of 32768 ragged (4-24 segment) min-snap QPs, kino-A*-like inputs, sharded
+  over the N ranks by segment count (uavqp_shard_bounds_ragged); strong scaling.
+In both modes the RCCL all-gather of the solved coefficient shards (uavqp_allgather_coeffs: the ctx-owned communicator of the
+C ABI, device buffers, in place) is run and timed separately and reported under "allgather" (DESIGN.md section 7).
+
+What is timed: the K steps are replayed as ONE hipGraph of K launches (uavqp_capture_*; --graph 0 = K eager launches), step i
+reads and writes buffer set i mod S where the S sets together exceed the 256 MiB Infinity Cache (no step finds its inputs
+or its output lines in a cache: the roofline figure is an HBM figure at every batch size).  The K-step block is bracketed by
+barrier + synchronize on both sides and by HIP events on the launch stream; it is repeated R >= 10 times and the MEDIAN block
+is reported (`ms_per_step` = block / K), MAX over ranks.  `roofline.achieved` uses the same clock as `value` (the HIP-event
+time of that block), never a different estimator.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,7 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+INFINITY_CACHE_BYTES = 256 << 20  # buffer sets rotate over more than this
 
 
 def parse():
@@ -34,60 +45,74 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU per step")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4], help="2: 4096 x 8-segment snap per GPU (headline); 4: 32768 ragged, sharded")
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (config 2; default 4096) / in total (config 4; default 32768)")
     ap.add_argument("--segments", type=int, default=8)
     ap.add_argument("--order", type=int, default=4, help="4 = min-snap (7th-order), 3 = min-jerk")
     ap.add_argument("--time-mode", default="distance", choices=["reference", "distance", "wide"])
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (0 auto)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="trajectories in the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="independent HIP streams the steps are issued on round-robin (0 = auto = 1; 2 pipelines consecutive steps: "
-                         "+40 % trajectories/s at the 4096 batch, but each kernel then shares the GPU and its own duration grows)")
-    ap.add_argument("--graph", type=int, default=0, metavar="G",
-                    help="replay the steps as hipGraphs of G launches per stream (uavqp_capture_*): takes the per-launch host "
-                         "cost and part of the inter-kernel gap out (measured with G = 50: 6.11 -> 5.85 us per step on one stream, "
-                         "1.06e9 trajectories/s on four); 0 = plain launches (default)")
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step block (0 = auto: >= 10, about 0.25 s in total)")
+    ap.add_argument("--graph", type=int, default=1, help="1: the K steps are one hipGraph of K launches (default); 0: K eager launches")
+    ap.add_argument("--sets", type=int, default=0, help="distinct in/out buffer sets the steps rotate over (0 = auto: > 256 MiB in total)")
+    ap.add_argument("--pipelined-streams", type=int, default=4, help="streams of the `pipelined` sub-record (0 = skip it)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (nccl) and run the barrier / all-reduce / all-gather code even at world size 1 (self-test)")
+                    help="initialise torch.distributed and run the barrier / communicator / all-gather code even at world size 1 (self-test)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child run under rocprofv3: kernels only
     ap.add_argument("--data", default="astar", choices=["astar", "uniform"],
                     help="astar: configs[1] generator; uniform: iid waypoints/times (tuning aid)")
     return ap.parse_args()
 
 
-CPU_BASELINE_SECONDS = 10.0
+CPU_BASELINE_SECONDS = 8.0
+
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
 
 
 def cpu_baseline(batch, r, n_sample):
-    """OSQP-faithful CPU restatement (oracle/osqp_port.c) timed on this host's cores: one full
-    setup+solve+cleanup per axis, exactly the reference's call pattern (test_minimum_jerk.cpp:75,100,125;
-    minimum_control.cpp:164-190), reference settings, stdout dumps excluded.  The reference itself cannot
-    be built (OSQP / osqp-eigen / Eigen / ROS absent), hence kind = "port"."""
+    """OSQP-faithful CPU restatement (oracle/osqp_port.c) timed on this host's cores: one full setup+solve+cleanup per
+    axis, exactly the reference's call pattern (test_minimum_jerk.cpp:75,100,125; minimum_control.cpp:164-190), reference
+    settings, stdout dumps excluded.  The reference itself cannot be built (OSQP / osqp-eigen / Eigen / ROS absent), hence
+    kind = "port".  value = 1 core (the reference is single-threaded); all_cores = one trajectory per thread on the
+    physical cores: warm-up pass, then the median of 7 passes."""
     from oracle import oracle
     oracle.build()
     n = min(n_sample, batch["waypoints"].shape[0])
     M = batch["M"]
     so = batch["seg_offsets"][: n + 1]
     args = (r, so, batch["waypoints"][:n], batch["times"][:n], batch["bc"][:n])
-    # bounded sample of about 10 s of single-core work: the batch is passed over repeatedly (same inputs)
-    passes, dt1 = 0, 0.0
-    while passes == 0 or (dt1 < CPU_BASELINE_SECONDS and passes < 16):
+    # bounded sample: the batch is passed over repeatedly (same inputs) for about CPU_BASELINE_SECONDS of single-core work
+    passes, dts = 0, []
+    while passes == 0 or (sum(dts) < CPU_BASELINE_SECONDS and passes < 16):
         t0 = time.perf_counter()
         _, st, iters = oracle.osqp_solve_batch(*args, threads=1)
-        dt1 += time.perf_counter() - t0
+        dts.append(time.perf_counter() - t0)
         passes += 1
-    dt1 /= passes
-    cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    oracle.osqp_solve_batch(*args, threads=cores)
-    dtn = time.perf_counter() - t0
+    dt1 = float(np.median(dts))
+    cores = physical_cores()
+    oracle.osqp_solve_batch(*args, threads=cores)   # warm-up: thread pool, page faults
+    dtn = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        oracle.osqp_solve_batch(*args, threads=cores)
+        dtn.append(time.perf_counter() - t0)
     return {"value": n / dt1, "unit": "trajectories/s", "cores": 1, "kind": "port",
             "sample": f"first {n} trajectories of the same batch (M={M}, r={r}); OSQP-port, reference settings "
-                      f"(eps 1e-3, max_iter 1000), 3 x (setup+solve+cleanup) per trajectory; {passes} passes of {dt1:.2f} s on 1 core; "
+                      f"(eps 1e-3, max_iter 1000), 3 x (setup+solve+cleanup) per trajectory; median of {passes} passes of {dt1:.2f} s on 1 core; "
                       f"median {int(np.median(iters))} ADMM iterations, {int((st == 1).sum())}/{n} reported solved",
-            "all_cores": {"value": n / dtn, "cores": cores}}
+            "all_cores": {"value": n / float(np.median(dtn)), "cores": cores, "passes_s": [round(x, 4) for x in dtn],
+                          "note": "physical cores, one trajectory per thread; warm-up pass excluded, median of 7"}}
 
 
 def measure_traffic(args):
@@ -109,9 +134,9 @@ def measure_traffic(args):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="uavqp_pmc_", dir="/tmp")
             cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                   sys.executable, os.path.abspath(__file__), "--inner", "--steps", "10", "--warmup", "2",
-                   "--batch", str(args.batch), "--segments", str(args.segments), "--order", str(args.order),
-                   "--time-mode", args.time_mode, "--variant", str(args.variant), "--streams", str(args.streams)]
+                   sys.executable, os.path.abspath(__file__), "--inner", "--steps", "40", "--warmup", "2", "--repeats", "1", "--graph", "0",
+                   "--config", str(args.config), "--batch", str(args.batch), "--segments", str(args.segments), "--order", str(args.order),
+                   "--time-mode", args.time_mode, "--variant", str(args.variant), "--pipelined-streams", "0", "--no-allgather"]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             vals = []
@@ -135,12 +160,14 @@ def main():
     import torch.distributed as dist
 
     import uav_motion_planning_amd as U
+    from uav_motion_planning_amd import distributed as D
     from uav_motion_planning_amd import workloads as W
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
+    backend = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -154,8 +181,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    else:
-        backend = None
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the uavqp product path has no CPU fallback")
@@ -163,67 +188,66 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    coll_dev = dev if backend in (None, "nccl") else torch.device("cpu")
+    rccl_ok = backend in (None, "nccl")
 
-    r, M, B = args.order, args.segments, args.batch
-    batch = W.uniform_batch(2, B, M, r, time_mode=args.time_mode, seed=W.SEED0 + 2 + 1000 * rank)
-    if args.data == "uniform":
-        rng = np.random.default_rng(1)
-        batch["waypoints"] = rng.uniform(-2, 2, size=batch["waypoints"].shape)
-        batch["times"] = rng.uniform(0.5, 2.0, size=batch["times"].shape)
-        batch["bc"] = np.zeros_like(batch["bc"])
-    d_wp = torch.from_numpy(batch["waypoints"]).to(dev)
-    d_T = torch.from_numpy(batch["times"]).to(dev)
-    d_bc = torch.from_numpy(batch["bc"]).to(dev)
-    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-    S = args.streams if args.streams > 0 else 1
-    # one ctx + stream + output buffer per pipeline slot: step i runs on slot i % S.  Steps are independent
-    # batches, so consecutive steps may overlap on the GPU (kernel boundary of one hides under the next).
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    ctxs, d_outs = [], []
-    for st_ in streams:
+    r = args.order
+    K = args.steps
+    # ------------------------------------------------------------------ workload: this rank's shard, S distinct buffer sets
+    if args.config == 2:
+        M = args.segments
+        B = args.batch if args.batch > 0 else 4096
+        batch = W.uniform_batch(2, B, M, r, time_mode=args.time_mode, seed=W.SEED0 + 2 + 1000 * rank)
+        if args.data == "uniform":
+            rng = np.random.default_rng(1)
+            batch["waypoints"] = rng.uniform(-2, 2, size=batch["waypoints"].shape)
+            batch["times"] = rng.uniform(0.5, 2.0, size=batch["times"].shape)
+            batch["bc"] = np.zeros_like(batch["bc"])
+        n_local, n_total, uni, mx = B, world * B, M, M
+        seg_local = B * M
+        bytes_local = B * W.algorithmic_bytes(r, M)
+        h_so = None
+        shard = batch
+        bounds = [g * B for g in range(world + 1)]
+        c_counts = [3 * 2 * r * seg_local] * world
+        workload = (f"configs[1]: batch of {B} independent {M}-segment order-{2 * r - 1} (r={r}) 3-axis trajectories per GPU, "
+                    f"synthetic A*-like waypoints, time allocation '{args.time_mode}'")
+        scaling = "weak"
+    else:
+        n_total = args.batch if args.batch > 0 else 32768
+        full = W.ragged_batch(4, n_total, r)                      # identical on every rank (seeded)
+        so = np.asarray(full["seg_offsets"], dtype=np.int64)
+        bounds = D.shard_bounds_ragged(so, world)                  # uavqp_shard_bounds_ragged: balanced by segment count
+        shard = D.local_slice(full, bounds[rank], bounds[rank + 1])
+        h_so = shard["seg_offsets"]
+        n_local, uni, mx = bounds[rank + 1] - bounds[rank], 0, 24
+        seg_local = int(h_so[-1])
+        Ms = np.diff(h_so)
+        bytes_local = int(sum(W.algorithmic_bytes(r, int(m)) for m in Ms)) + 4 * n_local
+        c_counts = [3 * 2 * r * int(so[bounds[g + 1]] - so[bounds[g]]) for g in range(world)]
+        workload = (f"configs[3]: ONE batch of {n_total} ragged (4-24 segment) order-{2 * r - 1} 3-axis trajectories, kino-A*-like roll-outs, "
+                    f"sharded over {world} GPU(s) by segment count (this rank: {n_local} trajectories, {seg_local} segments)")
+        scaling = "strong"
+    set_bytes = 8 * (np.asarray(shard["waypoints"]).size + np.asarray(shard["times"]).size + np.asarray(shard["bc"]).size + 3 * 2 * r * seg_local)
+    S = args.sets if args.sets > 0 else int(INFINITY_CACHE_BYTES // set_bytes) + 2
+    S = max(1, min(S, 4096))
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_so = up(h_so) if h_so is not None else None
+    sets = []
+    for _ in range(S):
+        sets.append(dict(wp=up(np.asarray(shard["waypoints"]).reshape(-1, 3)), T=up(np.asarray(shard["times"]).reshape(-1)),
+                         bc=up(shard["bc"]), out=torch.zeros(3 * 2 * r * seg_local, dtype=torch.float64, device=dev)))
+    d_st = torch.zeros(max(n_local, 1), dtype=torch.int32, device=dev)
+
+    def make_slot():
+        st_ = torch.cuda.Stream(device=dev)
         c = U.Context(local_rank)
         c.set_stream(st_.cuda_stream)
         c.set_variant(args.variant)
-        ctxs.append(c)
-        d_outs.append(torch.zeros(B * 3 * M * 2 * r, dtype=torch.float64, device=dev))
-    d_out = d_outs[0]
-    stream = streams[0]
+        return st_, c
 
-    def launch(k):
-        ctxs[k].solve_batch_device(r, B, M, M, None, d_wp, d_T, d_bc, d_outs[k], d_st)
-
-    graphs = None
-    if args.graph > 0:
-        # one executable hipGraph of G launches per pipeline slot (uavqp_capture_*): a "step" stays one kernel launch over
-        # one batch, steps are replayed G at a time; whatever does not fill a whole group is launched eagerly.
-        for k in range(S):
-            launch(k)          # eager once: sizes the workspaces before capture
-        torch.cuda.synchronize()
-        graphs = []
-        for k in range(S):
-            ctxs[k].capture_begin()
-            for _ in range(args.graph):
-                launch(k)
-            graphs.append(ctxs[k].capture_end())
-        for k in range(S):
-            ctxs[k].graph_launch(graphs[k])   # first replay uploads the graph: keep that out of the timed region
-        torch.cuda.synchronize()
-
-    def run_steps(n):
-        """Exactly n launches, round-robin over the pipeline slots."""
-        done, per_slot = 0, [0] * S
-        if graphs is not None:
-            k = 0
-            while n - done >= args.graph:
-                ctxs[k].graph_launch(graphs[k])
-                done += args.graph
-                per_slot[k] += args.graph
-                k = (k + 1) % S
-        for i in range(n - done):
-            launch(i % S)
-            per_slot[i % S] += 1
-        return per_slot
+    def launch(c, i):
+        s = sets[i % S]
+        c.solve_batch_device(r, n_local, uni, mx, d_so, s["wp"], s["T"], s["bc"], s["out"], d_st)
 
     def fence():
         torch.cuda.synchronize()
@@ -231,95 +255,181 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_steps(args.warmup)
+    stream, ctx = make_slot()
+    for i in range(max(args.warmup, 1)):       # also sizes the workspaces before any capture
+        launch(ctx, i)
     fence()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
-    t0 = time.perf_counter()
-    for k in range(S):
-        ev0[k].record(streams[k])
-    per_slot = run_steps(args.steps)
-    for k in range(S):
-        ev1[k].record(streams[k])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0   # this rank's K steps, complete on the device; MAX over ranks below
-    fence()                         # closing barrier + synchronize (its own cost is not part of the K steps)
-    # average time one launch occupies its stream (kernel + boundary), from the events of the timed region
-    region_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) / per_slot[k] for k in range(S) if per_slot[k] > 0]))
+    graph = None
+    if args.graph and K > 0:
+        ctx.capture_begin()
+        for i in range(K):
+            launch(ctx, i)
+        graph = ctx.capture_end()
+        ctx.graph_launch(graph)                # first replay uploads the graph: keep that out of the timed region
+        fence()
+
+    def block():
+        if graph is not None:
+            ctx.graph_launch(graph)
+        else:
+            for i in range(K):
+                launch(ctx, i)
+
+    # ------------------------------------------------------------------ the timed K-step block, repeated, median
+    if args.repeats > 0:
+        R = args.repeats
+    else:
+        t0 = time.perf_counter()
+        block()
+        torch.cuda.synchronize()
+        est = max(time.perf_counter() - t0, 1e-6)
+        R = int(min(200, max(10, 0.25 / est)))
+        if use_dist:
+            tR = torch.tensor([R], dtype=torch.int64, device=dev if rccl_ok else torch.device("cpu"))
+            dist.all_reduce(tR, op=dist.ReduceOp.MIN)
+            R = int(tR.item())
+    wall, evt = [], []
+    for _ in range(R):
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        block()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t0)   # this rank's K steps, complete on the device
+        fence()                                 # closing barrier + synchronize (its own cost is not part of the K steps)
+        evt.append(e0.elapsed_time(e1) * 1e-3)
+    dt = float(np.median(wall))
+    dt_evt = float(np.median(evt))
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        t = torch.tensor([dt, dt_evt], dtype=torch.float64, device=dev if rccl_ok else torch.device("cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert int((d_st == U.UAVQP_SOLVED).sum().item()) == B, "some trajectories were not solved"
-
-    # per-launch kernel duration: HIP events bracketing each launch on its launch stream (post-pass, same
-    # round-robin issue pattern as the timed region)
-    n_ev = min(args.steps, 200)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    for i, (a, b) in enumerate(evs):
-        a.record(streams[i % S])
-        launch(i % S)
-        b.record(streams[i % S])
-    torch.cuda.synchronize()
-    per_launch_ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
-    kernel_ms = min(per_launch_ms, region_ms)
-
-    gather = None
-    if use_dist and not args.no_allgather:
-        # RCCL all-gather of the solved coefficient shards over xGMI (equal shards)
-        g_src = d_out if coll_dev == dev else d_out.cpu()   # (gloo self-test: CPU tensors)
-        full = torch.empty(world * d_out.numel(), dtype=torch.float64, device=coll_dev)
-        for _ in range(3):
-            dist.all_gather_into_tensor(full, g_src)
-        fence()
-        g0 = time.perf_counter()
-        n_g = 10
-        for _ in range(n_g):
-            dist.all_gather_into_tensor(full, g_src)
-        fence()
-        g_ms = (time.perf_counter() - g0) / n_g * 1e3
-        ok = bool(torch.equal(full[rank * d_out.numel():(rank + 1) * d_out.numel()], g_src))
-        gather = {"ms": g_ms, "bytes_per_rank_out": d_out.numel() * 8, "bytes_total": full.numel() * 8,
-                  "own_shard_intact": ok,
-                  "value_with_gather": world * B / (dt / args.steps + g_ms * 1e-3)}
-
+        dt, dt_evt = float(t[0].item()), float(t[1].item())
+    if n_local > 0:
+        assert int((d_st[:n_local] == U.UAVQP_SOLVED).sum().item()) == n_local, "some trajectories were not solved"
     if args.inner:
         return
+
+    # ------------------------------------------------------------------ pipelined sub-record: the same K steps dealt to P streams
+    pipelined = None
+    if args.pipelined_streams > 1 and K >= args.pipelined_streams:
+        P = args.pipelined_streams
+        slots = [(stream, ctx)] + [make_slot() for _ in range(P - 1)]
+        for k, (_, c) in enumerate(slots):
+            launch(c, k)
+        torch.cuda.synchronize()
+        graphs = []
+        for k, (_, c) in enumerate(slots):
+            c.capture_begin()
+            for i in range(k, K, P):
+                launch(c, i)
+            graphs.append(c.capture_end())
+            c.graph_launch(graphs[-1])
+        torch.cuda.synchronize()
+        pw = []
+        for _ in range(R):
+            fence()
+            t0 = time.perf_counter()
+            for (_, c), g_ in zip(slots, graphs):
+                c.graph_launch(g_)
+            torch.cuda.synchronize()
+            pw.append(time.perf_counter() - t0)
+            fence()
+        pdt = float(np.median(pw))
+        if use_dist:
+            t = torch.tensor([pdt], dtype=torch.float64, device=dev if rccl_ok else torch.device("cpu"))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pdt = float(t.item())
+        pipelined = {"streams": P, "value": n_total * K / pdt if args.config == 4 else world * n_local * K / pdt, "ms_per_step": pdt / K * 1e3,
+                     "note": f"the same {K} steps dealt round-robin to {P} streams, one hipGraph each: consecutive steps overlap on the GPU "
+                             "(each kernel then shares the machine; per-kernel duration is not comparable with the single-stream figure)"}
+        for (_, c), g_ in zip(slots, graphs):
+            c.graph_destroy(g_)
+
+    # ------------------------------------------------------------------ the exchange step: all-gather of the coefficient shards
+    gather = None
+    if use_dist and not args.no_allgather:
+        tot = sum(c_counts)
+        full_out = torch.zeros(tot, dtype=torch.float64, device=dev)
+        off = sum(c_counts[:rank])
+        mine = full_out[off:off + c_counts[rank]]
+        mine.copy_(sets[0]["out"])
+        gctx = None
+        if rccl_ok:
+            D.create_comm(ctx)                 # ctx-owned RCCL communicator (uavqp_comm_create); torch.distributed ships the unique id
+            gctx = ctx
+            do = lambda: D.allgather_shards(mine, c_counts, full_out, ctx)
+        else:
+            cpu_full, cpu_mine = full_out.cpu(), mine.cpu()
+            do = lambda: D.allgather_shards(cpu_mine, c_counts, cpu_full, None)
+        for _ in range(3):
+            do()
+        gt = []
+        for _ in range(10):
+            fence()
+            g0 = time.perf_counter()
+            do()
+            if gctx is not None:
+                gctx.synchronize()
+            torch.cuda.synchronize()
+            gt.append(time.perf_counter() - g0)
+        fence()
+        g_s = float(np.median(gt))
+        t = torch.tensor([g_s], dtype=torch.float64, device=dev if rccl_ok else torch.device("cpu"))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g_s = float(t.item())
+        got = full_out if rccl_ok else cpu_full.to(dev)
+        ok = bool(torch.equal(got[off:off + c_counts[rank]], sets[0]["out"]))
+        n_step = n_total if args.config == 4 else world * n_local
+        gather = {"ms": g_s * 1e3, "bytes_per_rank_out": c_counts[rank] * 8, "bytes_total": tot * 8, "own_shard_intact": ok,
+                  "through": "uavqp_allgather_coeffs (RCCL, ctx communicator)" if rccl_ok else f"torch.distributed/{backend} stand-in",
+                  "value_with_gather": n_step / (dt / K + g_s)}
+        if gctx is not None:
+            gctx.comm_destroy()
+
     out = None
     if rank == 0:
-        bytes_per_traj = W.algorithmic_bytes(r, M)
-        achieved = B * bytes_per_traj / (kernel_ms * 1e-3) / 1e9
+        n_step = n_total if args.config == 4 else world * n_local
+        per_launch_s = dt_evt / K
+        achieved = bytes_local / per_launch_s / 1e9
         n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 4096
-        cpu = cpu_baseline(batch, r, n_cpu) if (n_cpu > 0 and world == 1) else None
+        cpu = cpu_baseline(batch, r, n_cpu) if (n_cpu > 0 and world == 1 and args.config == 2) else None
         traffic = measure_traffic(args) if (world == 1 and not args.no_traffic) else None
         out = {
-            "metric": "trajectories/sec (8-seg 7th-order min-snap, 3-axis)",
-            "value": world * B * args.steps / dt,
+            "metric": "trajectories/sec (8-seg 7th-order min-snap, 3-axis)" if args.config == 2 else "trajectories/sec (32768 ragged 4-24-seg min-snap, 3-axis, sharded)",
+            "value": n_step * K / dt,
             "unit": "trajectories/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": K,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": dt / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch of {B} independent {M}-segment order-{2 * r - 1} "
-                                   f"(r={r}) 3-axis trajectories per GPU, synthetic A*-like waypoints, "
-                                   f"time allocation '{args.time_mode}'",
-                       "batch_per_gpu": B, "segments": M, "r": r, "variant": args.variant, "streams": S, "graph": args.graph,
-                       "parallelism": f"shard{world}"},
+            "config": {"workload": workload, "batch_per_gpu": n_local, "segments": args.segments if args.config == 2 else "4-24", "r": r,
+                       "variant": args.variant, "graph": bool(graph is not None), "buffer_sets": S, "buffer_set_bytes": int(set_bytes),
+                       "repeats": R, "parallelism": f"shard{world}", "shard_bounds": bounds if world <= 16 else None},
+            "timing": {"block_wall_ms_median": dt * 1e3, "block_event_ms_median": dt_evt * 1e3,
+                       "block_wall_ms_min_max": [float(np.min(wall)) * 1e3, float(np.max(wall)) * 1e3], "repeats": R,
+                       "note": "K-step block between barrier + synchronize, repeated; value and ms_per_step from the median wall time (MAX over ranks)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
-                         "traffic_detail": traffic, "algorithmic_bytes_per_launch": B * bytes_per_traj,
-                         "kernel_ms": kernel_ms, "per_launch_event_ms": per_launch_ms,
-                         "stream_ms_per_launch": region_ms,
-                         "algorithmic_bytes_per_trajectory": bytes_per_traj},
+                         "traffic_detail": traffic, "algorithmic_bytes_per_launch": int(bytes_local),
+                         "kernel_ms": per_launch_s * 1e3,
+                         "kernel_ms_is": "HIP events on the launch stream around the timed K-step block / K (same clock as value; includes the inter-kernel gap)",
+                         "working_set_bytes": int(S * set_bytes),
+                         "algorithmic_bytes_per_trajectory": bytes_local / max(n_local, 1)},
             "cpu_baseline": cpu,
         }
+        if pipelined:
+            out["pipelined"] = pipelined
         if gather:
             out["allgather"] = gather
+    if graph is not None:
+        ctx.graph_destroy(graph)
     if use_dist:
         dist.destroy_process_group()  # RCCL prints its version banner here: keep the JSON line last
     if rank == 0:

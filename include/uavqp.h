@@ -54,7 +54,8 @@ enum {
     UAVQP_ERR_INVALID_ARG = -1,
     UAVQP_ERR_HIP = -2,       /* HIP runtime error; uavqp_last_error() has the text */
     UAVQP_ERR_NO_DEVICE = -3, /* no usable gfx950 device: the product path never falls back to CPU */
-    UAVQP_ERR_ALLOC = -4
+    UAVQP_ERR_ALLOC = -4,
+    UAVQP_ERR_RCCL = -5       /* RCCL missing or a collective failed; uavqp_last_error() has the text */
 };
 
 /* per-trajectory status (positive = OSQP's OSQP_SOLVED value, which the reference's solve() maps to true) */
@@ -277,6 +278,35 @@ int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_traj, int unif
                                      int n_rows, const double* d_waypoints, const double* d_times, const double* d_coeff,
                                      const double* d_obstacles, int n_obs, double robot_r, double robot_h, double h_max,
                                      double* d_corr_lo, double* d_corr_hi, double* d_clearance);
+
+/* ---- Multi-GPU: contiguous shards of the batch, one process (or thread) and one ctx per GPU ----
+ * Trajectories are independent QPs, so the solve itself needs no collective: every rank solves its own slice with the entry
+ * points above.  The one exchange step is the all-gather of the solved coefficient shards over xGMI (RCCL).  The reference has
+ * no multi-device code (its only remark on parallelism: test_minimum_jerk.cpp:73-74); nothing to mirror.
+ *
+ *   uavqp_shard_bounds          bounds[g] = floor(n_traj g / world), g = 0..world: rank g owns trajectories [bounds[g], bounds[g+1]).
+ *   uavqp_shard_bounds_ragged   same, balanced by total SEGMENT count (work is proportional to M_b): bounds[g] is the first
+ *                               trajectory whose segment offset reaches g / world of the total.  Host arithmetic on the host CSR
+ *                               offsets; no device, no communicator.
+ *   uavqp_comm_unique_id        fills a UAVQP_UNIQUE_ID_BYTES token on ONE rank (RCCL's ncclGetUniqueId); the caller ships it to
+ *                               the other ranks by whatever it has (MPI, a file, a socket, torch.distributed's store).
+ *   uavqp_comm_create           collective over all ranks: the ctx creates and owns the RCCL communicator (one per ctx; released
+ *                               by uavqp_comm_destroy / uavqp_destroy).  world = 1 is valid (single-GPU self test).
+ *   uavqp_allgather_coeffs      device buffers, asynchronous on the ctx stream (ordered behind the solve): rank g contributes
+ *                               counts[g] doubles from d_local; d_full receives the shards back to back in rank order
+ *                               (sum_g counts[g] doubles).  Equal counts: one ncclAllGather; otherwise every rank sends its shard
+ *                               to every peer directly (grouped ncclSend / ncclRecv: one hop per peer on the xGMI full mesh, no
+ *                               padding).  d_local may alias its own slot of d_full (in place).
+ *   uavqp_allgather_status      the same for the int32 status arrays (counts in trajectories).
+ * RCCL is bound at run time (librccl.so.1); without it uavqp_comm_* return UAVQP_ERR_RCCL and uavqp_last_error() says why. */
+#define UAVQP_UNIQUE_ID_BYTES 128
+int uavqp_shard_bounds(int n_traj, int world, int32_t* bounds);
+int uavqp_shard_bounds_ragged(const int32_t* seg_offsets, int n_traj, int world, int32_t* bounds);
+int uavqp_comm_unique_id(void* id_out);
+int uavqp_comm_create(uavqp_ctx* ctx, int rank, int world, const void* unique_id);
+int uavqp_comm_destroy(uavqp_ctx* ctx);
+int uavqp_allgather_coeffs(uavqp_ctx* ctx, const double* d_local, const int64_t* counts, double* d_full);
+int uavqp_allgather_status(uavqp_ctx* ctx, const int32_t* d_local, const int64_t* counts, int32_t* d_full);
 
 /* hipGraph capture of a launch-bound inner loop: everything enqueued on the ctx stream between
  * uavqp_capture_begin and uavqp_capture_end (any number of uavqp_solve_batch_device calls with their

@@ -1,6 +1,8 @@
-"""CPU, world_size 2, gloo: the N>1 path -- contiguous sharding + all-gather of coefficient shards.
-The per-rank solve is stood in for by the CPU oracle (tests may use it as the checker); the sharding
-and the collective are the product code in uav_motion_planning_amd/distributed.py."""
+"""CPU, world_size 2, gloo: the N>1 path -- contiguous sharding (uavqp_shard_bounds[_ragged] of the C ABI) + the in-place
+all-gather of coefficient and status shards.  The per-rank solve is stood in for by the CPU oracle (tests may use it as the
+checker) and the collective by torch.distributed/gloo (RCCL needs one GPU per rank; the C-ABI communicator itself is
+exercised single-rank on the GPU in tests/test_gpu_comm.py); the sharding, the slicing into views and the gather bookkeeping
+are the product code in uav_motion_planning_amd/distributed.py."""
 import os
 import sys
 
@@ -24,23 +26,23 @@ def _worker(rank, world, port, ragged, q):
     r = 4
     if ragged:
         batch = W.ragged_batch(4, 13, r, m_lo=2, m_hi=6)
-        bounds = D.shard_bounds_ragged(batch["seg_offsets"], world)
     else:
         batch = W.uniform_batch(2, 12, 4, r, time_mode="distance")
-        bounds = D.shard_bounds(12, world)
-    so = batch["seg_offsets"]
-    numels = [3 * 2 * r * int(so[bounds[g + 1]] - so[bounds[g]]) for g in range(world)]
-    loc = D.local_slice(batch, bounds[rank], bounds[rank + 1])
-    coef, st = oracle.solve_exact_batch(r, loc["seg_offsets"], loc["waypoints"], loc["times"],
-                                        loc["bc"].reshape(-1, 2, r - 1, 3))
-    full = D.allgather_coeffs(torch.from_numpy(coef), numels)
+    so = np.asarray(batch["seg_offsets"])
+    tb = dict(r=r, seg_offsets=so, waypoints=torch.from_numpy(np.asarray(batch["waypoints"]).reshape(-1, 3).copy()),
+              times=torch.from_numpy(np.asarray(batch["times"]).reshape(-1).copy()), bc=torch.from_numpy(np.asarray(batch["bc"]).copy()))
+    seen = {}
+
+    def solve_local(sh, c_out, st_out):
+        seen["n"] = len(sh["seg_offsets"]) - 1
+        c, st = oracle.solve_exact_batch(r, sh["seg_offsets"], sh["waypoints"].numpy(), sh["times"].numpy(),
+                                         sh["bc"].numpy().reshape(-1, 2, r - 1, 3))
+        c_out.copy_(torch.from_numpy(c))
+        st_out.copy_(torch.from_numpy(st.astype(np.int32)) + 1)     # oracle: 0 = ok -> 1 (= UAVQP_SOLVED), so that an unwritten slot shows
+    full, status, bounds = D.solve_sharded(tb, solve_local, rank, world)
     ref, _ = oracle.solve_exact_batch(r, so, np.asarray(batch["waypoints"]).reshape(-1, 3), np.asarray(batch["times"]).reshape(-1), batch["bc"])
-    ok = bool(np.array_equal(full.numpy(), ref))
-    # the same step through the one-call helper (shard by segment count -> solve -> all-gather coefficients + statuses)
-    batch = dict(batch, r=r)
-    full2, status2 = D.solve_sharded(batch, lambda sh: oracle.solve_exact_batch(r, sh["seg_offsets"], sh["waypoints"], sh["times"],
-                                                                                sh["bc"].reshape(-1, 2, r - 1, 3)))
-    ok = ok and bool(np.array_equal(full2.numpy(), ref)) and status2.numel() == so.size - 1 and bool((status2 == 0).all())  # oracle: 0 = ok
+    ok = bool(np.array_equal(full.numpy(), ref)) and status.numel() == so.size - 1 and bool((status == 1).all())
+    ok = ok and bounds == D.shard_bounds_ragged(so, world) and seen["n"] == bounds[rank + 1] - bounds[rank]
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -59,3 +61,28 @@ def test_two_rank_shard_and_allgather(oracle, ragged):
     results = sorted(q.get(timeout=5) for _ in range(2))
     assert results == [(0, True), (1, True)]
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_shard_bounds_of_the_c_abi():
+    """uavqp_shard_bounds[_ragged] (pure host arithmetic, callable without a GPU): contiguous, complete, ordered; the ragged
+    partition is balanced by segment count -- bounds[g] is the first trajectory whose offset reaches g / world of the total."""
+    sys.path.insert(0, ROOT)
+    from uav_motion_planning_amd import distributed as D
+    assert D.shard_bounds(10, 3) == [0, 3, 6, 10]
+    assert D.shard_bounds(0, 4) == [0, 0, 0, 0, 0]
+    assert D.shard_bounds(5, 8) == [0, 0, 1, 1, 2, 3, 3, 4, 5]
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        n, world = int(rng.integers(0, 200)), int(rng.integers(1, 9))
+        Ms = rng.integers(0, 25, size=n)
+        so = np.zeros(n + 1, dtype=np.int32)
+        so[1:] = np.cumsum(Ms)
+        b = D.shard_bounds_ragged(so, world)
+        assert b[0] == 0 and b[-1] == n and all(b[g] <= b[g + 1] for g in range(world))
+        total = int(so[-1])
+        for g in range(1, world):
+            want = int(np.searchsorted(so.astype(np.int64) * world, total * g, side="left"))   # exact integer form of the rule
+            assert b[g] == max(min(want, n), b[g - 1])
+        if total > 0 and n >= world:
+            shard = np.diff(so[np.array(b)])
+            assert shard.max() <= total / world + Ms.max()       # no shard exceeds its share by more than one trajectory

@@ -1,0 +1,50 @@
+"""-m gpu: the multi-GPU entry points of the C ABI on ONE GPU (world size 1 -- RCCL wants one GPU per rank, the driver runs
+the real N = 2, 4, 8 through bench.py): uavqp_comm_unique_id / uavqp_comm_create on the ctx, uavqp_allgather_coeffs and
+_status in place and out of place behind a solve on the ctx stream, uavqp_comm_destroy; and distributed.solve_sharded with
+that communicator on device tensors (views in, results written straight into the full output)."""
+import numpy as np
+import pytest
+import torch
+
+import uav_motion_planning_amd as U
+from uav_motion_planning_amd import distributed as D
+from uav_motion_planning_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_communicator_and_sharded_solve(oracle):
+    r, n = 4, 96
+    b = W.ragged_batch(4, n, r, m_lo=2, m_hi=12)
+    so = np.asarray(b["seg_offsets"])
+    dev = torch.device("cuda", 0)
+    tb = dict(r=r, seg_offsets=so, waypoints=torch.from_numpy(np.asarray(b["waypoints"]).reshape(-1, 3)).to(dev),
+              times=torch.from_numpy(np.asarray(b["times"])).to(dev), bc=torch.from_numpy(np.asarray(b["bc"])).to(dev))
+    with U.Context(0) as ctx:
+        uid = U.Context.comm_unique_id()
+        assert len(uid) == 128
+        ctx.comm_create(0, 1, uid)
+        with pytest.raises(U.UavqpError):
+            ctx.comm_create(0, 1, uid)            # one communicator per ctx
+
+        def solve_local(sh, c_out, st_out):
+            d_so = torch.from_numpy(sh["seg_offsets"]).to(dev)
+            ctx.solve_batch_device(r, len(sh["seg_offsets"]) - 1, 0, 12, d_so, sh["waypoints"], sh["times"], sh["bc"], c_out, st_out)
+        coeff, status, bounds = D.solve_sharded(tb, solve_local, 0, 1, ctx=ctx)
+        ctx.synchronize()
+        assert bounds == [0, n]
+        ref, _ = oracle.solve_exact_batch(r, so, np.asarray(b["waypoints"]).reshape(-1, 3), np.asarray(b["times"]), b["bc"])
+        got = coeff.cpu().numpy()
+        assert bool((status == U.UAVQP_SOLVED).all())
+        assert np.max(np.abs(got - ref)) < 1e-8 * np.max(np.abs(ref))
+        # out-of-place gather of a separate local buffer
+        full = torch.zeros_like(coeff)
+        ctx.allgather_coeffs(coeff.clone(), [coeff.numel()], full)
+        st_full = torch.zeros_like(status)
+        ctx.allgather_status(status.clone(), [status.numel()], st_full)
+        ctx.synchronize()
+        assert torch.equal(full, coeff) and torch.equal(st_full, status)
+        ctx.comm_destroy()
+        ctx.comm_destroy()                        # idempotent
+        with pytest.raises(U.UavqpError):
+            ctx.allgather_coeffs(coeff, [coeff.numel()], full)   # no communicator any more

@@ -16,6 +16,8 @@ UAVQP_ERR_INVALID_ARG = -1
 UAVQP_ERR_HIP = -2
 UAVQP_ERR_NO_DEVICE = -3
 UAVQP_ERR_ALLOC = -4
+UAVQP_ERR_RCCL = -5
+UAVQP_UNIQUE_ID_BYTES = 128
 
 UAVQP_SOLVED = 1
 UAVQP_MAX_ITER_REACHED = -2
@@ -47,6 +49,13 @@ SYMBOLS = (
     "uavqp_obstacle_grid_build_device",
     "uavqp_obstacle_grid_destroy",
     "uavqp_ellipsoid_check_grid_device",
+    "uavqp_shard_bounds",
+    "uavqp_shard_bounds_ragged",
+    "uavqp_comm_unique_id",
+    "uavqp_comm_create",
+    "uavqp_comm_destroy",
+    "uavqp_allgather_coeffs",
+    "uavqp_allgather_status",
     "uavqp_capture_begin",
     "uavqp_capture_end",
     "uavqp_graph_launch",
@@ -125,6 +134,13 @@ def lib():
     L.uavqp_obstacle_grid_destroy.argtypes = [vp, vp]
     L.uavqp_ellipsoid_check_grid_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, vp,
                                                     ctypes.c_double, ctypes.c_double, ip, vp]
+    L.uavqp_shard_bounds.argtypes = [i32, i32, ip]
+    L.uavqp_shard_bounds_ragged.argtypes = [ip, i32, i32, ip]
+    L.uavqp_comm_unique_id.argtypes = [vp]
+    L.uavqp_comm_create.argtypes = [vp, i32, i32, vp]
+    L.uavqp_comm_destroy.argtypes = [vp]
+    L.uavqp_allgather_coeffs.argtypes = [vp, dp, vp, dp]
+    L.uavqp_allgather_status.argtypes = [vp, ip, vp, ip]
     L.uavqp_capture_begin.argtypes = [vp]
     L.uavqp_capture_end.argtypes = [vp, ctypes.POINTER(vp)]
     L.uavqp_graph_launch.argtypes = [vp, vp]
@@ -137,5 +153,5 @@ def lib():
 
 def check(rc, what):
     if rc != UAVQP_OK:
-        msg = lib().uavqp_last_error().decode() if rc == UAVQP_ERR_HIP or rc == UAVQP_ERR_NO_DEVICE else ""
+        msg = lib().uavqp_last_error().decode() if rc in (UAVQP_ERR_HIP, UAVQP_ERR_NO_DEVICE, UAVQP_ERR_RCCL, UAVQP_ERR_INVALID_ARG) else ""
         raise UavqpError(f"{what} failed with code {rc} {msg}")

@@ -15,6 +15,7 @@
 
 #include "../../include/uavqp.h"
 #include "qp_device.h"
+#include "uavqp_comm.h"
 
 namespace uavqp {
 
@@ -624,6 +625,7 @@ struct uavqp_ctx {
     int num_cus = 256;
     double* ws = nullptr;
     size_t ws_bytes = 0;
+    uavqp::Comm comm;         // RCCL communicator of the multi-GPU entry points (uavqp_comm_create)
     void* dbg_queue = nullptr;  // (debug builds) where the last corridor solve kept its work counter
     int32_t* perm = nullptr;  // ragged dealing permutation (window_sort_kernel)
     size_t perm_count = 0;
@@ -744,6 +746,7 @@ extern "C" int uavqp_destroy(uavqp_ctx* ctx) {
     if (!ctx) return UAVQP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm.comm) (void)uavqp_comm_destroy(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->perm) (void)hipFree(ctx->perm);
     if (ctx->dummy) (void)hipFree(ctx->dummy);
@@ -1464,4 +1467,129 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
         hipLaunchKernelGGL(uavqp::cloud_corridor_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
+}
+
+// ===================================================================================================
+// Multi-GPU entry points (uavqp_comm.h)
+// ===================================================================================================
+extern "C" int uavqp_shard_bounds(int n_traj, int world, int32_t* bounds) {
+    if (n_traj < 0 || world < 1 || !bounds) return UAVQP_ERR_INVALID_ARG;
+    for (int g = 0; g <= world; ++g) bounds[g] = (int32_t)(((long long)n_traj * g) / world);
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_shard_bounds_ragged(const int32_t* seg_offsets, int n_traj, int world, int32_t* bounds) {
+    if (n_traj < 0 || world < 1 || !bounds || !seg_offsets) return UAVQP_ERR_INVALID_ARG;
+    for (int b = 0; b < n_traj; ++b)
+        if (seg_offsets[b + 1] < seg_offsets[b]) return UAVQP_ERR_INVALID_ARG;
+    const long long total = (long long)seg_offsets[n_traj] - seg_offsets[0];
+    bounds[0] = 0;
+    for (int g = 1; g < world; ++g) {
+        // first trajectory whose offset reaches g / world of the segments (exact integer comparison: off * world >= total * g)
+        const long long want = total * g;
+        const int32_t* lo = seg_offsets + bounds[g - 1];
+        const int32_t* hi = seg_offsets + n_traj;
+        const int32_t* it = std::lower_bound(lo, hi, want, [&](int32_t off, long long w) { return ((long long)off - seg_offsets[0]) * world < w; });
+        bounds[g] = (int32_t)(it - seg_offsets);
+    }
+    bounds[world] = n_traj;
+    return UAVQP_OK;
+}
+
+#define UAVQP_RCCL(expr)                                                                             \
+    do {                                                                                             \
+        ncclResult_t r_ = (expr);                                                                    \
+        if (r_ != ncclSuccess) {                                                                     \
+            g_last_error = std::string(#expr) + ": " + uavqp::rccl().GetErrorString(r_);             \
+            return UAVQP_ERR_RCCL;                                                                   \
+        }                                                                                            \
+    } while (0)
+
+static int rccl_ready() {
+    if (!uavqp::rccl().load()) {
+        g_last_error = uavqp::rccl().error;
+        return UAVQP_ERR_RCCL;
+    }
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_comm_unique_id(void* id_out) {
+    static_assert(UAVQP_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "token size follows RCCL");
+    if (!id_out) return UAVQP_ERR_INVALID_ARG;
+    int rc = rccl_ready();
+    if (rc != UAVQP_OK) return rc;
+    ncclUniqueId id;
+    UAVQP_RCCL(uavqp::rccl().GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_comm_create(uavqp_ctx* ctx, int rank, int world, const void* unique_id) {
+    if (!ctx || !unique_id || world < 1 || rank < 0 || rank >= world) return UAVQP_ERR_INVALID_ARG;
+    if (ctx->comm.comm) { g_last_error = "this ctx already owns a communicator"; return UAVQP_ERR_INVALID_ARG; }
+    int rc = rccl_ready();
+    if (rc != UAVQP_OK) return rc;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    UAVQP_RCCL(uavqp::rccl().CommInitRank(&comm, world, id, rank));
+    ctx->comm.comm = comm;
+    ctx->comm.rank = rank;
+    ctx->comm.world = world;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_comm_destroy(uavqp_ctx* ctx) {
+    if (!ctx) return UAVQP_ERR_INVALID_ARG;
+    if (!ctx->comm.comm) return UAVQP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ncclComm_t c = ctx->comm.comm;
+    ctx->comm = uavqp::Comm();
+    UAVQP_RCCL(uavqp::rccl().CommDestroy(c));
+    return UAVQP_OK;
+}
+
+template <typename T>
+static int allgather_shards(uavqp_ctx* ctx, const T* d_local, const int64_t* counts, T* d_full, ncclDataType_t dt) {
+    if (!ctx || !counts || !d_full) return UAVQP_ERR_INVALID_ARG;
+    if (!ctx->comm.comm) { g_last_error = "no communicator: call uavqp_comm_create first"; return UAVQP_ERR_INVALID_ARG; }
+    const int world = ctx->comm.world, rank = ctx->comm.rank;
+    bool equal = true;
+    int64_t total = 0;
+    for (int g = 0; g < world; ++g) {
+        if (counts[g] < 0) return UAVQP_ERR_INVALID_ARG;
+        equal = equal && counts[g] == counts[0];
+        total += counts[g];
+    }
+    if (total == 0) return UAVQP_OK;
+    if (counts[rank] > 0 && !d_local) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    uavqp::RcclApi& R = uavqp::rccl();
+    if (equal) {
+        UAVQP_RCCL(R.AllGather(d_local, d_full, (size_t)counts[0], dt, ctx->comm.comm, ctx->stream));
+        return UAVQP_OK;
+    }
+    // all-gather-v: every rank sends its shard to every peer directly, one hop per peer on the xGMI full mesh
+    std::vector<int64_t> off(world + 1, 0);
+    for (int g = 0; g < world; ++g) off[g + 1] = off[g] + counts[g];
+    UAVQP_RCCL(R.GroupStart());
+    for (int g = 0; g < world; ++g) {
+        if (g == rank) continue;
+        if (counts[rank] > 0) UAVQP_RCCL(R.Send(d_local, (size_t)counts[rank], dt, g, ctx->comm.comm, ctx->stream));
+        if (counts[g] > 0) UAVQP_RCCL(R.Recv(d_full + off[g], (size_t)counts[g], dt, g, ctx->comm.comm, ctx->stream));
+    }
+    UAVQP_RCCL(R.GroupEnd());
+    if (counts[rank] > 0 && d_local != d_full + off[rank])
+        UAVQP_HIP(hipMemcpyAsync(d_full + off[rank], d_local, sizeof(T) * (size_t)counts[rank], hipMemcpyDeviceToDevice, ctx->stream));
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_allgather_coeffs(uavqp_ctx* ctx, const double* d_local, const int64_t* counts, double* d_full) {
+    return allgather_shards<double>(ctx, d_local, counts, d_full, ncclFloat64);
+}
+
+extern "C" int uavqp_allgather_status(uavqp_ctx* ctx, const int32_t* d_local, const int64_t* counts, int32_t* d_full) {
+    return allgather_shards<int32_t>(ctx, d_local, counts, d_full, ncclInt32);
 }

@@ -148,6 +148,35 @@ class Context:
                                                           p(first_hit), p(flags))
         _lib.check(rc, "uavqp_ellipsoid_check_grid_device")
 
+    # ---- multi-GPU: the ctx owns an RCCL communicator (include/uavqp.h, "Multi-GPU") ----
+    @staticmethod
+    def comm_unique_id():
+        """RCCL rendezvous token (bytes, UAVQP_UNIQUE_ID_BYTES): call on ONE rank, ship it to the others."""
+        buf = ctypes.create_string_buffer(_lib.UAVQP_UNIQUE_ID_BYTES)
+        _lib.check(_lib.lib().uavqp_comm_unique_id(buf), "uavqp_comm_unique_id")
+        return buf.raw
+
+    def comm_create(self, rank, world, unique_id):
+        """Collective over all ranks: create the communicator this ctx owns (world = 1 is a valid self test)."""
+        assert len(unique_id) == _lib.UAVQP_UNIQUE_ID_BYTES
+        buf = ctypes.create_string_buffer(bytes(unique_id), _lib.UAVQP_UNIQUE_ID_BYTES)
+        _lib.check(_lib.lib().uavqp_comm_create(self._h, int(rank), int(world), buf), "uavqp_comm_create")
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_destroy(self):
+        _lib.check(_lib.lib().uavqp_comm_destroy(self._h), "uavqp_comm_destroy")
+
+    def allgather_coeffs(self, local, counts, full):
+        """RCCL all-gather of float64 device shards on the ctx stream: rank g contributes counts[g] doubles of `local`,
+        `full` receives them back to back in rank order (`local` may be the rank's own slice of `full`)."""
+        c = (ctypes.c_int64 * len(counts))(*[int(x) for x in counts])
+        _lib.check(_lib.lib().uavqp_allgather_coeffs(self._h, _ptr(local), c, _ptr(full)), "uavqp_allgather_coeffs")
+
+    def allgather_status(self, local, counts, full):
+        """The same for the int32 status arrays (counts in trajectories)."""
+        c = (ctypes.c_int64 * len(counts))(*[int(x) for x in counts])
+        _lib.check(_lib.lib().uavqp_allgather_status(self._h, _ptr(local), c, _ptr(full)), "uavqp_allgather_status")
+
     def capture_begin(self):
         """Start hipGraph capture of everything subsequently enqueued on the ctx stream."""
         _lib.check(_lib.lib().uavqp_capture_begin(self._h), "uavqp_capture_begin")
