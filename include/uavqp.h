@@ -222,6 +222,16 @@ int uavqp_eval_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segme
                             const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
                             int what, double* d_out);
 
+/* Batched PolyTraj::getTraj + getLength + getMeanVel (src/planner/traj_utils/include/traj_utils/poly_traj.hpp:175-207), the two
+ * evaluator members without a per-sample output: positions sampled at t = 0, dt, 2 dt, ... while t < total time (the reference's
+ * dt is the constant 0.01 and its t is ACCUMULATED in floating point: the sample count follows that accumulation exactly, so a
+ * total time that is a multiple of dt -- the reference's own 1.0 s per segment -- gives the reference's count), length = sum of the
+ * chord lengths between consecutive samples, mean velocity = length / total time.
+ *   d_length / d_mean_vel [n_traj] float64, d_n_samples [n_traj] int32: any of them may be NULL.  Asynchronous on the ctx stream. */
+int uavqp_traj_length_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                             const double* d_times, const double* d_coeff, double dt, double* d_length, double* d_mean_vel,
+                             int32_t* d_n_samples);
+
 /* Batched SE(3) ellipsoid collision check of solved trajectories against an obstacle point cloud
  * (SURVEY.md section 8-f, N4).  Replaces, for every sample of every trajectory, KinoAstar::isCollisionFree(pt, acc)
  * (src/planner/path_searching/src/kino_astar.cpp:721-758): body axis b3 = normalize(acc + 9.81 z),

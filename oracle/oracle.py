@@ -197,6 +197,15 @@ def poly_eval(nc, times, coef_traj, t, what=7):
     return out.reshape(K, 3)
 
 
+def traj_length(nc, times, coef_traj, dt=0.01):
+    """Reference PolyTraj::getTraj + getLength + getMeanVel (poly_traj.hpp:175-207) for one trajectory: (length, mean velocity, samples)."""
+    T, pT = _d(times)
+    c, pc = _d(coef_traj)
+    out = np.zeros(2)
+    n = lib().oracle_traj_length(int(nc), int(T.size), pT, pc, ctypes.c_double(dt), out.ctypes.data_as(_dp))
+    return float(out[0]), float(out[1]), int(n)
+
+
 def is_collision_free(pt, acc, obstacles, robot_r, robot_h):
     """Reference KinoAstar::isCollisionFree(pt, acc) (kino_astar.cpp:721-758) against an obstacle array [n,3]."""
     p, pp = _d(pt)
@@ -256,6 +265,18 @@ def ref_solve(pos_1d, bound_vel, bound_acc, time_vec):
                                         l.ctypes.data_as(_dp), u.ctypes.data_as(_dp), info.ctypes.data_as(_ip), ctypes.byref(eps))
     return dict(ok=(rc == 1), rc=rc, coef=coef, P=P, A=A, l=l, u=u, n=int(info[0]), m=int(info[1]), max_iter=int(info[2]),
                 warm_start=bool(info[3]), p_inserted=int(info[4]), a_inserted=int(info[5]), eps_prim_inf=eps.value)
+
+
+def ref_polytraj_length(nc, times, coef_traj):
+    """The reference's own PolyTraj::getTraj / getLength / getMeanVel (poly_traj.hpp:175-207, dt = 0.01 hard-coded there)."""
+    global _ref
+    if _ref is None:
+        _ref = ctypes.CDLL(_REF_PATH)
+    T, pT = _d(times)
+    c, pc = _d(coef_traj)
+    out = np.zeros(2)
+    n = _ref.ref_polytraj_length(int(nc), int(T.size), pT, pc, out.ctypes.data_as(_dp))
+    return float(out[0]), float(out[1]), int(n)
 
 
 def ref_polytraj_eval(nc, times, coef_traj, t):

@@ -35,3 +35,25 @@ void oracle_poly_eval(int nc, int M, const double* times, const double* coef, do
         ++k;
     }
 }
+
+/* PolyTraj::getTraj (:175-187) followed by getLength (:189-202) and getMeanVel (:204-207): positions sampled at t = 0, then
+ * t += dt while t < total_time (the reference accumulates t in floating point with dt = 0.01 -- so does this loop: for a
+ * total time that is a multiple of dt the accumulated t decides whether the last sample exists), length = sum of the chord
+ * lengths, mean velocity = length / total_time.  out2[0] = length, out2[1] = mean velocity; returns the number of samples. */
+#include <math.h>
+int oracle_traj_length(int nc, int M, const double* times, const double* coef, double dt, double* out2) {
+    double total = 0.0;
+    for (int i = 0; i < M; ++i) total += times[i];                /* PolyTraj::init :59-72 */
+    double t = 0.0, len = 0.0, pl[3] = {0, 0, 0}, pn[3];
+    int n = 0;
+    while (t < total) {
+        oracle_poly_eval(nc, M, times, coef, t, 1, pn);
+        if (n > 0) len += sqrt((pn[0] - pl[0]) * (pn[0] - pl[0]) + (pn[1] - pl[1]) * (pn[1] - pl[1]) + (pn[2] - pl[2]) * (pn[2] - pl[2]));
+        pl[0] = pn[0]; pl[1] = pn[1]; pl[2] = pn[2];
+        t += dt;
+        ++n;
+    }
+    out2[0] = len;
+    out2[1] = len / total;
+    return n;
+}

@@ -22,6 +22,23 @@ void ref_polytraj_eval(int nc, int M, const double* times, const double* coef, d
     for (int k = 0; k < 3; ++k) { out[k] = p[k]; out[3 + k] = v[k]; out[6 + k] = a[k]; }
 }
 
+// PolyTraj::getTraj + getLength + getMeanVel (poly_traj.hpp:175-207: samples every 0.01 s, accumulated t); returns the sample count
+int ref_polytraj_length(int nc, int M, const double* times, const double* coef, double* out2) {
+    PolyTraj traj;
+    traj.reset();
+    for (int i = 0; i < M; ++i) {
+        std::vector<double> cx(coef + ((size_t)0 * M + i) * nc, coef + ((size_t)0 * M + i + 1) * nc);
+        std::vector<double> cy(coef + ((size_t)1 * M + i) * nc, coef + ((size_t)1 * M + i + 1) * nc);
+        std::vector<double> cz(coef + ((size_t)2 * M + i) * nc, coef + ((size_t)2 * M + i + 1) * nc);
+        traj.addSegment(cx, cy, cz, times[i]);
+    }
+    traj.init();
+    const int n = (int)traj.getTraj().size();
+    out2[0] = traj.getLength();
+    out2[1] = traj.getMeanVel();
+    return n;
+}
+
 double ref_polytraj_total_time(int M, const double* times) {
     PolyTraj traj;
     traj.reset();

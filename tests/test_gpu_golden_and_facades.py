@@ -227,3 +227,37 @@ def test_misaligned_device_views_take_the_generic_kernel(oracle):
         assert bool((d_st == U.UAVQP_SOLVED).all())
     ref, _ = oracle.solve_exact_batch(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
     assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("r,mode,ragged", [(3, "reference", False), (4, "distance", False), (4, "reference", True)])
+def test_batched_traj_length_and_mean_velocity_vs_oracle(gpu_ctx, oracle, r, mode, ragged):
+    """uavqp_traj_length_device = PolyTraj::getTraj + getLength + getMeanVel (poly_traj.hpp:175-207) for a batch, against the
+    restated reference loop (oracle/poly_eval.c, itself pinned on the reference header): the sample COUNT exactly -- constant
+    1.0 s segments make the total time a multiple of the 0.01 s step, where the accumulated t decides -- length and mean
+    velocity to 1e-10 relative (parallel chord sum, t_s = s dt instead of the accumulated t)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 40
+    if ragged:
+        b = W.ragged_batch(4, n, r, m_lo=1, m_hi=9)
+        b["times"] = np.round(np.asarray(b["times"]) * 4) / 4 + 0.25          # multiples of 0.25 s: totals on the 0.01 grid
+        uni = 0
+    else:
+        b = W.uniform_batch(2, n, 5, r, time_mode=mode)
+        uni = 5
+    so = np.asarray(b["seg_offsets"])
+    T = np.asarray(b["times"]).reshape(-1)
+    coef, st = gpu_ctx.solve_batch_host(r, so, np.asarray(b["waypoints"]).reshape(-1, 3), T, b["bc"])
+    assert np.all(st == U.UAVQP_SOLVED)
+    d_so, d_T, d_c = torch.from_numpy(so).to(dev), torch.from_numpy(T).to(dev), torch.from_numpy(coef).to(dev)
+    length = torch.zeros(n, dtype=torch.float64, device=dev)
+    mean_v = torch.zeros(n, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    gpu_ctx.traj_length_device(r, n, uni, None if uni else d_so, d_T, d_c, 0.01, length, mean_v, cnt)
+    gpu_ctx.synchronize()
+    length, mean_v, cnt = length.cpu().numpy(), mean_v.cpu().numpy(), cnt.cpu().numpy()
+    for k in range(n):
+        ck = coef[3 * 2 * r * so[k]:3 * 2 * r * so[k + 1]]
+        le, ve, ne = oracle.traj_length(2 * r, T[so[k]:so[k + 1]], ck)
+        assert cnt[k] == ne, (k, cnt[k], ne)
+        assert abs(length[k] - le) <= 1e-10 * le and abs(mean_v[k] - ve) <= 1e-10 * ve

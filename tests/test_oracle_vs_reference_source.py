@@ -85,3 +85,20 @@ def test_poly_eval_restatement_equals_reference_polytraj_header(ref):
             a = ref.ref_polytraj_eval(nc, T, c, float(t))
             b = ref.poly_eval(nc, T, c, float(t), 7)
             assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-13, (nc, M, t)
+
+
+def test_traj_length_restatement_equals_reference_polytraj_header(ref):
+    """oracle/poly_eval.c::oracle_traj_length vs the reference's own PolyTraj::getTraj / getLength / getMeanVel
+    (traj_utils/poly_traj.hpp:175-207) compiled from where it lies: the same sample COUNT -- including total times that are
+    multiples of the 0.01 s step, where the reference's floating-point accumulation of t decides whether the last sample
+    exists -- and length / mean velocity to 1e-12."""
+    from uav_motion_planning_amd import workloads as W
+    for r, M, mode in [(3, 3, "reference"), (4, 7, "reference"), (3, 5, "distance"), (4, 8, "wide")]:
+        b = W.uniform_batch(2, 6, M, r, time_mode=mode)
+        coef, _ = ref.solve_exact_batch(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+        c = coef.reshape(6, -1)
+        for k in range(6):
+            la, va, na = ref.traj_length(2 * r, b["times"][k], c[k])
+            lb, vb, nb = ref.ref_polytraj_length(2 * r, b["times"][k], c[k])
+            assert na == nb
+            assert abs(la - lb) <= 1e-12 * lb and abs(va - vb) <= 1e-12 * vb

@@ -44,6 +44,7 @@ SYMBOLS = (
     "uavqp_solve_corridor_warm_device",
     "uavqp_time_reallocate_device",
     "uavqp_eval_batch_device",
+    "uavqp_traj_length_device",
     "uavqp_ellipsoid_check_device",
     "uavqp_corridor_from_cloud_device",
     "uavqp_obstacle_grid_build_device",
@@ -126,6 +127,7 @@ def lib():
     L.uavqp_solve_corridor_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip]
     L.uavqp_time_reallocate_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, ctypes.c_double, ctypes.c_double, i32, ctypes.c_double, ip]
     L.uavqp_eval_batch_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, i32, dp]
+    L.uavqp_traj_length_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, ctypes.c_double, dp, dp, ip]
     L.uavqp_ellipsoid_check_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, dp, i32,
                                                ctypes.c_double, ctypes.c_double, ip, vp]
     L.uavqp_corridor_from_cloud_device.argtypes = [vp, i32, i32, i32, ip, i32, dp, dp, dp, dp, i32, ctypes.c_double, ctypes.c_double,

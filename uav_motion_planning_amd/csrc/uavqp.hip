@@ -411,6 +411,76 @@ __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// N1 (continued): PolyTraj::getTraj + getLength + getMeanVel (traj_utils/poly_traj.hpp:175-207) for a whole batch.
+// One wave per trajectory.  Lane 0 repeats the reference's sampling loop to COUNT the samples -- the reference accumulates
+// t += dt in floating point and stops at t >= total_time, so for a total time that is a multiple of dt (its own constant
+// 1.0 s per segment) the rounding of that accumulation decides whether the last sample exists; the count has to be exact.
+// The 64 lanes then evaluate the chords in parallel at t_s = s dt (differs from the accumulated t by ~1e-16 s relative:
+// rounding-level differences in the positions) and the wave sums them.
+// ---------------------------------------------------------------------------------------------------
+struct LengthArgs {
+    int n_traj, uniform;
+    const int32_t* seg_offsets;
+    const double* times;
+    const double* coeff;
+    double dt;
+    double* length;
+    double* mean_vel;
+    int32_t* n_samples;
+};
+
+template <int R>
+__global__ __launch_bounds__(64) void traj_length_kernel(LengthArgs a) {
+    constexpr int NC = 2 * R;
+    const int lane = threadIdx.x;
+    for (int b = blockIdx.x; b < a.n_traj; b += gridDim.x) {
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        const double* __restrict__ T = a.times + s0;
+        const double* __restrict__ c = a.coeff + (size_t)3 * NC * s0;
+        double total = 0.0;
+        int n = 0;
+        if (lane == 0) {
+            for (int i = 0; i < M; ++i) total += T[i];                      // PolyTraj::init :64-72
+            double t = 0.0;
+            while (t < total && n < (1 << 24)) { t += a.dt; ++n; }          // getTraj :180-184 (accumulated t)
+        }
+        total = __shfl(total, 0, 64);
+        n = __shfl(n, 0, 64);
+        auto pos = [&](int s, double (&p)[3]) {
+            double t = (double)s * a.dt;
+            int idx = 0;
+            while (idx < M && t > T[idx] + 1e-4) { t -= T[idx]; ++idx; }    // evaluatePos :77-88
+            if (idx == M) { --idx; t = T[idx]; }
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double* ca = c + ((size_t)ax * M + idx) * NC;
+                double v = 0.0;
+#pragma unroll
+                for (int j = NC - 1; j >= 0; --j) v = fma(v, t, ca[j]);
+                p[ax] = v;
+            }
+        };
+        double acc = 0.0;
+        if (M >= 1)
+            for (int s = lane; s + 1 < n; s += 64) {                        // getLength :189-202: chords between consecutive samples
+                double p0[3], p1[3];
+                pos(s, p0);
+                pos(s + 1, p1);
+                const double dx = p1[0] - p0[0], dy = p1[1] - p0[1], dz = p1[2] - p0[2];
+                acc += sqrt(dx * dx + dy * dy + dz * dz);
+            }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) {
+            if (a.length) a.length[b] = acc;
+            if (a.mean_vel) a.mean_vel[b] = acc / total;                    // getMeanVel :204-207
+            if (a.n_samples) a.n_samples[b] = n;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // N4: SE(3) ellipsoid collision check.  One lane per (trajectory, sample); obstacle points stream through LDS
 // in tiles shared by the 256 samples of a block.
 // ---------------------------------------------------------------------------------------------------
@@ -1070,6 +1140,25 @@ extern "C" int uavqp_eval_batch_device(uavqp_ctx* ctx, int r, int n_traj, int un
         hipLaunchKernelGGL(uavqp::eval_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL(uavqp::eval_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+    UAVQP_HIP(hipGetLastError());
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_traj_length_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                        const double* d_times, const double* d_coeff, double dt, double* d_length, double* d_mean_vel,
+                                        int32_t* d_n_samples) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0 || !(dt > 0.0) || !(dt < INFINITY)) return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!d_times || !d_coeff || (uniform_segments == 0 && !d_seg_offsets)) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    uavqp::LengthArgs a;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.dt = dt;
+    a.length = d_length; a.mean_vel = d_mean_vel; a.n_samples = d_n_samples;
+    int grid = n_traj < ctx->num_cus * 32 ? n_traj : ctx->num_cus * 32;
+    if (r == 3)
+        hipLaunchKernelGGL(uavqp::traj_length_kernel<3>, dim3(grid), dim3(64), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(uavqp::traj_length_kernel<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }

@@ -85,6 +85,14 @@ class Context:
                                                 n_samples, float(t0), float(dt), int(what), p(out))
         _lib.check(rc, "uavqp_eval_batch_device")
 
+    def traj_length_device(self, r, n_traj, uniform_segments, seg_offsets, times, coeff, dt=0.01, length=None, mean_vel=None, n_samples=None):
+        """Batched PolyTraj::getTraj + getLength + getMeanVel (poly_traj.hpp:175-207; dt = the reference's 0.01 s): device buffers."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_traj_length_device(self._h, r, n_traj, uniform_segments, p(seg_offsets), p(times), p(coeff), float(dt),
+                                                 p(length), p(mean_vel), p(n_samples))
+        _lib.check(rc, "uavqp_traj_length_device")
+
     def time_reallocate_device(self, r, n_traj, uniform_segments, seg_offsets, times, coeff, v_max, a_max,
                                samples_per_seg=16, max_stretch=1.5, changed=None):
         """One stretch-only time re-allocation step (device buffers, `times` updated in place)."""
