@@ -192,6 +192,31 @@ int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int unif
                                      double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
                                      uint64_t* d_active_set, int warm_start);
 
+/* GENERAL inequality rows (north-star extension: the reference hands any l <= A x <= u to OSQP, minimum_control.cpp:146-147,
+ * 164-180, but only ever builds equality rows, :98-125).  On top of the knot boxes of uavqp_solve_corridor_batch_device every
+ * segment carries up to rows_per_segment (1 or 2) rows
+ *       row_lo <= p_i^(d)(tau T_i) <= row_hi      per axis,   d = 0 position, 1 velocity, 2 acceleration (, 3 jerk for r = 4)
+ * i.e. position samples at in-segment times (BASELINE config 3's "K = 2 mid-segment samples"), per-axis velocity / acceleration
+ * limits, or -- through the monomial basis -- any row a' c_i on the coefficients of one segment.  This is the ORIGINAL spline
+ * space (adapters.refine_with_mid_knots inserts knots instead: cheaper -- it runs on the corridor solver -- but a larger space).
+ *   d_corr_lo / d_corr_hi  knot boxes as in uavqp_solve_corridor_batch_device, or both NULL: the reference's waypoint equalities
+ *   d_row_tau    [sum_b M_b][rows_per_segment]     position of the row in its segment as a fraction of T_i, 0 <= tau < 1
+ *                                                  (tau = 0 with d >= 1 is a limit on a knot derivative; tau = 0, d = 0 is the knot box: rejected)
+ *   d_row_deriv  [sum_b M_b][rows_per_segment]     int32 derivative order d, < 0: slot unused
+ *   d_row_lo / d_row_hi [sum_b M_b][rows_per_segment][3]   bounds per axis (lo == hi: an equality row; +-1e300 for a one-sided row)
+ *   d_active_out [n_traj][3][2 + 2 rows_per_segment] uint64 (may be NULL): working set at the solution -- word 0 / 1: knot boxes
+ *                active / at the upper bound (bit k = interior waypoint k), then per row slot j words 2+2j / 3+2j (bit i = segment i)
+ * Exact dual active-set solve (Goldfarb-Idnani on the block-tridiagonal KKT system with the rows' multipliers riding in the knot
+ * blocks): no feasible starting point is needed, the result is the QP's minimiser to rounding.  An infeasible or
+ * degenerate problem stops at uavqp_settings.max_iter (default 12 M (1 + rows_per_segment) + 30) with UAVQP_MAX_ITER_REACHED and
+ * the minimiser of the working set reached so far (which need NOT satisfy the remaining rows).  M <= 63.  Asynchronous. */
+int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                  const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                  const double* d_bc, const double* d_corr_lo, const double* d_corr_hi, int rows_per_segment,
+                                  const double* d_row_tau, const int32_t* d_row_deriv, const double* d_row_lo,
+                                  const double* d_row_hi, double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
+                                  uint64_t* d_active_out);
+
 /* Time re-allocation step of the outer loop of BASELINE config 5 (north-star extension; the reference uses a
  * constant 1.0 s per segment, test_minimum_jerk.cpp:65-71, and has no such loop -- nothing to mirror, parity is
  * per inner solve).  The 3-axis speed |v| and acceleration |a| of the solved polynomials are sampled at

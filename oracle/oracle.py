@@ -163,9 +163,11 @@ def osqp_solve_axis(r, pos, bc_start, bc_end, T, settings=None):
     return out, info
 
 
-def osqp_solve_batch(r, seg_offsets, waypoints, times, bc, settings=None, threads=1, corr_lo=None, corr_hi=None):
+def osqp_solve_batch(r, seg_offsets, waypoints, times, bc, settings=None, threads=1, corr_lo=None, corr_hi=None,
+                     rows_per_segment=0, row_tau=None, row_deriv=None, row_lo=None, row_hi=None):
     """Batch in the C-ABI layout: 3 x (setup + solve + cleanup) per trajectory.  Returns (coef, status, iters).
-    corr_lo / corr_hi (waypoint layout): interior waypoint rows become l <= p <= u (corridor extension)."""
+    corr_lo / corr_hi (waypoint layout): interior waypoint rows become l <= p <= u (corridor extension).
+    rows_per_segment / row_*: extra rows lo <= p_i^(d)(tau T_i) <= hi in the layout of uavqp_solve_rows_batch_device."""
     so, pso = _i(seg_offsets)
     wp, pwp = _d(waypoints)
     tt, ptt = _d(times)
@@ -178,10 +180,17 @@ def osqp_solve_batch(r, seg_offsets, waypoints, times, bc, settings=None, thread
     if corr_lo is not None:
         clo, plo = _d(corr_lo)
         chi, phi = _d(corr_hi)
-    rc = lib().osqp_port_solve_batch_corridor(r, n_traj, pso, pwp, ptt, pbc, plo, phi,
-                                     ctypes.byref(settings) if settings is not None else None,
-                                     out.ctypes.data_as(_dp), status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip),
-                                     int(threads))
+    K = int(rows_per_segment)
+    ptau = pdrv = prlo = prhi = None
+    if K > 0:
+        rtau, ptau = _d(row_tau)
+        rdrv, pdrv = _i(row_deriv)
+        rlo, prlo = _d(row_lo)
+        rhi, prhi = _d(row_hi)
+    rc = lib().osqp_port_solve_batch_rows(r, n_traj, pso, pwp, ptt, pbc, plo, phi, K, ptau, pdrv, prlo, prhi,
+                                          ctypes.byref(settings) if settings is not None else None,
+                                          out.ctypes.data_as(_dp), status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip),
+                                          int(threads))
     if rc != 0:
         raise RuntimeError(f"osqp_port_solve_batch rc={rc}")
     return out, status, iters

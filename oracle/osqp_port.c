@@ -92,9 +92,14 @@ static double falling(int k, int d) { double f = 1; for (int j = 0; j < d; ++j) 
 
 /* Problem data exactly as minimum_control.cpp:5-125 builds it (r=3), same pattern for r=4.
  * P: upper triangle only (osqp-eigen hands OSQP the upper-triangular view).  A keeps the structural zeros. */
+/* Extra inequality rows (north-star extension, no reference counterpart: the reference only builds the equality rows above;
+ * OSQP itself accepts any l <= A x <= u, minimum_control.cpp:146-147,164-180): row e bounds the derivative d of segment seg at
+ * local time t, i.e. the monomial row  k!/(k-d)! t^(k-d)  on that segment's coefficients. */
+typedef struct { int n; const int* seg; const double* t; const int* d; const double* lo; const double* hi; } extra_rows;
+
 static void build_problem(int r, int M, const double* T, const double* pos, const double* bcs, const double* bce,
-                          const double* corr_lo, const double* corr_hi, csc* P, csc* A, double* l, double* u) {
-    const int R = 2 * r, n = R * M, m = 2 * r + (r + 1) * (M - 1);
+                          const double* corr_lo, const double* corr_hi, const extra_rows* ex, csc* P, csc* A, double* l, double* u) {
+    const int R = 2 * r, n = R * M, m0 = 2 * r + (r + 1) * (M - 1), nex = ex ? ex->n : 0, m = m0 + nex;
     trip* tp = (trip*)malloc(sizeof(trip) * (size_t)(r * (r + 1) / 2 * M));
     int np = 0;
     for (int i = 0; i < M; ++i)
@@ -107,7 +112,7 @@ static void build_problem(int r, int M, const double* T, const double* pos, cons
             }
     *P = csc_from_triplets(n, n, tp, np);
     free(tp);
-    trip* ta = (trip*)malloc(sizeof(trip) * (size_t)(r + (M + 1) * (R + r * (R + r + 1))));
+    trip* ta = (trip*)malloc(sizeof(trip) * (size_t)(r + (M + 1) * (R + r * (R + r + 1)) + nex * R));
     int na = 0;
 #define ADD(rr, cc, vv) do { ta[na].r = (rr); ta[na].c = (cc); ta[na].v = (vv); ++na; } while (0)
     for (int d = 0; d < r; ++d) ADD(d, d, falling(d, d));                                 /* :29-31 */
@@ -125,6 +130,8 @@ static void build_problem(int r, int M, const double* T, const double* pos, cons
         for (int d = 1; d < r; ++d)
             for (int k = 0; k < R; ++k) ADD((r + 1) * M + (d - 1), R * i + k, k >= d ? falling(k, d) * pow(T[i], k - d) : 0.0);
     }
+    for (int e = 0; e < nex; ++e)
+        for (int k = ex->d[e]; k < R; ++k) ADD(m0 + e, R * ex->seg[e] + k, falling(k, ex->d[e]) * pow(ex->t[e], k - ex->d[e]));
 #undef ADD
     *A = csc_from_triplets(m, n, ta, na);
     free(ta);
@@ -139,6 +146,7 @@ static void build_problem(int r, int M, const double* T, const double* pos, cons
      * becomes l <= p_i(T_i) <= u -- the only rows with l < u, and the reason OSQP's ADMM is needed at all. */
     if (corr_lo && corr_hi)
         for (int i = 0; i < M - 1; ++i) { l[r + (r + 1) * i] = corr_lo[i]; u[r + (r + 1) * i] = corr_hi[i]; }
+    for (int e = 0; e < nex; ++e) { l[m0 + e] = ex->lo[e]; u[m0 + e] = ex->hi[e]; }
 }
 
 /* ------------------------------------------------------------------ scaling (Ruiz) */
@@ -264,12 +272,14 @@ static void ldl_solve(const ldl_t* f, double* b) { /* b in original ordering, so
 }
 
 /* Banded ordering: [start rows][x seg 0][knot 0 rows][x seg 1]...[x seg M-1][end rows] */
-static void kkt_ordering(int r, int M, int* perm /* new -> old */) {
-    const int R = 2 * r, n = R * M;
+static void kkt_ordering(int r, int M, const extra_rows* ex, int* perm /* new -> old */) {
+    const int R = 2 * r, n = R * M, m0 = 2 * r + (r + 1) * (M - 1);
     int k = 0;
     for (int d = 0; d < r; ++d) perm[k++] = n + d;
     for (int i = 0; i < M; ++i) {
         for (int c = 0; c < R; ++c) perm[k++] = R * i + c;
+        for (int e = 0; ex && e < ex->n; ++e)
+            if (ex->seg[e] == i) perm[k++] = n + m0 + e;     /* extra rows right behind the coefficients of their segment */
         if (i < M - 1) {
             perm[k++] = n + r + (r + 1) * i;
             for (int d = 0; d < r; ++d) perm[k++] = n + (r + 1) * (i + 1) + d;
@@ -359,17 +369,27 @@ int osqp_port_solve_axis(int r, int M, const double* pos, const double* bcs, con
 }
 
 /* corr_lo / corr_hi: M-1 bounds for the interior waypoints 1..M-1 of this axis (NULL: equalities at pos). */
+static int solve_axis_rows(int r, int M, const double* pos, const double* bcs, const double* bce, const double* T,
+                           const double* corr_lo, const double* corr_hi, const extra_rows* ex,
+                           const port_settings* user, double* coef, port_info* info);
+
 int osqp_port_solve_axis_corridor(int r, int M, const double* pos, const double* bcs, const double* bce, const double* T,
                                   const double* corr_lo, const double* corr_hi,
                                   const port_settings* user, double* coef, port_info* info) {
+    return solve_axis_rows(r, M, pos, bcs, bce, T, corr_lo, corr_hi, NULL, user, coef, info);
+}
+
+static int solve_axis_rows(int r, int M, const double* pos, const double* bcs, const double* bce, const double* T,
+                           const double* corr_lo, const double* corr_hi, const extra_rows* ex,
+                           const port_settings* user, double* coef, port_info* info) {
     if ((r != 3 && r != 4) || M < 1) return -2;
     port_settings st;
     if (user) st = *user; else osqp_port_default_settings(&st);
-    const int n = 2 * r * M, m = 2 * r + (r + 1) * (M - 1), N = n + m;
+    const int n = 2 * r * M, m = 2 * r + (r + 1) * (M - 1) + (ex ? ex->n : 0), N = n + m;
     csc P, A;
     double* q = (double*)calloc((size_t)n, sizeof(double));                 /* getGradient: q = 0, :21-24 */
     double* l = (double*)malloc(sizeof(double) * m); double* u = (double*)malloc(sizeof(double) * m);
-    build_problem(r, M, T, pos, bcs, bce, corr_lo, corr_hi, &P, &A, l, u);
+    build_problem(r, M, T, pos, bcs, bce, corr_lo, corr_hi, ex, &P, &A, l, u);
 
     /* ---- osqp_setup ---- */
     scaling_t sc;
@@ -387,7 +407,7 @@ int osqp_port_solve_axis_corridor(int r, int M, const double* pos, const double*
         rho_inv[i] = 1.0 / rho_vec[i];
     }
     int* perm = (int*)malloc(sizeof(int) * N);
-    kkt_ordering(r, M, perm);
+    kkt_ordering(r, M, ex, perm);
     ldl_t F;
     kkt_build(&F, n, m, &P, &A, st.sigma, rho_inv, perm);
     int rc = ldl_numeric(&F);
@@ -475,6 +495,7 @@ typedef struct {
     int r, b0, b1; const int* so; const double* wp; const double* times; const double* bc;
     const port_settings* st; double* out; int* status; int* iters;
     const double* clo; const double* chi;  /* optional corridor bounds, waypoint layout [sum(M_b+1)][3] */
+    int K; const double* rtau; const int* rdrv; const double* rlo; const double* rhi;  /* optional rows, C-ABI layout of uavqp_solve_rows_batch_device */
 } job_t;
 
 static void* job_run(void* arg) {
@@ -499,8 +520,24 @@ static void* job_run(void* arg) {
                 lo = (double*)malloc(sizeof(double) * (M - 1)); hi = (double*)malloc(sizeof(double) * (M - 1));
                 for (int i = 1; i < M; ++i) { lo[i - 1] = j->clo[3 * (size_t)(s0 + b + i) + ax]; hi[i - 1] = j->chi[3 * (size_t)(s0 + b + i) + ax]; }
             }
-            osqp_port_solve_axis_corridor(r, M, pos, bs, be, j->times + s0, lo, hi, j->st, j->out + (size_t)3 * 2 * r * s0 + (size_t)ax * 2 * r * M, &info);
-            free(lo); free(hi);
+            extra_rows ex = {0, NULL, NULL, NULL, NULL, NULL};
+            int* eseg = NULL; int* ed = NULL; double* et = NULL; double* elo = NULL; double* ehi = NULL;
+            if (j->K > 0 && j->rdrv) {
+                const int cap = M * j->K;
+                eseg = (int*)malloc(sizeof(int) * cap); ed = (int*)malloc(sizeof(int) * cap); et = (double*)malloc(sizeof(double) * cap);
+                elo = (double*)malloc(sizeof(double) * cap); ehi = (double*)malloc(sizeof(double) * cap);
+                for (int i = 0; i < M; ++i)
+                    for (int q = 0; q < j->K; ++q) {
+                        const size_t row = (size_t)(s0 + i) * j->K + q;
+                        if (j->rdrv[row] < 0) continue;
+                        eseg[ex.n] = i; ed[ex.n] = j->rdrv[row]; et[ex.n] = j->rtau[row] * j->times[s0 + i];
+                        elo[ex.n] = j->rlo[row * 3 + ax]; ehi[ex.n] = j->rhi[row * 3 + ax];
+                        ++ex.n;
+                    }
+                ex.seg = eseg; ex.d = ed; ex.t = et; ex.lo = elo; ex.hi = ehi;
+            }
+            solve_axis_rows(r, M, pos, bs, be, j->times + s0, lo, hi, ex.n > 0 ? &ex : NULL, j->st, j->out + (size_t)3 * 2 * r * s0 + (size_t)ax * 2 * r * M, &info);
+            free(lo); free(hi); free(eseg); free(ed); free(et); free(elo); free(ehi);
             if (info.status != PORT_SOLVED) worst = info.status;
             if (info.iters > it_max) it_max = info.iters;
         }
@@ -521,9 +558,24 @@ int osqp_port_solve_batch(int r, int n_traj, const int* seg_offsets, const doubl
     return osqp_port_solve_batch_corridor(r, n_traj, seg_offsets, waypoints, times, bc, NULL, NULL, st, coef_out, status_out, iters_out, n_threads);
 }
 
+int osqp_port_solve_batch_rows(int r, int n_traj, const int* seg_offsets, const double* waypoints, const double* times,
+                               const double* bc, const double* corr_lo, const double* corr_hi, int K, const double* row_tau,
+                               const int* row_deriv, const double* row_lo, const double* row_hi, const port_settings* st,
+                               double* coef_out, int* status_out, int* iters_out, int n_threads);
+
 int osqp_port_solve_batch_corridor(int r, int n_traj, const int* seg_offsets, const double* waypoints, const double* times,
                                    const double* bc, const double* corr_lo, const double* corr_hi, const port_settings* st,
                                    double* coef_out, int* status_out, int* iters_out, int n_threads) {
+    return osqp_port_solve_batch_rows(r, n_traj, seg_offsets, waypoints, times, bc, corr_lo, corr_hi, 0, NULL, NULL, NULL, NULL, st,
+                                      coef_out, status_out, iters_out, n_threads);
+}
+
+/* rows: layout of uavqp_solve_rows_batch_device (include/uavqp.h): [segments][K] tau (fraction of T), derivative order (< 0 unused),
+ * [segments][K][3] bounds per axis */
+int osqp_port_solve_batch_rows(int r, int n_traj, const int* seg_offsets, const double* waypoints, const double* times,
+                               const double* bc, const double* corr_lo, const double* corr_hi, int K, const double* row_tau,
+                               const int* row_deriv, const double* row_lo, const double* row_hi, const port_settings* st,
+                               double* coef_out, int* status_out, int* iters_out, int n_threads) {
     if (r != 3 && r != 4) return -2;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n_traj) n_threads = n_traj > 0 ? n_traj : 1;
@@ -531,7 +583,8 @@ int osqp_port_solve_batch_corridor(int r, int n_traj, const int* seg_offsets, co
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
     for (int t = 0; t < n_threads; ++t) {
         job_t j = { r, (int)((long long)n_traj * t / n_threads), (int)((long long)n_traj * (t + 1) / n_threads),
-                    seg_offsets, waypoints, times, bc, st, coef_out, status_out, iters_out, corr_lo, corr_hi };
+                    seg_offsets, waypoints, times, bc, st, coef_out, status_out, iters_out, corr_lo, corr_hi,
+                    K, row_tau, row_deriv, row_lo, row_hi };
         jobs[t] = j;
     }
     if (n_threads == 1) job_run(&jobs[0]);

@@ -1,0 +1,182 @@
+"""-m gpu: GENERAL inequality rows through the C ABI (uavqp_solve_rows_batch_device): knot boxes + rows
+lo <= p_i^(d)(tau T_i) <= hi at in-segment times (position samples, velocity / acceleration limits).
+
+Checkers (no reference code exists for these rows -- the reference only ever builds equality rows, minimum_control.cpp:98-125):
+ (1) with every row wide open the result equals the corridor solve / the plain equality solve;
+ (2) an exact optimality certificate from the REFERENCE-FORMULATION matrices (oracle.assemble = minimum_control.cpp:5-96) with
+     the extra rows appended as monomial rows on the segment's coefficients: primal feasibility, stationarity
+     P x + A' nu = 0, multipliers zero on inactive rows and right-signed on active ones;
+ (3) the OSQP-faithful port with the same extra rows at eps 1e-10 (1e-5 relative = what ADMM reaches);
+ (4) the exact-rational fixtures of tests/golden/rows_exact.json including the active sets (test_rows_golden.py)."""
+import math
+
+import numpy as np
+import pytest
+
+import uav_motion_planning_amd as U
+from uav_motion_planning_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+BIG = 1e300
+
+
+def mono_row(r, M, seg, t, d):
+    """Row of the reference formulation: p_seg^(d)(t) on the 2r M monomial coefficients (ascending powers)."""
+    a = np.zeros(2 * r * M)
+    for k in range(d, 2 * r):
+        a[2 * r * seg + k] = math.prod(range(k - d + 1, k + 1)) * t ** (k - d)
+    return a
+
+
+def kkt_certificate_rows(oracle, r, M, T, coef, pos, bcs, bce, lo, hi, rows):
+    """rows: list of (segment, tau, d, lo, hi).  Returns (primal violation, stationarity residual, complementarity violation)."""
+    P, A = oracle.assemble(r, T)
+    l, u = oracle.bounds(r, pos, bcs, bce)
+    l, u = l.copy(), u.copy()
+    wrows = [r + (r + 1) * i for i in range(M - 1)]
+    if lo is not None:
+        l[wrows] = lo
+        u[wrows] = hi
+    extra = [mono_row(r, M, s, tau * T[s], d) for (s, tau, d, _, _) in rows]
+    if extra:
+        A = np.vstack([A, np.array(extra)])
+        l = np.r_[l, [x[3] for x in rows]]
+        u = np.r_[u, [x[4] for x in rows]]
+    x = coef
+    Ax = A @ x
+    scale = max(1.0, np.max(np.abs(Ax)))
+    prim = max(np.max(l - Ax), np.max(Ax - u), 0.0) / scale
+    at_lo = np.abs(Ax - l) < 1e-8 * scale
+    at_hi = np.abs(Ax - u) < 1e-8 * scale
+    act = at_lo | at_hi
+    nu, *_ = np.linalg.lstsq(A[act].T, -(P @ x), rcond=None)     # multipliers live on the active rows only
+    stat = np.max(np.abs(P @ x + A[act].T @ nu)) / max(1.0, np.max(np.abs(P @ x)))
+    comp, nscale = 0.0, max(1e-300, np.max(np.abs(nu)))
+    for v, lo_, hi_ in zip(nu, at_lo[act] & ~at_hi[act], at_hi[act] & ~at_lo[act]):
+        if lo_:
+            comp = max(comp, v / nscale)         # P x + A' nu = 0: nu <= 0 at a lower bound
+        elif hi_:
+            comp = max(comp, -v / nscale)
+    return prim, stat, comp
+
+
+def run_rows(ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, uniform):
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    so = np.asarray(b["seg_offsets"])
+    n = so.size - 1
+    out = torch.zeros(int(so[-1]) * 6 * r, dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev)
+    act = torch.zeros((n, 3, 2 + 2 * K), dtype=torch.int64, device=dev)
+    ctx.solve_rows_device(r, n, uniform, int(np.max(np.diff(so))), None if uniform else up(so), up(np.asarray(b["waypoints"]).reshape(-1, 3)),
+                          up(np.asarray(b["times"]).reshape(-1)), up(b["bc"]), up(lo), up(hi), K, up(tau), up(drv.astype(np.int32)), up(rlo), up(rhi),
+                          out, st, it, act)
+    ctx.synchronize()
+    return out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), act.cpu().numpy()
+
+
+@pytest.mark.parametrize("r,M,K", [(3, 8, 2), (4, 6, 1), (3, 5, 1), (4, 4, 2)])
+def test_wide_open_rows_reproduce_the_corridor_and_the_equality_solve(gpu_ctx, r, M, K):
+    n = 40
+    b = W.uniform_batch(3, n, M, r, time_mode="distance")
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    tau = np.tile(np.array([0.5, 0.25])[:K], (n * M, 1))
+    drv = np.tile(np.array([1, 0])[:K], (n * M, 1))
+    rlo, rhi = np.full((n * M, K, 3), -BIG), np.full((n * M, K, 3), BIG)
+    got, st, it, act = run_rows(gpu_ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, M)
+    ref, st2, _ = gpu_ctx.solve_corridor_batch_host(r, None, b["waypoints"], b["times"], b["bc"], lo, hi, uniform_segments=M)
+    assert np.all(st == U.UAVQP_SOLVED) and np.all(st2 == U.UAVQP_SOLVED)
+    assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref))
+    assert not act[:, :, 2:].any()
+    got2, st3, _, _ = run_rows(gpu_ctx, r, b, None, None, K, tau, drv, rlo, rhi, M)
+    eq, _ = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    assert np.all(st3 == U.UAVQP_SOLVED) and np.max(np.abs(got2 - eq)) < 1e-9 * np.max(np.abs(eq))
+
+
+def _rows_problem(b, M, K, h_pos, v_lim, n):
+    """Config-3 style extra rows: a position sample at mid-segment inside chord +- h_pos and (K = 2) a velocity limit there."""
+    wp = b["waypoints"]
+    tau = np.tile(np.array([0.5, 0.5])[:K], (n * M, 1))
+    drv = np.tile(np.array([0, 1])[:K], (n * M, 1))
+    rlo, rhi = np.zeros((n * M, K, 3)), np.zeros((n * M, K, 3))
+    mid = 0.5 * (wp[:, :-1] + wp[:, 1:]).reshape(n * M, 3)
+    rlo[:, 0], rhi[:, 0] = mid - h_pos, mid + h_pos
+    if K == 2:
+        rlo[:, 1], rhi[:, 1] = -v_lim, v_lim
+    return tau, drv, rlo, rhi
+
+
+@pytest.mark.parametrize("r,M,K,n", [(3, 8, 2, 48), (3, 16, 2, 24), (4, 6, 2, 48), (3, 5, 1, 48), (4, 8, 1, 32)])
+def test_rows_kkt_certificate_and_osqp_port(gpu_ctx, oracle, r, M, K, n):
+    b = W.uniform_batch(3, n, M, r, time_mode="distance")
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    tau, drv, rlo, rhi = _rows_problem(b, M, K, 0.2, 3.2, n)
+    got, st, it, act = run_rows(gpu_ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, M)
+    solved = st == U.UAVQP_SOLVED
+    assert solved.mean() >= 0.9, np.unique(st, return_counts=True)     # (a few of these random problems are infeasible: capped)
+    assert np.all(solved | (st == U.UAVQP_MAX_ITER_REACHED))
+    g = got.reshape(n, 3, 2 * r * M)
+    worst, n_active_rows = np.zeros(3), 0
+    for k in np.nonzero(solved)[0]:
+        for ax in range(3):
+            rows = [(s, tau[k * M + s, j], int(drv[k * M + s, j]), rlo[k * M + s, j, ax], rhi[k * M + s, j, ax]) for s in range(M) for j in range(K)]
+            prim, stat, comp = kkt_certificate_rows(oracle, r, M, b["times"][k], g[k, ax], b["waypoints"][k, :, ax], b["bc"][k, 0, :, ax],
+                                                    b["bc"][k, 1, :, ax], lo[k, 1:M, ax], hi[k, 1:M, ax], rows)
+            worst = np.maximum(worst, [prim, stat, comp])
+        n_active_rows += sum(bin(int(v) & 0xFFFFFFFFFFFFFFFF).count("1") for v in act[k, :, 2::2].ravel())
+    assert worst[0] < 1e-9 and worst[1] < 1e-7 and worst[2] < 1e-6, worst
+    assert n_active_rows > n                                          # the extra rows really bind
+    # OSQP-faithful port with the same rows
+    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=400000)
+    ref, st_ref, _ = oracle.osqp_solve_batch(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"], settings=s, corr_lo=lo, corr_hi=hi,
+                                             rows_per_segment=K, row_tau=tau, row_deriv=drv, row_lo=rlo, row_hi=rhi, threads=8)
+    good = solved & (st_ref == oracle.PORT_SOLVED)
+    assert good.sum() >= 0.8 * n
+    rr = ref.reshape(n, 3, 2 * r * M)
+    err = np.max(np.abs(g - rr), axis=(1, 2)) / np.max(np.abs(rr), axis=(1, 2))
+    assert err[good].max() < 1e-5, err[good].max()
+
+
+def test_rows_on_a_ragged_batch_and_knot_derivative_limits(gpu_ctx, oracle):
+    """Ragged batch; row slot 0 = acceleration limit AT the knots (tau = 0, d = 2), waypoints as equalities (no boxes)."""
+    r, n, K = 4, 60, 1
+    b = W.ragged_batch(4, n, r, m_lo=2, m_hi=10)
+    so = np.asarray(b["seg_offsets"])
+    S = int(so[-1])
+    tau = np.zeros((S, K))
+    drv = np.full((S, K), 2)
+    drv[so[:-1], 0] = -1                      # the first segment's slot: its tau = 0 knot is the start knot (fixed by bc)
+    a_lim = 6.0
+    rlo, rhi = np.full((S, K, 3), -a_lim), np.full((S, K, 3), a_lim)
+    got, st, it, act = run_rows(gpu_ctx, r, b, None, None, K, tau, drv, rlo, rhi, 0)
+    assert np.all((st == U.UAVQP_SOLVED) | (st == U.UAVQP_MAX_ITER_REACHED)) and (st == U.UAVQP_SOLVED).mean() > 0.9
+    wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+    T = np.asarray(b["times"])
+    n_bind = 0
+    for k in np.nonzero(st == U.UAVQP_SOLVED)[0][::3]:
+        M = so[k + 1] - so[k]
+        c = got[24 * so[k]:24 * so[k + 1]].reshape(3, M, 8)
+        acc_knots = 2.0 * c[:, 1:, 2]                                  # acceleration at the start of segments 1..M-1
+        assert np.all(np.abs(acc_knots) <= a_lim + 1e-8)
+        n_bind += int((np.abs(np.abs(acc_knots) - a_lim) < 1e-8).sum())
+        for ax in range(3):
+            rows = [(s, 0.0, 2, -a_lim, a_lim) for s in range(1, M)]
+            prim, stat, comp = kkt_certificate_rows(oracle, r, M, T[so[k]:so[k + 1]], c[ax].ravel(), wp[so[k] + k:so[k + 1] + k + 1, ax],
+                                                    b["bc"][k, 0, :, ax], b["bc"][k, 1, :, ax], None, None, rows)
+            assert prim < 1e-9 and stat < 1e-6 and comp < 1e-5, (prim, stat, comp)
+    assert n_bind > 5
+
+
+def test_rows_invalid_input_is_flagged(gpu_ctx):
+    r, M, n, K = 3, 4, 6, 1
+    b = W.uniform_batch(3, n, M, r)
+    tau = np.full((n * M, K), 0.5)
+    drv = np.zeros((n * M, K))
+    rlo, rhi = np.full((n * M, K, 3), -BIG), np.full((n * M, K, 3), BIG)
+    tau[2 * M + 1, 0] = 1.5                   # outside [0, 1)
+    rlo[4 * M + 2, 0, 1], rhi[4 * M + 2, 0, 1] = 1.0, -1.0   # lo > hi
+    drv[5 * M, 0] = 3                         # derivative order >= r
+    got, st, it, act = run_rows(gpu_ctx, r, b, None, None, K, tau, drv, rlo, rhi, M)
+    assert list(st[[2, 4, 5]]) == [U.UAVQP_INVALID_INPUT] * 3 and np.all(st[[0, 1, 3]] == U.UAVQP_SOLVED)

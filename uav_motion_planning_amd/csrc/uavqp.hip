@@ -651,6 +651,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 #include "qp_twisted.h"
 #include "qp_phased.h"
 #include "qp_corridor.h"
+#include "qp_rows.h"
 #include "obstacle_grid.h"
 
 namespace uavqp {
@@ -1267,6 +1268,70 @@ extern "C" int uavqp_debug_corridor_stamps(uavqp_ctx* ctx, long long* out7) {
     return UAVQP_OK;
 }
 #endif
+
+extern "C" int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                             const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                             const double* d_bc, const double* d_corr_lo, const double* d_corr_hi, int rows_per_segment,
+                                             const double* d_row_tau, const int32_t* d_row_deriv, const double* d_row_lo,
+                                             const double* d_row_hi, double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
+                                             uint64_t* d_active_out) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0 || (rows_per_segment != 1 && rows_per_segment != 2))
+        return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!d_waypoints || !d_times || !d_bc || !d_coeff_out || !d_status_out || !d_row_tau || !d_row_deriv || !d_row_lo || !d_row_hi)
+        return UAVQP_ERR_INVALID_ARG;
+    if ((d_corr_lo == nullptr) != (d_corr_hi == nullptr)) return UAVQP_ERR_INVALID_ARG;
+    if (uniform_segments == 0 && (!d_seg_offsets || max_segments < 1)) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    const int Mmax = uniform_segments > 0 ? uniform_segments : max_segments;
+    long long rows = 0;
+    if (uniform_segments > 0) rows = (long long)n_traj * (uniform_segments + 1);
+    else {
+        int32_t last = 0;
+        UAVQP_HIP(hipMemcpyAsync(&last, d_seg_offsets + n_traj, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+        if (last < 0) return UAVQP_ERR_INVALID_ARG;
+        rows = (long long)last + n_traj;
+    }
+    const int K = rows_per_segment, Bk = r + K;
+    const int F = Bk * (Bk + 1) / 2 + Bk + 2 * (1 + K);   // must match rows_solve_kernel's state layout
+    long long grid = (3LL * n_traj + 63) / 64;
+    const long long max_grid = (long long)ctx->num_cus * 4;
+    if (grid > max_grid) grid = max_grid;
+    const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
+    const size_t b_state = sizeof(double) * (size_t)Mmax * F * (size_t)grid * 64;
+    int rc = ensure_ws(ctx, b_xsol + b_state);
+    if (rc != UAVQP_OK) return rc;
+    uavqp::RowsArgs a;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax;
+    a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 12 * Mmax * (1 + K) + 30;
+    a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
+    a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.row_tau = d_row_tau; a.row_deriv = d_row_deriv; a.row_lo = d_row_lo; a.row_hi = d_row_hi;
+    a.xsol = ctx->ws; a.ws = (double*)((char*)ctx->ws + b_xsol);
+    a.status = d_status_out; a.iters = d_iters_out; a.active = (unsigned long long*)d_active_out;
+    hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
+    if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
+    if (r == 3) {
+        if (K == 1) hipLaunchKernelGGL((uavqp::rows_solve_kernel<3, 1>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((uavqp::rows_solve_kernel<3, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+    } else {
+        if (K == 1) hipLaunchKernelGGL((uavqp::rows_solve_kernel<4, 1>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((uavqp::rows_solve_kernel<4, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+    }
+    // Hermite solution -> coefficients (the corridor solver's emission kernel; it reads the same fields)
+    uavqp::CorridorArgs e{};
+    e.n_traj = n_traj; e.uniform = uniform_segments; e.max_segments = Mmax; e.seg_offsets = d_seg_offsets; e.waypoints = d_waypoints;
+    e.times = d_times; e.bc = d_bc; e.coeff = d_coeff_out; e.status = d_status_out; e.xsol = ctx->ws;
+    const long long chunks = 3LL * (rows - n_traj);
+    long long egrid = (chunks + 255) / 256;
+    if (egrid > (long long)ctx->num_cus * 16) egrid = (long long)ctx->num_cus * 16;
+    if (chunks > 0) {
+        if (r == 3) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<3>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, e, chunks);
+        else hipLaunchKernelGGL((uavqp::corridor_emit_kernel<4>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, e, chunks);
+    }
+    UAVQP_HIP(hipGetLastError());
+    return UAVQP_OK;
+}
 
 extern "C" int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                                  const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,

@@ -123,6 +123,18 @@ class Context:
                                                          p(iters_out), p(active_set), 1 if warm_start else 0)
         _lib.check(rc, "uavqp_solve_corridor_warm_device")
 
+    def solve_rows_device(self, r, n_traj, uniform_segments, max_segments, seg_offsets, waypoints, times, bc, corr_lo, corr_hi,
+                          rows_per_segment, row_tau, row_deriv, row_lo, row_hi, coeff_out, status_out, iters_out=None, active_out=None):
+        """Knot boxes (or None: waypoint equalities) + up to rows_per_segment general rows lo <= p_i^(d)(tau T_i) <= hi per segment and
+        axis; exact dual active-set solve on device buffers (uavqp_solve_rows_batch_device)."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        rc = _lib.lib().uavqp_solve_rows_batch_device(self._h, r, n_traj, uniform_segments, max_segments, p(seg_offsets), p(waypoints),
+                                                      p(times), p(bc), p(corr_lo), p(corr_hi), int(rows_per_segment), p(row_tau),
+                                                      p(row_deriv), p(row_lo), p(row_hi), p(coeff_out), p(status_out), p(iters_out),
+                                                      p(active_out))
+        _lib.check(rc, "uavqp_solve_rows_batch_device")
+
     def corridor_from_cloud_device(self, r, n_traj, uniform_segments, seg_offsets, n_rows, waypoints, times, coeff,
                                    obstacles, n_obs, robot_r, robot_h, h_max, corr_lo, corr_hi, clearance=None):
         """Corridor boxes of every waypoint row from an obstacle cloud, robot ellipsoid of kino_astar.cpp:721-758
