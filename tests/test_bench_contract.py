@@ -1,5 +1,5 @@
-"""CPU: the bench.py contract, checked on the committed round-1 bench line (profiles/r01_bench4096.json -- produced by
-`python bench.py` on the MI355X box) and on the script's defaults.  No GPU, no oracle."""
+"""CPU: the bench.py contract, checked on the committed round-2 bench line (profiles/r02_bench4096.json -- produced by
+`python bench.py` on the MI355X box, tools/collect_profiles.sh) and on the script's defaults.  No GPU, no oracle."""
 import json
 import os
 import re
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_key():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench4096.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench4096.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -24,6 +24,11 @@ def test_committed_bench_line_has_every_contract_key():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    # one clock for value and roofline: the per-launch time behind `achieved` is the HIP-event time of the same K-step block
+    # whose wall time gives `value`; the event time cannot exceed the wall time, and they agree within the launch overhead of one graph
+    assert r["kernel_ms"] <= d["ms_per_step"] * (1 + 1e-9) and r["kernel_ms"] > 0.9 * d["ms_per_step"]
+    assert r["working_set_bytes"] > 256 * 2 ** 20               # the steps rotate over more than the Infinity Cache
+    assert d["timing"]["repeats"] >= 10 and "pipelined" in d and d["pipelined"]["value"] > 0
     assert r["algorithmic_bytes_per_launch"] == 4096 * 1960            # SURVEY.md section 8-d figure x units per launch
     assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.5 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
@@ -33,8 +38,8 @@ def test_committed_bench_line_has_every_contract_key():
 
 
 def test_rocprof_summary_agrees_with_the_bench_line():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench4096.json")))
-    txt = open(os.path.join(ROOT, "profiles", "r01_bench4096_kernel_stats.csv")).read()
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench4096.json")))
+    txt = open(os.path.join(ROOT, "profiles", "r02_bench4096_kernel_stats.csv")).read()
     m = re.search(r'"void uavqp::solve_twisted_kernel<4, 8, 8, 8>\(uavqp::BatchArgs\)",(\d+),(\d+),([\d.]+)', txt)
     assert m, "headline kernel missing from the rocprofv3 --stats summary"
     avg_us = float(m.group(3)) / 1e3
@@ -45,6 +50,7 @@ def test_bench_defaults_follow_the_contract():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert re.search(r'"--gpus", type=int, default=1', src)
     assert re.search(r'"--steps", type=int, default=\d+', src) and re.search(r'"--warmup", type=int, default=\d+', src)
-    assert re.search(r'"--batch", type=int, default=4096', src) and re.search(r'"--segments", type=int, default=8', src)
+    assert re.search(r'"--batch", type=int, default=0', src) and "if args.batch > 0 else 4096" in src and re.search(r'"--segments", type=int, default=8', src)
+    assert re.search(r'"--config", type=int, default=2', src)      # BASELINE.json configs[1]: the configuration the metric is quoted on
     assert re.search(r'"--order", type=int, default=4', src)
     assert "oracle" not in re.sub(r"def cpu_baseline.*?\n\n\n", "", src, flags=re.S).replace("oracle/osqp_port.c", "")  # oracle only in cpu_baseline

@@ -66,6 +66,23 @@ def main():
                       "GB_per_s": n * bytes_c / ms / 1e6, "solved": int((st == 1).sum()), "iters_mean": float(it.float().mean()),
                       "iters_max": int(it.max())}))
 
+    # ---- config 3 with its "K = 2 mid-segment samples" as GENERAL rows (uavqp_solve_rows_batch_device): a position sample at
+    # mid-segment inside the chord +- 0.25 m and a velocity limit there, on top of the knot boxes
+    K = 2
+    wpn = b["waypoints"]
+    tau = np.full((n * M, K), 0.5)
+    drv = np.tile(np.array([0, 1], dtype=np.int32), (n * M, 1))
+    mid = 0.5 * (wpn[:, :-1] + wpn[:, 1:]).reshape(n * M, 3)
+    rlo, rhi = np.zeros((n * M, K, 3)), np.zeros((n * M, K, 3))
+    rlo[:, 0], rhi[:, 0] = mid - 0.25, mid + 0.25
+    rlo[:, 1], rhi[:, 1] = -3.5, 3.5
+    d_tau, d_drv, d_rlo, d_rhi = up(tau), up(drv), up(rlo), up(rhi)
+    ms = timeit(lambda: ctx.solve_rows_device(r, n, M, M, None, d["waypoints"], d["times"], d["bc"], d_lo, d_hi, K, d_tau, d_drv, d_rlo, d_rhi,
+                                              out, st, it), s, n=3, warm=1)
+    print(json.dumps({"config": "3-corridor+rows(K=2: mid-segment position sample, velocity limit)", "n": n, "M": M, "r": r, "ms": ms,
+                      "traj_per_s": n / ms * 1e3, "solved": int((st == 1).sum()), "capped": int((st == -2).sum()),
+                      "iters_mean": float(it.float().mean()), "iters_max": int(it.max())}))
+
     # ---- config 4: 32768 ragged (M in [4, 24]), r=4
     r, n = 4, 32768
     b = W.ragged_batch(4, n, r)
