@@ -108,7 +108,8 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *                          UAVQP_MAX_ITER_REACHED with a feasible, smooth trajectory (as OSQP's status of the same name).
  *   kernel_variant         as uavqp_set_variant (0 auto)
  *   ragged_window_sort     1: ragged batches >= 2048 are dealt to lanes by segment count inside windows (default), 0: lane order
- *   generic_lanes_per_traj 0 auto, 1 = one lane per trajectory, 3 = one lane per (trajectory, axis)
+ *   generic_lanes_per_traj 0 auto, 1 = one lane per trajectory, 2 = a lane pair per trajectory (two-sided elimination),
+ *                          3 = one lane per (trajectory, axis)
  *   generic_waves_per_cu   0 auto, > 0: resident waves per CU of the generic kernel
  *   corridor_pdas_rounds   block-pivoting rounds before the single-pivot active-set phase (default 3)
  *   realloc_dead_band      uavqp_time_reallocate_device stretches only when the limit ratio exceeds this (default 1.01)

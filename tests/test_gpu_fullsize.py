@@ -170,8 +170,9 @@ def test_long_trajectories_generic_path(gpu_ctx, oracle):
 
 
 def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx):
-    """Large ragged batches are dealt to the lanes in windows of 1024 trajectories by descending segment count
-    (window_sort_kernel + solve_generic_kernel<R, LSORT>).  Which lane solves a trajectory must not change a single bit:
+    """Large ragged batches are dealt to the lanes in windows of 16 waves' trajectories by descending segment count
+    (window_sort_kernel + solve_generic2_kernel<R, LSORT>: a lane pair per trajectory, the default; solve_generic_kernel<R, LSORT,
+    NAX>: one lane per trajectory or per (trajectory, axis)).  Which lane solves a trajectory must not change a single bit:
     compare with the plain lane order (uavqp_settings.ragged_window_sort = 0) on a batch that needs two grid rounds, is
     not a multiple of the window, and contains single-segment and over-long (flagged invalid) trajectories.  The status
     buffer is pre-filled with 0 (no valid code): a trajectory the dealing dropped would keep it."""
@@ -204,6 +205,10 @@ def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx):
         c_plain3, st_plain3 = run()
         gpu_ctx.set_settings(ragged_window_sort=1)
         c_deal3, st_deal3 = run()
+        gpu_ctx.set_settings(generic_lanes_per_traj=1)      # one lane per trajectory, windows of 1024
+        c_deal1, st_deal1 = run()
+        gpu_ctx.set_settings(ragged_window_sort=0)
+        c_plain1, st_plain1 = run()
     finally:
         gpu_ctx.set_settings(ragged_window_sort=1, generic_lanes_per_traj=0)
     assert np.array_equal(st_deal3, st_plain3) and np.array_equal(st_deal3, st_deal)
@@ -213,6 +218,10 @@ def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx):
     valid = np.repeat(Ms <= 24, Ms * 24)
     assert np.array_equal(c_deal[valid], c_plain[valid])
     assert np.array_equal(c_deal3[valid], c_plain3[valid])
+    assert np.array_equal(c_deal1[valid], c_plain1[valid]) and np.array_equal(st_deal1, st_deal) and np.array_equal(st_plain1, st_deal)
+    # the three lane layouts order the eliminations differently: same solution to rounding
+    scale = 1.0 + np.abs(c_deal1[valid])
+    assert np.max(np.abs(c_deal[valid] - c_deal1[valid]) / scale) < 1e-9 and np.max(np.abs(c_deal3[valid] - c_deal1[valid]) / scale) < 1e-9
     assert np.all(np.isfinite(c_deal[valid])) and np.all(np.isnan(c_deal[~valid]))   # invalid ones are left untouched
     # spot check: waypoint interpolation of a few trajectories from both ends of the batch
     for k in (0, 1, n // 2, n - 2, n - 1):

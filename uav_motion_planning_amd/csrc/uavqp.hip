@@ -650,6 +650,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 
 #include "qp_twisted.h"
 #include "qp_phased.h"
+#include "qp_generic2.h"
 #include "qp_corridor.h"
 #include "qp_rows.h"
 #include "obstacle_grid.h"
@@ -739,7 +740,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     if (!ctx || !st || st->struct_size != (int32_t)sizeof(uavqp_settings)) return UAVQP_ERR_INVALID_ARG;
     if (!(st->eps_prim_inf >= 0.0) || !(st->realloc_dead_band >= 1.0) || !(st->realloc_overshoot >= 1.0) || !(st->realloc_dead_band < INFINITY) ||
         !(st->realloc_overshoot < INFINITY) || st->corridor_pdas_rounds < 0 || st->corridor_pdas_rounds > 64 ||
-        (st->generic_lanes_per_traj != 0 && st->generic_lanes_per_traj != 1 && st->generic_lanes_per_traj != 3) || st->generic_waves_per_cu < 0 ||
+        (st->generic_lanes_per_traj != 0 && st->generic_lanes_per_traj != 1 && st->generic_lanes_per_traj != 2 && st->generic_lanes_per_traj != 3) || st->generic_waves_per_cu < 0 ||
         st->generic_waves_per_cu > 32)
         return UAVQP_ERR_INVALID_ARG;
     const int rc = apply_variant(ctx, st->kernel_variant);
@@ -939,14 +940,25 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     int nax = n_traj <= 32 * ctx->num_cus ? 1 : 3;
     if (ctx->settings.generic_lanes_per_traj == 1) nax = 3;       // one lane per trajectory carries all three axes
     else if (ctx->settings.generic_lanes_per_traj == 3) nax = 1;  // one lane per (trajectory, axis)
-    const int ipw = nax == 3 ? 64 : 21;
+    // two lanes per trajectory (qp_generic2.h: twisted elimination with a runtime segment count): half the dependent chain
+    // per lane and twice the waves
+    // (inputs staged in LDS: 32 (4 Mmax + 3) doubles per wave, within the 64 KiB a workgroup gets without opting in)
+    const size_t pair_lds = uavqp::generic2_lds_bytes(Mmax);
+    // Measured (MI355X, us per launch, lanes per trajectory 1 / 2 / 3-axis-lanes): 32768 ragged M in [4, 24], r = 4: 86 / 54 / 125;
+    // r = 3: 72 / 48 / 85; 4096 ragged: 45 / 30 / 36; 1000 ragged: 43 / 26 / 29; 32768 x M = 14: 50 / 41 / 76; x M = 24: 123 / 73 /
+    // 178; 262144 x M = 14: 501 / 356 / 716; 32768 x M = 1: 5.4 / 8.5 / 5.9, M = 2: 9.6 / 9.3 / 10.9, M = 3: 13.1 / 13.1 / 15.4
+    // (tools/generic2_probe.py) -- the pair kernel everywhere but for the shortest trajectories.
+    const bool pair = pair_lds <= 64 * 1024 && aligned16 &&
+                      (ctx->settings.generic_lanes_per_traj == 2 || (ctx->settings.generic_lanes_per_traj == 0 && Mmax >= 3));
+    if (pair) nax = 3;
+    const int ipw = pair ? 32 : (nax == 3 ? 64 : 21);
     const int block = 64;
     int grid = (n_traj + ipw - 1) / ipw;
     // Resident waves: the kernel is bound by the E/h workspace round trip, and the workspace is per resident lane.  With
     // one wave per CU it is ~30 MB (r = 4, M = 14) and stays in L2 while the grid strides over the batch (measured with
     // tools/generic_grid_probe.py: 65536 x M=14: 111 us at 1 wave/CU vs 141 us at 8; 262144: 524 vs 640 us; r = 3, M = 20,
     // 262144: 625 vs 920 us); up to 128 trajectories per CU two waves per CU run the batch in a single round (49 vs 58 us).
-    int waves_per_cu = nax == 3 ? (n_traj <= 128 * ctx->num_cus ? 2 : 1) : 12;
+    int waves_per_cu = pair ? (int)std::min<size_t>(4, (160 * 1024) / pair_lds) : (nax == 3 ? (n_traj <= 128 * ctx->num_cus ? 2 : 1) : 12);
     if (ctx->settings.generic_waves_per_cu > 0) waves_per_cu = ctx->settings.generic_waves_per_cu;
     const int max_grid = ctx->num_cus * waves_per_cu;
     if (grid > max_grid) grid = max_grid;
@@ -969,13 +981,17 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
         }
         const int win = 16 * ipw;
         const int n_win = (n_traj + win - 1) / win;
-        if (nax == 3) hipLaunchKernelGGL((uavqp::window_sort_kernel<1024>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
+        if (pair) hipLaunchKernelGGL((uavqp::window_sort_kernel<512>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
+        else if (nax == 3) hipLaunchKernelGGL((uavqp::window_sort_kernel<1024>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
         else hipLaunchKernelGGL((uavqp::window_sort_kernel<336>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
         a.perm = ctx->perm;
     }
 #define UAVQP_GENERIC(RR)                                                                                                   \
     do {                                                                                                                    \
-        if (nax == 3) {                                                                                                     \
+        if (pair) {                                                                                                         \
+            if (lsort) hipLaunchKernelGGL((uavqp::solve_generic2_kernel<RR, true>), dim3(grid), dim3(block), pair_lds, ctx->stream, a);  \
+            else hipLaunchKernelGGL((uavqp::solve_generic2_kernel<RR, false>), dim3(grid), dim3(block), pair_lds, ctx->stream, a);       \
+        } else if (nax == 3) {                                                                                              \
             if (lsort) hipLaunchKernelGGL((uavqp::solve_generic_kernel<RR, true, 3>), dim3(grid), dim3(block), 0, ctx->stream, a);  \
             else hipLaunchKernelGGL((uavqp::solve_generic_kernel<RR, false, 3>), dim3(grid), dim3(block), 0, ctx->stream, a);       \
         } else {                                                                                                            \
@@ -1265,6 +1281,16 @@ extern "C" int uavqp_debug_corridor_stamps(uavqp_ctx* ctx, long long* out7) {
     if (!ctx || !out7 || !ctx->ws) return UAVQP_ERR_INVALID_ARG;
     UAVQP_HIP(hipStreamSynchronize(ctx->stream));
     UAVQP_HIP(hipMemcpy(out7, (char*)ctx->dbg_queue + 64, 7 * sizeof(long long), hipMemcpyDeviceToHost));
+    return UAVQP_OK;
+}
+#endif
+
+#ifdef G2_TIMING
+// (probe build) s_memtime stamps of wave 0 of the last ragged pair-kernel launch: tools/generic2_sections.py
+extern "C" int uavqp_debug_generic2_stamps(uavqp_ctx* ctx, long long* out9) {
+    if (!ctx || !out9) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    UAVQP_HIP(hipMemcpy(out9, (char*)ctx->dummy + 1024, 15 * sizeof(long long), hipMemcpyDeviceToHost));
     return UAVQP_OK;
 }
 #endif
