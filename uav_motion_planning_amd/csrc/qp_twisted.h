@@ -195,8 +195,17 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                 h[0][i][ax] = (isR && ((i & 1) == 0)) ? -v : v;
             }
         }
+        // (LPT == 2: the own durations stay in registers for the emission -- the duration tile has a row stride of M doubles, a
+        // 4-way bank conflict per read for M = 8)
+        double Town[LPT == 2 ? mL : 1];
+#pragma unroll
+        for (int j = 0; j < (LPT == 2 ? mL : 1); ++j) Town[j] = 1.0;
         SegBlocks<R> sa;
-        sa.build(Tof(0));
+        {
+            const double t0 = Tof(0);
+            Town[0] = t0;
+            sa.build(t0);
+        }
         double pb[NAX], dpa[NAX];
 #pragma unroll
         for (int ax = 0; ax < NAX; ++ax) {
@@ -207,7 +216,11 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
         for (int j = 1; j < mL; ++j) {
             if (j < m) {
                 SegBlocks<R> sb;
-                sb.build(Tof(j));
+                {
+                    const double tj = Tof(j);
+                    if constexpr (LPT == 2) Town[j] = tj;
+                    sb.build(tj);
+                }
                 double dpb[NAX];
 #pragma unroll
                 for (int ax = 0; ax < NAX; ++ax) {
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                             }
                             double pa, pb, Tj;
                             if constexpr (C::ALIAS) { pa = P_[j][ax]; pb = P_[j + 1][ax]; Tj = T_[j]; }
-                            else { pa = pos(jc, ax); pb = pos(jc + 1, ax); Tj = Tof(jc); }
+                            else { pa = pos(jc, ax); pb = pos(jc + 1, ax); Tj = Town[j]; }
                             segment_coeffs<R>(isR ? pb : pa, ys, isR ? pa : pb, ye, Tj, fast_rcp(Tj), c8);
                             if (j < m) finite = finite && (fabs(c8[NC - 1]) < INFINITY) && (fabs(c8[R]) < INFINITY);
                             // slot in original order: L ascending, R descending within the chunk
@@ -446,8 +459,31 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                     wave_lds_sync();
 #pragma unroll
                     for (int it = 0; it < PPL; ++it) {
-                        const int g = it * 64 + lane;
-                        const int pl = g / PPL, col = g - pl * PPL;
+                        // which 16-byte piece a lane copies.  Plain order (lane it*64 + l -> piece l of 8 consecutive rows)
+                        // is 2-way conflicted for 128-byte rows at the write-friendly stride of 36 dwords: ds_read_b128
+                        // serves the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) over 64 banks, and the four
+                        // half rows a group reads must tile them -- which at 9 bank-quads per row only both halves of
+                        // rows rho and rho + 8 do.  So instruction `it` takes rows it + 8 k (k = 0..7), quad q of a
+                        // 32-lane half reads half (q >> 1) & 1 of row it + 8 * {0, 2, 2, 0, 3, 1, 1, 3}[q]: every row is
+                        // still written out as one complete 128-byte line (SQ_LDS_BANK_CONFLICT 34 % -> see profiles/).
+                        int pl, col;
+                        if constexpr (PPL == 8 && TILE == 32) {
+                            const int kq = (lane >> 2) & 7;
+                            pl = it + 8 * ((0xD728 >> (2 * kq)) & 3) + (lane & 32);
+                            col = ((kq >> 1) & 1) * 4 + (lane & 3);
+                        } else if constexpr (PPL == 12 && TILE == 32) {
+                            // 192-byte rows at 52 dwords (13 bank-quads): a read group tiles the banks with the same third
+                            // of four rows 4 apart -- instruction `it` copies third it % 3 of rows gamma + 16 (it / 3) + 4 i,
+                            // gamma = the lane group, i = the quad's place in it
+                            const int kq = lane >> 2, k7 = kq & 7;
+                            const int gam = (kq >> 3) * 2 + ((0x96 >> k7) & 1), i4 = k7 >> 1;
+                            pl = gam + 16 * (it / 3) + 4 * i4;
+                            col = 4 * (it % 3) + (lane & 3);
+                        } else {
+                            const int g = it * 64 + lane;
+                            pl = g / PPL;
+                            col = g - pl * PPL;
+                        }
                         const int ctl = pl >> 1, cR = pl & 1;
                         const int cm = cR ? mR : mL;
                         const int ccnt = max(0, min((q + 1) * CH, cm) - q * CH);
