@@ -48,6 +48,7 @@ struct RowsArgs {
     int32_t* iters;             // pre-filled with 0 (may be null)
     double* ws;                 // [wave][knot 1..M][F][lane]
     unsigned long long* active; // [n_traj][3][2 + 2 K]: knot boxes (active, upper), then per row slot (active, upper); may be null
+    const unsigned long long* warm;   // [n_traj][3][2]: initial working set of the knot boxes (the box-only solution's: uavqp.hip), may be null
 };
 
 // g_l, g_r with  p^(d)(tau T) = g_l' x_k + g_r' x_{k+1}   (x = derivatives 0..R-1 at the two end knots of the segment).
@@ -161,6 +162,15 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
             xM[d + 1] = bc[(ND + d) * 3];
         }
         pin = eqmask;
+        if (a.warm) {
+            // Start from the working set of the box-only problem (solved first by the corridor kernel): at its solution all box
+            // multipliers have the right sign, which is what the dual method needs of a starting set.  (Any set is admissible:
+            // the first solve starts every multiplier from 0, so a wrong-signed one reaches zero at t = 0 and leaves.)
+            const unsigned long long valid = M >= 2 ? ((1ull << M) - 2ull) : 0ull;
+            const unsigned long long w0 = a.warm[(size_t)g * 2] & valid & ~eqmask;
+            pin |= w0;
+            upper = a.warm[(size_t)g * 2 + 1] & w0;
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) ract[j] = req[j];
         for (int k = 1; k <= M; ++k)
