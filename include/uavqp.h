@@ -263,7 +263,10 @@ int uavqp_traj_length_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segm
  * (src/planner/path_searching/src/kino_astar.cpp:721-758): body axis b3 = normalize(acc + 9.81 z),
  * b2 = normalize(b3 x (1,0,0)), b1 = normalize(b2 x b3), E = Rot diag(robot_r, robot_r, robot_h) Rot', and a
  * sample collides when some obstacle point o within robot_r + 0.1 of it has |E^-1 (o - p)| <= 1.  The kd-tree
- * radius search of the reference is an exhaustive scan here (same candidate set).
+ * radius search of the reference is an exhaustive scan here.  Candidate set: |o - p|^2 <= (robot_r + 0.1)^2 in float64; the
+ * reference's PCL search works on float32 points with a float radius (kino_astar.cpp:747-748), so a point within float rounding
+ * of the search sphere may be a candidate in one and not in the other.  The VERDICT is unaffected: the ellipsoid (semi-axes
+ * robot_r, robot_r, robot_h <= robot_r) lies strictly inside that sphere, so such a point never passes |E^-1 (o - p)| <= 1.
  *   samples: t_s = t0 + s*dt, position and acceleration from the polynomials (segment rule of uavqp_eval_batch_device)
  *   d_obstacles [n_obs][3] float64
  *   d_first_hit [n_traj] int32: index of the first colliding sample, n_samples if the trajectory is collision-free
@@ -280,7 +283,8 @@ int uavqp_ellipsoid_check_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_
  *     query visit 27 cells; clouds too large for 2^22 cells get larger cells).  Synchronous (sizes depend on the
  *     cloud's bounds); the grid owns a sorted copy of the points, d_obstacles may be freed afterwards.
  *   uavqp_ellipsoid_check_grid_device: arguments and results of uavqp_ellipsoid_check_device with the grid in place
- *     of the raw cloud -- same candidate set and the same arithmetic per candidate, hence identical flags.
+ *     of the raw cloud -- the same candidate set as uavqp_ellipsoid_check_device and the same arithmetic per candidate, hence
+ *     flags identical to it.
  * No reference counterpart as a batch; the per-query semantics are the reference's. */
 typedef struct uavqp_grid uavqp_grid;
 int uavqp_obstacle_grid_build_device(uavqp_ctx* ctx, const double* d_obstacles, int n_obs, double cell_size, uavqp_grid** out_grid);

@@ -292,6 +292,10 @@ def test_corridor_pipeline_helper_one_call(oracle):
         ctx.ellipsoid_check_device(r, n, 0, d_so, d_T, res["coeff"], ns, 0.0, res["check_dt"], d_obs, obs.shape[0], ROBOT_R, ROBOT_H, fh)
         ctx.synchronize()
         assert torch.equal(fh, res["first_hit"])
+        # the repair loop acts on the check: it never leaves more trajectories colliding than the first check found, and what it
+        # reports is the state of the returned coefficients
+        assert 0 <= res["repairs"] <= 2 and int((~res["collision_free"]).sum().item()) <= res["colliding_before_repair"]
+        assert torch.equal(res["collision_free"], fh >= ns)
     assert np.all(T >= b["times"] * (1 - 1e-15))
     for k in range(n):
         s0, M = int(so[k]), int(so[k + 1] - so[k])
