@@ -27,11 +27,8 @@ def main():
         r = int(rng.choice([3, 4]))
         ragged = bool(rng.integers(0, 2))
         n = int(rng.choice([rng.integers(1, 70), rng.integers(70, 600), rng.integers(2048, 3000)], p=[0.6, 0.3, 0.1]))
-        for k, v in (("UAVQP_GENERIC_NAX", rng.choice(["", "1", "3"])), ("UAVQP_NO_LSORT", rng.choice(["", "1"]))):
-            if v:
-                os.environ[k] = str(v)
-            else:
-                os.environ.pop(k, None)
+        knobs = dict(generic_lanes_per_traj=int(rng.choice([0, 1, 2, 3])), ragged_window_sort=int(rng.integers(0, 2)))
+        ctx.set_settings(**knobs)
         if ragged:
             b = W.ragged_batch(draw, n, r, m_lo=1, m_hi=int(rng.integers(2, 26)), seed=seed * 100000 + draw)
             b["times"] = b["times"] * rng.uniform(0.5, 3.0, size=b["times"].shape)
@@ -57,7 +54,7 @@ def main():
             err = np.max(np.abs(g - ref)) / np.max(np.abs(ref))
             worst_eq = max(worst_eq, err)
             if not err < 1e-7:
-                print("EQUALITY FAILURE draw", draw, dict(r=r, ragged=ragged, n=n, k=int(k), M=s1 - s0, err=err), dict(os.environ))
+                print("EQUALITY FAILURE draw", draw, dict(r=r, ragged=ragged, n=n, k=int(k), M=s1 - s0, err=err), knobs)
                 return 1
         # corridor on the same batch (boxes of random width, a few degenerate)
         if n <= 600 and np.all(np.diff(so) <= 63):
