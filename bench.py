@@ -13,7 +13,10 @@ all 3 axes) over one batch of synthetic waypoints already resident in HBM.
   rank solves its own 4096-trajectory shard (weak scaling, no data-path collective in the timed loop).
 --config 4 (BASELINE.json configs[3]): ONE batch of 32768 ragged (4-24 segment) min-snap QPs, kino-A*-like inputs, sharded
   over the N ranks by segment count (uavqp_shard_bounds_ragged); strong scaling.
-In both modes the RCCL all-gather of the solved coefficient shards (uavqp_allgather_coeffs: the ctx-owned communicator of the
+--config 5 (BASELINE.json configs[4]): ONE batch of 16384 ragged min-snap trajectories through the whole corridor pipeline
+  (pipeline.py: boxes from a pillar cloud with the SE(3) robot ellipsoid, <= 5 x (corridor solve + time re-allocation), collision
+  check), sharded like config 4; a step = one pass of the pipeline, host-sequenced (no graph).
+In all modes the RCCL all-gather of the solved coefficient shards (uavqp_allgather_coeffs: the ctx-owned communicator of the
 C ABI, device buffers, in place) is run and timed separately and reported under "allgather" (DESIGN.md section 7).
 
 What is timed: the K steps are replayed as ONE hipGraph of K launches (uavqp_capture_*; --graph 0 = K eager launches), step i
@@ -45,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 4], help="2: 4096 x 8-segment snap per GPU (headline); 4: 32768 ragged, sharded")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5], help="2: 4096 x 8-segment snap per GPU (headline); 4: 32768 ragged, sharded; 5: 16384 ragged + cloud corridors + time re-allocation pipeline, sharded")
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (config 2; default 4096) / in total (config 4; default 32768)")
     ap.add_argument("--segments", type=int, default=8)
     ap.add_argument("--order", type=int, default=4, help="4 = min-snap (7th-order), 3 = min-jerk")
@@ -213,8 +216,8 @@ def main():
                     f"synthetic A*-like waypoints, time allocation '{args.time_mode}'")
         scaling = "weak"
     else:
-        n_total = args.batch if args.batch > 0 else 32768
-        full = W.ragged_batch(4, n_total, r)                      # identical on every rank (seeded)
+        n_total = args.batch if args.batch > 0 else (32768 if args.config == 4 else 16384)
+        full = W.ragged_batch(args.config, n_total, r)            # identical on every rank (seeded)
         so = np.asarray(full["seg_offsets"], dtype=np.int64)
         bounds = D.shard_bounds_ragged(so, world)                  # uavqp_shard_bounds_ragged: balanced by segment count
         shard = D.local_slice(full, bounds[rank], bounds[rank + 1])
@@ -227,6 +230,18 @@ def main():
         workload = (f"configs[3]: ONE batch of {n_total} ragged (4-24 segment) order-{2 * r - 1} 3-axis trajectories, kino-A*-like roll-outs, "
                     f"sharded over {world} GPU(s) by segment count (this rank: {n_local} trajectories, {seg_local} segments)")
         scaling = "strong"
+        if args.config == 5:
+            # the whole device pipeline per step (uav_motion_planning_amd/pipeline.py): plain solve -> corridor boxes from the pillar
+            # cloud (SE(3) robot ellipsoid) -> <= 5 x (warm-started corridor solve + time re-allocation) -> grid collision check
+            # (+ repair of what it flags).  Host-sequenced (it synchronises between rounds): no graph, no pipelined sub-record.
+            obstacles = W.pillar_cloud(5, n_pillars=60, resolution=0.2)       # the same map on every rank (seeded)
+            bytes_local += int(sum(8 * 2 * 3 * (int(m) - 1) for m in Ms))     # corridor rows
+            args.graph = 0
+            args.pipelined_streams = 0
+            args.no_traffic = True
+            workload = (f"configs[4]: ONE batch of {n_total} ragged (4-24 segment) order-{2 * r - 1} trajectories through the corridor pipeline "
+                        f"(boxes from a {obstacles.shape[0]}-point pillar cloud, <= 5 outer rounds of corridor solve + time re-allocation, "
+                        f"collision check), sharded over {world} GPU(s) by segment count (this rank: {n_local} trajectories)")
     set_bytes = 8 * (np.asarray(shard["waypoints"]).size + np.asarray(shard["times"]).size + np.asarray(shard["bc"]).size + 3 * 2 * r * seg_local)
     S = args.sets if args.sets > 0 else int(INFINITY_CACHE_BYTES // set_bytes) + 2
     S = max(1, min(S, 4096))
@@ -245,8 +260,21 @@ def main():
         c.set_variant(args.variant)
         return st_, c
 
+    pipe_state = {}
+    if args.config == 5:
+        from uav_motion_planning_amd.pipeline import corridor_pipeline_device
+        d_obs = up(obstacles)
+        T0 = sets[0]["T"].clone()
+
     def launch(c, i):
         s = sets[i % S]
+        if args.config == 5:
+            s["T"].copy_(T0)                       # the re-allocation stretches the durations in place
+            if "grid" not in pipe_state:           # one grid per map, built once (as a planner would)
+                pipe_state["grid"] = c.obstacle_grid_build(d_obs, d_obs.shape[0], 0.4 + 0.1)
+            res = corridor_pipeline_device(c, r, d_so, s["wp"], s["T"], s["bc"], d_obs, mx, grid=pipe_state["grid"])
+            s["out"], pipe_state["status"], pipe_state["res"] = res["coeff"], res["status"], res
+            return
         c.solve_batch_device(r, n_local, uni, mx, d_so, s["wp"], s["T"], s["bc"], s["out"], d_st)
 
     def fence():
@@ -306,7 +334,9 @@ def main():
         t = torch.tensor([dt, dt_evt], dtype=torch.float64, device=dev if rccl_ok else torch.device("cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_evt = float(t[0].item()), float(t[1].item())
-    if n_local > 0:
+    if n_local > 0 and args.config == 5:
+        assert float((pipe_state["status"] == U.UAVQP_SOLVED).double().mean().item()) > 0.999, "corridor pipeline left trajectories unsolved"
+    elif n_local > 0:
         assert int((d_st[:n_local] == U.UAVQP_SOLVED).sum().item()) == n_local, "some trajectories were not solved"
     if args.inner:
         return
@@ -381,7 +411,7 @@ def main():
         g_s = float(t.item())
         got = full_out if rccl_ok else cpu_full.to(dev)
         ok = bool(torch.equal(got[off:off + c_counts[rank]], sets[0]["out"]))
-        n_step = n_total if args.config == 4 else world * n_local
+        n_step = n_total if args.config != 2 else world * n_local
         gather = {"ms": g_s * 1e3, "bytes_per_rank_out": c_counts[rank] * 8, "bytes_total": tot * 8, "own_shard_intact": ok,
                   "through": "uavqp_allgather_coeffs (RCCL, ctx communicator)" if rccl_ok else f"torch.distributed/{backend} stand-in",
                   "value_with_gather": n_step / (dt / K + g_s)}
@@ -390,14 +420,15 @@ def main():
 
     out = None
     if rank == 0:
-        n_step = n_total if args.config == 4 else world * n_local
+        n_step = n_total if args.config != 2 else world * n_local
         per_launch_s = dt_evt / K
         achieved = bytes_local / per_launch_s / 1e9
         n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 4096
         cpu = cpu_baseline(batch, r, n_cpu) if (n_cpu > 0 and world == 1 and args.config == 2) else None
         traffic = measure_traffic(args) if (world == 1 and not args.no_traffic) else None
         out = {
-            "metric": "trajectories/sec (8-seg 7th-order min-snap, 3-axis)" if args.config == 2 else "trajectories/sec (32768 ragged 4-24-seg min-snap, 3-axis, sharded)",
+            "metric": {2: "trajectories/sec (8-seg 7th-order min-snap, 3-axis)", 4: "trajectories/sec (32768 ragged 4-24-seg min-snap, 3-axis, sharded)",
+                       5: "trajectories/sec (16384 ragged min-snap through the SE(3)-corridor + time re-allocation pipeline, sharded)"}[args.config],
             "value": n_step * K / dt,
             "unit": "trajectories/s",
             "n_gpus": world,
@@ -419,7 +450,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
                          "traffic_detail": traffic, "algorithmic_bytes_per_launch": int(bytes_local),
                          "kernel_ms": per_launch_s * 1e3,
-                         "kernel_ms_is": "HIP events on the launch stream around the timed K-step block / K (same clock as value; includes the inter-kernel gap)",
+                         "kernel_ms_is": ("HIP events on the launch stream around the timed K-step block / K (same clock as value; includes the inter-kernel gap)"
+                                          if args.config != 5 else "one pass of the WHOLE pipeline (about 20 launches, host-synchronised between outer rounds), not one kernel"),
                          "working_set_bytes": int(S * set_bytes),
                          "algorithmic_bytes_per_trajectory": bytes_local / max(n_local, 1)},
             "cpu_baseline": cpu,

@@ -160,8 +160,8 @@ def test_config5_full_size_pipeline_parity(oracle):
     b = W.ragged_batch(5, n, r)
     so = b["seg_offsets"]
     wp = np.asarray(b["waypoints"]).reshape(-1, 3)
-    first = (so[:-1] + np.arange(n)).astype(np.int64)
-    obs = W.pillar_cloud(5, keep_clear=wp[first])
+    obs = W.pillar_cloud(5, n_pillars=60, resolution=0.2)      # the map of tools/bench_configs.py (a waypoint inside a pillar's
+    assert obs.shape[0] > 10000                                #  reach degenerates to the reference's equality row)
     dev = torch.device("cuda", 0)
     up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     d_so, d_wp, d_T, d_bc, d_obs = up(so), up(wp), up(b["times"]), up(b["bc"]), up(obs)

@@ -22,7 +22,8 @@ def corridor_pipeline_device(ctx, r, seg_offsets, waypoints, times, bc, obstacle
     check_robot = (r, h) of the ellipsoid used by the final check when it differs from the one the boxes were built with (a safety
     margin; the tests use it to force the repair path).
     Returns dict(coeff, status, corr_lo, corr_hi (the boxes of the final solve), first_hit (of the final check, check_samples = none),
-    collision_free (bool per trajectory), colliding_before_repair, repairs, rounds, still_stretching, iterations)."""
+    collision_free (bool per trajectory), colliding_before_repair, colliding_with_blocked_waypoints (of those: trajectories with a
+    waypoint the cloud leaves no room around -- not repairable by narrower boxes), repairs, rounds, still_stretching, iterations)."""
     import torch
     n = seg_offsets.numel() - 1
     rows = waypoints.reshape(-1, 3).shape[0]
@@ -57,7 +58,7 @@ def corridor_pipeline_device(ctx, r, seg_offsets, waypoints, times, bc, obstacle
     own_grid = grid is None
     if own_grid:
         grid = ctx.obstacle_grid_build(obstacles, n_obs, chk_r + 0.1)
-    repairs, colliding_before = 0, None
+    repairs, colliding_before, hopeless = 0, None, 0
     try:
         seg_cnt = (seg_offsets[1:] - seg_offsets[:-1]).long()
         traj_of_seg = torch.repeat_interleave(torch.arange(n, device=dev), seg_cnt)
@@ -70,9 +71,19 @@ def corridor_pipeline_device(ctx, r, seg_offsets, waypoints, times, bc, obstacle
             ctx.ellipsoid_check_grid_device(r, n, 0, seg_offsets, times, coeff, check_samples, 0.0, dt, grid, chk_r, chk_h, first_hit)
             ctx.synchronize()
             hit = first_hit < check_samples
-            n_hit = int(hit.sum().item())
             if colliding_before is None:
-                colliding_before = n_hit
+                colliding_before = int(hit.sum().item())
+                # a trajectory with a waypoint the cloud leaves no room around (degenerate box: the searcher's waypoint itself is
+                # within the robot's reach of an obstacle) cannot be helped by narrower boxes
+                roomy = torch.ones(n, dtype=torch.bool, device=dev)
+                tight_rows = ((hi - lo).min(dim=1).values <= 0.0)
+                interior = torch.ones(rows, dtype=torch.bool, device=dev)
+                interior[(seg_offsets[:-1].long() + torch.arange(n, device=dev))] = False
+                interior[(seg_offsets[1:].long() + torch.arange(n, device=dev))] = False
+                roomy[traj_of_row[tight_rows & interior]] = False
+                hopeless = int((hit & ~roomy).sum().item())
+            hit = hit & roomy
+            n_hit = int(hit.sum().item())
             if n_hit == 0 or repairs >= repair_rounds:
                 break
             # halve the boxes of the flagged trajectories towards their waypoints (last round: the waypoint equalities), re-solve
@@ -92,6 +103,6 @@ def corridor_pipeline_device(ctx, r, seg_offsets, waypoints, times, bc, obstacle
         if own_grid:
             ctx.obstacle_grid_destroy(grid)
     return dict(coeff=coeff, status=status, corr_lo=lo, corr_hi=hi, first_hit=first_hit, collision_free=first_hit >= check_samples,
-                colliding_before_repair=colliding_before, repairs=repairs, rounds=rounds,
+                colliding_before_repair=colliding_before, colliding_with_blocked_waypoints=hopeless, repairs=repairs, rounds=rounds,
                 still_stretching=int((changed > 0).sum().item()), iterations=it_hist, check_dt=dt,
                 all_solved=bool((status == _lib.UAVQP_SOLVED).all().item()))
