@@ -229,3 +229,62 @@ def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx):
             continue
         c = c_deal[24 * so[k]:24 * so[k + 1]].reshape(3, Ms[k], 8)
         assert np.allclose(c[:, :, 0].T, wp[so[k] + k:so[k + 1] + k], rtol=0, atol=1e-9 * max(1.0, np.abs(wp).max()))
+
+
+@pytest.mark.parametrize("r", [3, 4])
+def test_pair_kernel_edges_long_ragged_unaligned_and_empty_trajectories(gpu_ctx, oracle, r):
+    """The lane-pair kernel of ragged batches (qp_generic2.h) off its tuned shape: segment counts 1..58 in one batch (more than
+    64 sixteen-byte units per trajectory: the extra staging loop), zero-segment trajectories in the CSR (flagged, nothing written),
+    views that start at an odd double (only 8-byte aligned: the one-lane kernel must take them), and every lane layout against
+    the exact oracle."""
+    import torch
+    rng = np.random.default_rng(58 + r)
+    n = 150
+    Ms = rng.integers(1, 59, size=n)
+    Ms[[3, 77, 149]] = 0                                      # empty trajectories: invalid input, not a crash
+    so = np.zeros(n + 1, dtype=np.int32)
+    so[1:] = np.cumsum(Ms)
+    tot = int(so[-1])
+    wp = np.cumsum(rng.uniform(-1.0, 1.0, size=(tot + n, 3)), axis=0)
+    T = rng.uniform(0.4, 2.0, size=tot)
+    bc = rng.uniform(-1.0, 1.0, size=(n, 2, r - 1, 3))
+    valid = Ms > 0
+    dev = torch.device("cuda", 0)
+    d_so = torch.from_numpy(so).to(dev)
+    nc = 3 * 2 * r
+
+    def run(offset):
+        # buffers shifted by `offset` doubles: offset 1 = 8-byte-aligned-only views
+        def shifted(x):
+            buf = torch.zeros(x.size + 2, dtype=torch.float64, device=dev)
+            v = buf[offset:offset + x.size]
+            v.copy_(torch.from_numpy(np.ascontiguousarray(x).reshape(-1)).to(dev))
+            return v
+        d_wp, d_T, d_bc = shifted(wp), shifted(T), shifted(bc)
+        obuf = torch.full((tot * nc + 2,), np.nan, dtype=torch.float64, device=dev)
+        out = obuf[offset:offset + tot * nc]
+        st = torch.zeros(n, dtype=torch.int32, device=dev)
+        gpu_ctx.solve_batch_device(r, n, 0, 58, d_so, d_wp, d_T, d_bc, out, st)
+        gpu_ctx.synchronize()
+        return out.cpu().numpy(), st.cpu().numpy()
+
+    results = {}
+    try:
+        for mode in (0, 1, 2, 3):
+            gpu_ctx.set_settings(generic_lanes_per_traj=mode)
+            for off in (0, 1):
+                results[(mode, off)] = run(off)
+    finally:
+        gpu_ctx.set_settings(generic_lanes_per_traj=0)
+    for key, (c, st) in results.items():
+        assert np.all(st[valid] == U.UAVQP_SOLVED) and np.all(st[~valid] == U.UAVQP_INVALID_INPUT), key
+        assert np.all(np.isfinite(c)), key                      # every coefficient of every valid trajectory was written
+    base = results[(1, 0)][0]
+    for key, (c, _) in results.items():
+        assert np.max(np.abs(c - base) / (1.0 + np.abs(base))) < 1e-9, key
+    # against the exact oracle, trajectory by trajectory (the oracle wants M >= 1)
+    for k in np.nonzero(valid)[0][::7]:
+        s0, s1 = int(so[k]), int(so[k + 1])
+        ref, _ = oracle.solve_exact_batch(r, np.array([0, s1 - s0], dtype=np.int32), wp[s0 + k:s1 + k + 1], T[s0:s1], bc[k:k + 1])
+        g = base[nc * s0:nc * s1]
+        assert np.max(np.abs(g - ref)) < 1e-8 * np.max(np.abs(ref)), k
