@@ -49,6 +49,7 @@ struct RowsArgs {
     double* ws;                 // [wave][knot 1..M][F][lane]
     unsigned long long* active; // [n_traj][3][2 + 2 K]: knot boxes (active, upper), then per row slot (active, upper); may be null
     const unsigned long long* warm;   // [n_traj][3][2]: initial working set of the knot boxes (the box-only solution's: uavqp.hip), may be null
+    unsigned int* queue;              // work counter, zeroed before the launch
 };
 
 // g_l, g_r with  p^(d)(tau T) = g_l' x_k + g_r' x_{k+1}   (x = derivatives 0..R-1 at the two end knots of the segment).
@@ -103,33 +104,61 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
     constexpr int F_L = 0, F_Y = NL, F_LC = NL + B, F_LN = NL + B + NCN, F = NL + B + 2 * NCN;
     constexpr int NONE = 1 << 30;
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_slots = gridDim.x * blockDim.x;
     const int kmax = a.uniform > 0 ? a.uniform : a.max_segments;   // blocks 1..M
     double* ws = a.ws + (size_t)(slot >> 6) * (size_t)kmax * F * 64 + (slot & 63);
     auto Wf = [&](int k, int f) -> double& { return ws[((size_t)(k - 1) * F + f) * 64]; };   // block k = 1..M
 
+    // Dynamic dealing: a lane that has finished its problem takes the next one from a global counter at once (every lane runs
+    // ONE active-set iteration per trip of the outer loop), so a wave does not run as long as the slowest of 64 problems per
+    // round -- iteration counts spread from 1 to 80+ (config 3 with K = 2 rows: 25 mean, 82 max).
     const long long total = (long long)a.n_traj * 3;
-    for (long long g = slot; g < total; g += n_slots) {
-        const int b = (int)(g / 3), ax = (int)(g - 3LL * b);
-        int s0, M;
-        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
-        const long long base3 = 3LL * ((long long)s0 + b) + ax;
-        const double* wp = a.waypoints + base3;
-        const double* T = a.times + s0;
-        const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
-        auto klo = [&](int k) -> double { return a.corr_lo ? a.corr_lo[base3 + 3 * k] : wp[3 * k]; };
-        auto khi = [&](int k) -> double { return a.corr_hi ? a.corr_hi[base3 + 3 * k] : wp[3 * k]; };
-        auto rdv = [&](int s, int j) -> int { return a.row_deriv ? a.row_deriv[(size_t)(s0 + s) * K + j] : -1; };
-        auto rta = [&](int s, int j) -> double { return a.row_tau[(size_t)(s0 + s) * K + j]; };
-        auto rlo = [&](int s, int j) -> double { return a.row_lo[((size_t)(s0 + s) * K + j) * 3 + ax]; };
-        auto rhi = [&](int s, int j) -> double { return a.row_hi[((size_t)(s0 + s) * K + j) * 3 + ax]; };
+    long long g = -1;            // problem = 3 * trajectory + axis, -1: none
+    bool exhausted = false;      // the counter has run past the last problem
+    int b = 0, ax = 0, s0 = 0, M = 0;
+    long long base3 = 0;
+    const double* wp = a.waypoints;
+    const double* T = a.times;
+    const double* bc = a.bc;
+    auto klo = [&](int k) -> double { return a.corr_lo ? a.corr_lo[base3 + 3 * k] : wp[3 * k]; };
+    auto khi = [&](int k) -> double { return a.corr_hi ? a.corr_hi[base3 + 3 * k] : wp[3 * k]; };
+    auto rdv = [&](int s, int j) -> int { return a.row_deriv ? a.row_deriv[(size_t)(s0 + s) * K + j] : -1; };
+    auto rta = [&](int s, int j) -> double { return a.row_tau[(size_t)(s0 + s) * K + j]; };
+    auto rlo = [&](int s, int j) -> double { return a.row_lo[((size_t)(s0 + s) * K + j) * 3 + ax]; };
+    auto rhi = [&](int s, int j) -> double { return a.row_hi[((size_t)(s0 + s) * K + j) * 3 + ax]; };
+    unsigned long long eqmask = 0ull, pin = 0ull, upper = 0ull;
+    unsigned long long rused[K], req[K], ract[K], rup[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { rused[j] = 0ull; req[j] = 0ull; ract[j] = 0ull; rup[j] = 0ull; }
+    double x0[R], xM[R];
+#pragma unroll
+    for (int c = 0; c < R; ++c) { x0[c] = 0.0; xM[c] = 0.0; }
+    int it = 0;
+    bool done = false, capped = false;
+    double tpend = 1.0;
+    unsigned long long ppin = 0ull, pract[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) pract[j] = 0ull;
+    int new_kind = -1, new_idx = -1;
 
+    for (;;) {
+      if (g < 0 && !exhausted) {
+        const long long q = (long long)atomicAdd(a.queue, 1u);
+        if (q >= total) {
+            exhausted = true;
+        } else {
+        g = q;
+        b = (int)(g / 3);
+        ax = (int)(g - 3LL * b);
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        base3 = 3LL * ((long long)s0 + b) + ax;
+        wp = a.waypoints + base3;
+        T = a.times + s0;
+        bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
         // ---- validation, permanent (equality) constraints
         bool ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;   // working-set masks are 64-bit
         if (ok)
             for (int i = 0; i < M; ++i) ok = ok && (T[i] > 0.0) && (T[i] < INFINITY);
-        unsigned long long eqmask = 0ull, pin = 0ull, upper = 0ull;
-        unsigned long long rused[K], req[K], ract[K], rup[K];
+        eqmask = 0ull; pin = 0ull; upper = 0ull;
 #pragma unroll
         for (int j = 0; j < K; ++j) { rused[j] = 0ull; req[j] = 0ull; ract[j] = 0ull; rup[j] = 0ull; }
         if (ok) {
@@ -151,9 +180,8 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
         }
         if (!ok) {
             atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
-            continue;
-        }
-        double x0[R], xM[R];
+            g = -1;            // takes another problem on the next trip
+        } else {
         x0[0] = wp[0];
         xM[0] = wp[3 * M];
 #pragma unroll
@@ -178,18 +206,27 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
             for (int c = 0; c < NCN; ++c) { Wf(k, F_LC + c) = 0.0; Wf(k, F_LN + c) = 0.0; }
 
         // ---- dual active-set iterations
-        int it = 0;
-        bool done = (M == 1);   // a single segment has no free knot: nothing to decide (its rows cannot be influenced and are ignored)
-        bool capped = false;
+        it = 0;
+        done = (M == 1);   // a single segment has no free knot: nothing to decide (its rows cannot be influenced and are ignored)
+        capped = false;
         // what the next backward sweep does to the stored multipliers: lam_cur <- lam_cur + tpend (lam_new - lam_cur) for the
         // constraints in the masks of the PREVIOUS solve (ppin, pract), 0 for a constraint that has just joined
-        double tpend = 1.0;
-        unsigned long long ppin = 0ull, pract[K];
+        tpend = 1.0;
+        ppin = 0ull;
 #pragma unroll
         for (int j = 0; j < K; ++j) pract[j] = 0ull;
-        int new_kind = -1, new_idx = -1;   // the constraint being added (kind 0: knot box, 1 + j: row slot j), not subject to the sign test
+        new_kind = -1; new_idx = -1;   // the constraint being added (kind 0: knot box, 1 + j: row slot j), not subject to the sign test
+        }      // valid problem
+        }      // ticket in range
+      }        // refill
+      if (__ballot(g >= 0) == 0ull) {
+          if (__ballot(!exhausted) == 0ull) break;
+          continue;
+      }
+      if (g >= 0) {
+        bool finish = done;    // (M == 1: nothing to iterate)
 
-        while (!done) {
+        if (!done) {
             // ================= forward sweep: blocks k = 1..M =================
             {
                 FullBlocks<R> sa;
@@ -531,8 +568,9 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
             ppin = pin;
 #pragma unroll
             for (int j = 0; j < K; ++j) pract[j] = ract[j];
-            if (capped) break;   // the last solve (for the working set it stopped with) is what is handed over
-            if (tkind >= 0) {
+            if (capped) {
+                finish = true;   // the last solve (for the working set it stopped with) is what is handed over
+            } else if (tkind >= 0) {
                 // a multiplier of W reaches zero before the new point: it leaves, the others stop at that fraction of the way
                 tpend = tmin;
                 if (tkind == 0) pin &= ~(1ull << tidx);
@@ -553,35 +591,40 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                     new_kind = vkind; new_idx = vidx;
                 }
             }
-            if (!done && it >= a.max_iter) {
+            if (!done && !finish && it >= a.max_iter) {
                 // give up: re-solve once for the working set as it stands WITHOUT the constraint that was being added
                 if (new_kind == 0) pin &= ~(1ull << new_idx);
                 else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
                 new_kind = -1;
                 capped = true;
             }
+            if (done) finish = true;
         }
 
         // ================= hand-over: Hermite solution of the interior knots =================
-        for (int k = 1; k < M; ++k) {
-            double* o = a.xsol + (base3 + 3LL * k) * R;
+        if (finish) {
+            for (int k = 1; k < M; ++k) {
+                double* o = a.xsol + (base3 + 3LL * k) * R;
 #pragma unroll
-            for (int c = 0; c < R; ++c) o[c] = Wf(k, F_Y + c);
-        }
-        if (capped) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
-        if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
-        if (a.active) {
-            unsigned long long* o = a.active + (size_t)g * (2 + 2 * K);
-            const unsigned long long valid = M >= 2 ? ((1ull << M) - 2ull) : 0ull;
-            o[0] = pin & ~eqmask & valid;
-            o[1] = upper & o[0];
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                o[2 + 2 * j] = ract[j] & ~req[j];
-                o[3 + 2 * j] = rup[j] & o[2 + 2 * j];
+                for (int c = 0; c < R; ++c) o[c] = Wf(k, F_Y + c);
             }
+            if (capped) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
+            if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
+            if (a.active) {
+                unsigned long long* o = a.active + (size_t)g * (2 + 2 * K);
+                const unsigned long long valid = M >= 2 ? ((1ull << M) - 2ull) : 0ull;
+                o[0] = pin & ~eqmask & valid;
+                o[1] = upper & o[0];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    o[2 + 2 * j] = ract[j] & ~req[j];
+                    o[3 + 2 * j] = rup[j] & o[2 + 2 * j];
+                }
+            }
+            g = -1;
         }
-    }
+      }   // lane has a problem
+    }     // trips
 }
 
 }  // namespace uavqp

@@ -1412,14 +1412,15 @@ extern "C" int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, 
     if (grid > max_grid) grid = max_grid;
     const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
     const size_t b_state = sizeof(double) * (size_t)Mmax * F * (size_t)grid * 64;
-    int rc = ensure_ws(ctx, b_xsol + b_state);
+    int rc = ensure_ws(ctx, b_xsol + 256 + b_state);
     if (rc != UAVQP_OK) return rc;
     uavqp::RowsArgs a;
     a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax;
     a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 12 * Mmax * (1 + K) + 30;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.row_tau = d_row_tau; a.row_deriv = d_row_deriv; a.row_lo = d_row_lo; a.row_hi = d_row_hi;
-    a.xsol = ctx->ws; a.ws = (double*)((char*)ctx->ws + b_xsol);
+    a.xsol = ctx->ws; a.queue = (unsigned int*)((char*)ctx->ws + b_xsol); a.ws = (double*)((char*)ctx->ws + b_xsol + 256);
+    UAVQP_HIP(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
     a.status = d_status_out; a.iters = d_iters_out; a.active = (unsigned long long*)d_active_out;
     a.warm = warm ? (const unsigned long long*)ctx->rows_warm : nullptr;
     hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
