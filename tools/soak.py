@@ -40,7 +40,7 @@ def main():
             b["bc"] = rng.uniform(-2.0, 2.0, size=b["bc"].shape)
             so, uni = b["seg_offsets"], M
             spec = (2 <= M <= 12 and M != 11) if r == 4 else (M in (2, 3, 4, 5, 6, 7, 8, 10, 12, 16))
-            ctx.set_variant(int(rng.choice([0, 1, 2, 8, 16, 32])) if spec else int(rng.choice([0, 1])))
+            ctx.set_variant(int(rng.choice([0, 1, 2, 4, 8, 16, 32])) if spec else int(rng.choice([0, 1])))
             got, st = ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
             ctx.set_variant(0)
         wp = np.asarray(b["waypoints"]).reshape(-1, 3)

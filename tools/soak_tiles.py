@@ -30,7 +30,7 @@ def main():
         b["bc"] = rng.uniform(-2.0, 2.0, size=b["bc"].shape)
         d = {k: torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in ("waypoints", "times", "bc")}
         outs = []
-        variant = int(rng.choice([0, 2, 8, 16, 32]))
+        variant = int(rng.choice([0, 2, 4, 8, 16, 32]))
         for v in (variant, 1):
             ctx.set_variant(v)
             out = torch.full((n * 3 * M * 2 * r,), float("nan"), dtype=torch.float64, device=dev)

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
     constexpr int NAX = C::NAX;
     constexpr int ND = C::ND, NC = C::NC, NK = C::NK, mL = C::mL, mR = C::mR;
     static_assert(M >= 2, "twisted kernel needs an interior knot");
-    static_assert((LPT == 2 && (TILE == 32 || TILE == 16)) || (LPT == 8 && TILE == 8), "tile shapes: 2 lanes x 32|16, 8 lanes x 8");
+    static_assert((LPT == 2 && (TILE == 32 || TILE == 16)) || (LPT == 8 && TILE == 8) || (LPT == 16 && TILE == 4), "tile shapes: 2 lanes x 32|16, 8 lanes x 8, 16 lanes x 4");
 
     __shared__ __attribute__((aligned(16))) double s_in[2][C::IN_D];
     __shared__ __attribute__((aligned(16))) double s_out[LPT == 2 ? C::OUT_D : 2];
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
     const int isR = lane & 1;
     const int tl = lane / LPT;
     const int tlc = tl < TILE ? tl : TILE - 1;  // clamp LDS indexing of idle lanes (TILE == 16)
-    const int axl = (lane % LPT) >> 1;           // LPT == 8: axis of this lane pair (3 = idle pair)
+    const int axl = ((lane % LPT) >> 1) & 3;     // LPT >= 8: axis of this lane pair (3 = idle pair)
+    const int sub = LPT == 16 ? (lane >> 3) & 1 : 0;   // LPT == 16: which half of the own segments this lane pair emits
     const int ax0 = LPT == 2 ? 0 : (axl < 3 ? axl : 2);
     const int m = isR ? mR : mL;
     const int n_tiles = (a.n_traj + TILE - 1) / TILE;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
 #pragma unroll
                         for (int ax = 0; ax < NAX; ++ax) z[i][ax] -= sa.A01[q][i] * h[j - 1][q][ax];
                     }
-                typename std::conditional<LPT == 8, SymInv<ND>, SmallLDL<ND>>::type ldl;
+                typename std::conditional<LPT >= 8, SymInv<ND>, SmallLDL<ND>>::type ldl;
                 ldl.factor(S);
 #pragma unroll
                 for (int ax = 0; ax < NAX; ++ax) {
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
 #pragma unroll
                 for (int c = i + 1; c < ND; ++c) S[i][c] = 0.0;  // upper triangle is never read
             }
-            typename std::conditional<LPT == 8, SymInv<ND>, SmallLDL<ND>>::type ldl;
+            typename std::conditional<LPT >= 8, SymInv<ND>, SmallLDL<ND>>::type ldl;
             ldl.factor(S);
 #pragma unroll
             for (int ax = 0; ax < NAX; ++ax) {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
         bool finite = true;
         double* __restrict__ out = a.coeff + (size_t)base * 3 * M * NC;
 
-        if constexpr (LPT == 8) {
+        if constexpr (LPT >= 8) {
             // one axis per lane pair: coefficients go straight from registers to HBM (4 x 16 B per segment);
             // at the batch sizes this shape is used for, store efficiency is irrelevant, latency is not.
             // Back-substitution first (in place, h[j] <- y_j), so that the mL segment evaluations below are
@@ -359,8 +360,14 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                         }
                 }
             }
+            // LPT == 16: two lane pairs per (trajectory, axis) repeat elimination and back-substitution and split the EMISSION --
+            // pair `sub` evaluates and stores the own segments sub * H .. sub * H + H - 1 (selects between the two compile-time
+            // candidates, one instruction stream): 4 trajectories per wave, so a 4096-trajectory batch fills all 1024 SIMDs and
+            // the longest part of the wave (emission: ~60 % of its cycles) is halved.
+            constexpr int NSUB = LPT / 8, H = (mL + NSUB - 1) / NSUB;
 #pragma unroll
-            for (int j = 0; j < mL; ++j) {
+            for (int s = 0; s < H; ++s) {
+                const int j = s + sub * H;
                 const bool act = (j < m);
                 const int jc = act ? j : (m > 0 ? m - 1 : 0);
                 const double Tj = Tof(jc);
@@ -370,8 +377,13 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
                     const double fs = ((d & 1) == 0) ? -1.0 : 1.0;
-                    const double yj = h[j][d][0];
-                    const double yj1 = (j + 1 >= mL || j + 1 == m) ? ynext[d][0] : h[j + 1 < mL ? j + 1 : j][d][0];
+                    auto Y = [&](int q) -> double { return (q >= mL || q == m) ? ynext[d][0] : h[q < mL ? q : mL - 1][d][0]; };
+                    double yj = h[s][d][0], yj1 = Y(s + 1);
+                    if constexpr (NSUB == 2) {
+                        const int jb = (H + s < mL) ? H + s : mL - 1;
+                        yj = sub ? h[jb][d][0] : yj;
+                        yj1 = sub ? Y(H + s + 1) : yj1;
+                    }
                     ys[d] = isR ? fs * yj1 : yj;
                     ye[d] = isR ? fs * yj : yj1;
                 }
@@ -502,12 +514,13 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
             const int f = finite ? 1 : 0;
             const int other = __builtin_amdgcn_mov_dpp(f, 0xB1, 0xF, 0xF, true);
             bool fin = (f & other) != 0;
-            if constexpr (LPT == 8) {  // all three axis pairs of the trajectory must be finite
+            if constexpr (LPT >= 8) {  // all axis pairs of the trajectory must be finite
                 const unsigned long long fm = __ballot(fin || axl == 3);
-                fin = ((fm >> (8 * tlc)) & 0xFFull) == 0xFFull;
+                constexpr unsigned long long grp = LPT == 8 ? 0xFFull : 0xFFFFull;
+                fin = ((fm >> (LPT * tlc)) & grp) == grp;
             }
             bool okt = ok;
-            if constexpr (LPT == 8) okt = (okmask >> (8 * tlc)) & 1ull;  // lane 0 of the group is a real axis pair
+            if constexpr (LPT >= 8) okt = (okmask >> (LPT * tlc)) & 1ull;  // lane 0 of the group is a real axis pair
             if ((lane % LPT) == 0 && tl < nv && a.status) a.status[base + tl] = okt ? (fin ? UAVQP_SOLVED : UAVQP_NON_FINITE) : UAVQP_INVALID_INPUT;
         }
         UAVQP_STAMP(4);

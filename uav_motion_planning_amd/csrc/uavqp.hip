@@ -660,6 +660,7 @@ namespace uavqp {
 typedef void (*twisted_fn)(BatchArgs);
 template <int R, int M>
 static twisted_fn twisted_ptr(int tile) {
+    if (tile == 4) return &solve_twisted_kernel<R, M, 4, 16>;  // two lane pairs per axis: emission split in two (smallest batches)
     if (tile == 8) return &solve_twisted_kernel<R, M, 8, 8>;  // one lane pair per axis (latency shape)
     return tile == 16 ? &solve_twisted_kernel<R, M, 16> : &solve_twisted_kernel<R, M, 32>;
 }
@@ -806,7 +807,7 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
     uavqp_default_settings(&ctx->settings);
     if (const char* e = std::getenv("UAVQP_TILE")) {
         const int t = std::atoi(e);
-        if (t == 8 || t == 16 || t == 32 || t == 64) {
+        if (t == 4 || t == 8 || t == 16 || t == 32 || t == 64) {
             (void)apply_variant(ctx, t);
             ctx->settings.kernel_variant = t;
         }
@@ -850,7 +851,7 @@ extern "C" int uavqp_synchronize(uavqp_ctx* ctx) {
 }
 
 static int apply_variant(uavqp_ctx* ctx, int variant) {
-    if (variant == 8 || variant == 16 || variant == 32 || variant == 64) {  // specialised kernel with a fixed tile shape
+    if (variant == 4 || variant == 8 || variant == 16 || variant == 32 || variant == 64) {  // specialised kernel with a fixed tile shape
         ctx->variant = 2;
         ctx->tile_override = variant;
         return UAVQP_OK;
@@ -911,7 +912,11 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
         // 4096: 6.0 / 7.5 / 8.2   8192: 8.7 / 8.5 / 9.4   16384: 14.1 / 9.7 / 10.0   32768: 23.8 / 17.5 / 12.6).
         // One CU moves only ~10 B/clk, so a small batch is spread over all 256 CUs with fewer trajectories per
         // wave; a large one wants the full-wave shape that does the least redundant work.
-        int tile = (n_traj <= 28 * ctx->num_cus) ? 8 : (n_traj <= 72 * ctx->num_cus ? 16 : 32);
+        // Tile 4 (16 lanes per trajectory: emission split over two lane pairs per axis) was built for the 4096 headline batch --
+        // 1024 waves, every SIMD busy, 15 % fewer instructions per wave -- and measures 6.51 vs 6.47 us there (four waves per CU
+        // slow each other down by what the shorter wave gains); it wins only while the grid is small: 1024 trajectories 4.21 vs
+        // 4.59 us, 2048: 5.16 vs 5.03 us.
+        int tile = (n_traj <= 5 * ctx->num_cus) ? 4 : ((n_traj <= 28 * ctx->num_cus) ? 8 : (n_traj <= 72 * ctx->num_cus ? 16 : 32));
         if (ctx->tile_override) tile = ctx->tile_override;
         if (tile == 64) {  // phase-split workgroup kernel (16 trajectories per 256-thread workgroup)
             uavqp::twisted_fn pf = uavqp::find_phased(r, uniform_segments);
