@@ -386,10 +386,27 @@ def main():
         mine = full_out[off:off + c_counts[rank]]
         mine.copy_(sets[0]["out"])
         gctx = None
+        comm_err = None
         if rccl_ok:
-            D.create_comm(ctx)                 # ctx-owned RCCL communicator (uavqp_comm_create); torch.distributed ships the unique id
+            # ctx-owned RCCL communicator (uavqp_comm_create); torch.distributed ships the unique id.  The exchange leg must never
+            # take the headline line down with it: a rank that cannot build the communicator says so, the ranks agree (MIN), and
+            # the leg falls back to torch.distributed's own all-gather on the same device buffers.
+            try:
+                D.create_comm(ctx)
+                flag = 1
+            except Exception as e:  # noqa: BLE001
+                comm_err, flag = repr(e), 0
+            tf = torch.tensor([flag], dtype=torch.int32, device=dev)
+            dist.all_reduce(tf, op=dist.ReduceOp.MIN)
+            if int(tf.item()) == 0:
+                if flag:
+                    ctx.comm_destroy()
+                comm_err = comm_err or "another rank could not create the communicator"
+        if rccl_ok and comm_err is None:
             gctx = ctx
             do = lambda: D.allgather_shards(mine, c_counts, full_out, ctx)
+        elif rccl_ok:
+            do = lambda: D.allgather_shards(mine, c_counts, full_out, None)
         else:
             cpu_full, cpu_mine = full_out.cpu(), mine.cpu()
             do = lambda: D.allgather_shards(cpu_mine, c_counts, cpu_full, None)
@@ -413,7 +430,8 @@ def main():
         ok = bool(torch.equal(got[off:off + c_counts[rank]], sets[0]["out"]))
         n_step = n_total if args.config != 2 else world * n_local
         gather = {"ms": g_s * 1e3, "bytes_per_rank_out": c_counts[rank] * 8, "bytes_total": tot * 8, "own_shard_intact": ok,
-                  "through": "uavqp_allgather_coeffs (RCCL, ctx communicator)" if rccl_ok else f"torch.distributed/{backend} stand-in",
+                  "through": ("uavqp_allgather_coeffs (RCCL, ctx communicator)" if gctx is not None else
+                              (f"torch.distributed all-gather (uavqp_comm_create failed: {comm_err})" if rccl_ok else f"torch.distributed/{backend} stand-in")),
                   "value_with_gather": n_step / (dt / K + g_s)}
         if gctx is not None:
             gctx.comm_destroy()
