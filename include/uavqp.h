@@ -210,8 +210,11 @@ int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  *                active / at the upper bound (bit k = interior waypoint k), then per row slot j words 2+2j / 3+2j (bit i = segment i)
  * Exact dual active-set solve (Goldfarb-Idnani on the block-tridiagonal KKT system with the rows' multipliers riding in the knot
  * blocks): no feasible starting point is needed, the result is the QP's minimiser to rounding.  An infeasible or
- * degenerate problem stops at uavqp_settings.max_iter (default 12 M (1 + rows_per_segment) + 30) with UAVQP_MAX_ITER_REACHED and
- * the minimiser of the working set reached so far (which need NOT satisfy the remaining rows).  M <= 63.  Asynchronous. */
+ * degenerate problem ends with UAVQP_MAX_ITER_REACHED and the minimiser of the last regular working set (which need NOT satisfy
+ * the remaining rows): either at uavqp_settings.max_iter (default 12 M (1 + rows_per_segment) + 30), or as soon as a row of the
+ * working set is no longer on its bound after the solve -- the working set's KKT system has become singular to working
+ * precision (rows that no free unknown can move, e.g. a position sample right behind the fixed start state).  M <= 63.
+ * Asynchronous. */
 int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                   const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
                                   const double* d_bc, const double* d_corr_lo, const double* d_corr_hi, int rows_per_segment,

@@ -180,3 +180,34 @@ def test_rows_invalid_input_is_flagged(gpu_ctx):
     drv[5 * M, 0] = 3                         # derivative order >= r
     got, st, it, act = run_rows(gpu_ctx, r, b, None, None, K, tau, drv, rlo, rhi, M)
     assert list(st[[2, 4, 5]]) == [U.UAVQP_INVALID_INPUT] * 3 and np.all(st[[0, 1, 3]] == U.UAVQP_SOLVED)
+
+
+def test_conflicting_rows_are_reported_not_solved(gpu_ctx):
+    """Found by tools/soak_rows.py: when the rows of a working set become (numerically) dependent on the free unknowns -- an
+    infeasible or degenerate problem -- its KKT system is singular, the solve no longer puts the active rows on their bounds, and
+    such a problem used to come back UAVQP_SOLVED with violated rows.  Here the same functional twice with contradictory bounds
+    (p(0.3 T) <= a and p(0.3 T) >= a + 0.1): UAVQP_MAX_ITER_REACHED, the feasible neighbours unaffected."""
+    r, M, K, n = 3, 6, 2, 8
+    b = W.uniform_batch(3, n, M, r, time_mode="reference")
+    eq, _ = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=M)
+    c = eq.reshape(n, 3, M, 2 * r)
+    tau = np.tile(np.array([0.3, 0.3]), (n * M, 1))
+    drv = np.tile(np.array([0, 0]), (n * M, 1))
+    rlo, rhi = np.full((n * M, K, 3), -BIG), np.full((n * M, K, 3), BIG)
+    bad = [1, 5]
+    for k in range(n):
+        t = 0.3 * b["times"][k, 2]
+        p = sum(c[k, :, 2, q] * t ** q for q in range(2 * r))                   # the unconstrained path at the sample of segment 2
+        if k in bad:
+            rhi[k * M + 2, 0] = p - 0.05                                         # slot 0: p(0.3 T) <= a
+            rlo[k * M + 2, 1] = p + 0.05                                         # slot 1: p(0.3 T) >= a + 0.1
+        else:
+            rhi[k * M + 2, 0] = p + 0.5                                          # slack rows
+            rlo[k * M + 2, 1] = p - 0.5
+    got, st, it, act = run_rows(gpu_ctx, r, b, None, None, K, tau, drv, rlo, rhi, M)
+    good = np.setdiff1d(np.arange(n), bad)
+    assert np.all(st[good] == U.UAVQP_SOLVED) and np.all(st[bad] == U.UAVQP_MAX_ITER_REACHED), st
+    assert np.all(np.isfinite(got))
+    g = got.reshape(n, 3, M, 2 * r)
+    assert np.max(np.abs(g[good] - c[good])) < 1e-9 * np.max(np.abs(c))         # their rows are slack: the equality solution
+    assert it[bad].max() < 20                                                    # detected at once, not at the iteration cap

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
             bool vupper = false;
             double tmin = 2.0;           // first multiplier to reach zero on the way to the new point
             int tkind = -1, tidx = NONE;
+            bool inconsistent = false;   // an active row is not on its bound: singular working set
             {
                 double yn[B];            // block k+1
 #pragma unroll
@@ -485,10 +486,20 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                     if (k <= M - 1) {
 #pragma unroll
                         for (int j = 0; j < K; ++j) {
-                            if (!usedn[j] || ((ract[j] >> k) & 1ull)) continue;
+                            if (!usedn[j]) continue;
                             double v = 0.0;
 #pragma unroll
                             for (int c = 0; c < R; ++c) v += gln[j][c] * y[c] + grn[j][c] * (k + 1 == M ? xM[c] : yn[c]);
+                            if ((ract[j] >> k) & 1ull) {
+                                // a row of the working set must sit ON its bound.  If it does not, the working set's KKT system is
+                                // singular to working precision: its rows are (numerically) dependent on the free unknowns -- an
+                                // infeasible or degenerate problem (e.g. a position sample right behind the fixed start state,
+                                // which no free derivative can move).  The solve is then worthless; the iteration ends as the
+                                // iteration cap does (found by tools/soak_rows.py: such a problem came back "solved").
+                                const double bnd = ((rup[j] >> k) & 1ull) ? rhi(k, j) : rlo(k, j);
+                                if (!(fabs(v - bnd) <= 1e-8 * (1.0 + fabs(bnd)))) inconsistent = true;
+                                continue;
+                            }
                             const double l = rlo(k, j), h = rhi(k, j);
                             const double below = l - v, above = v - h;
                             const double viol = (below > above ? below : above);
@@ -570,6 +581,18 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
             for (int j = 0; j < K; ++j) pract[j] = ract[j];
             if (capped) {
                 finish = true;   // the last solve (for the working set it stopped with) is what is handed over
+            } else if (inconsistent) {
+                // as at the iteration cap: one more solve WITHOUT the constraint that was being added (or, if none was, without
+                // the rows of the working set), status UAVQP_MAX_ITER_REACHED
+                if (new_kind == 0) pin &= ~(1ull << new_idx);
+                else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
+                else {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) ract[j] = req[j];
+                }
+                new_kind = -1;
+                tpend = 1.0;
+                capped = true;
             } else if (tkind >= 0) {
                 // a multiplier of W reaches zero before the new point: it leaves, the others stop at that fraction of the way
                 tpend = tmin;
