@@ -86,8 +86,7 @@ int uavqp_synchronize(uavqp_ctx* ctx);
 /* Kernel variant selection: 0 = auto, 1 = generic lane-per-trajectory kernel, 2 = register-resident
  * specialised kernel (uniform batches only, tile shape chosen by batch size); 4 / 8 / 16 / 32 = specialised
  * kernel with that many trajectories per wave (4: two lane pairs per axis, the smallest batches; 8: one lane
- * pair per axis, latency shape; 16 / 32: one lane pair per trajectory); 64 = phase-split workgroup kernel
- * (even segment counts; falls back to 8).
+ * pair per axis, latency shape; 16 / 32: one lane pair per trajectory).
  * For benchmarking/tests; results agree to rounding. */
 int uavqp_set_variant(uavqp_ctx* ctx, int variant);
 

@@ -135,7 +135,7 @@ def test_quarter_million_batch_throughput_shape_agrees_with_generic(gpu_ctx):
     assert rel.max() < 1e-10
 
 
-@pytest.mark.parametrize("variant", [0, 1, 8, 32, 64])
+@pytest.mark.parametrize("variant", [0, 1, 4, 8, 32])
 def test_non_finite_waypoints_and_extreme_allocations(gpu_ctx, variant):
     """NaN / inf waypoints give UAVQP_NON_FINITE for that trajectory only; time ratios of 1:200 inside one
     trajectory still solve (they arise in re-allocation loops)."""

@@ -649,7 +649,6 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 }  // namespace uavqp
 
 #include "qp_twisted.h"
-#include "qp_phased.h"
 #include "qp_generic2.h"
 #include "qp_corridor.h"
 #include "qp_rows.h"
@@ -673,12 +672,6 @@ static twisted_fn find_twisted(int r, int M, int tile) {
 #undef UAVQP_CASE
     return nullptr;
 }
-static twisted_fn find_phased(int r, int M) {
-#define UAVQP_PCASE(RR, MM) if (r == RR && M == MM) return &solve_phased_kernel<RR, MM>;
-    UAVQP_PCASE(4, 4) UAVQP_PCASE(4, 8) UAVQP_PCASE(3, 4) UAVQP_PCASE(3, 8) UAVQP_PCASE(3, 16)
-#undef UAVQP_PCASE
-    return nullptr;
-}
 }  // namespace uavqp
 
 // ===================================================================================================
@@ -693,7 +686,7 @@ struct uavqp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int variant = 0;
-    int tile_override = 0;  // fixed tile shape of the specialised kernel (variants 8 / 16 / 32 / 64)
+    int tile_override = 0;  // fixed tile shape of the specialised kernel (variants 4 / 8 / 16 / 32)
     uavqp_settings settings{};
     int num_cus = 256;
     double* ws = nullptr;
@@ -807,7 +800,7 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
     uavqp_default_settings(&ctx->settings);
     if (const char* e = std::getenv("UAVQP_TILE")) {
         const int t = std::atoi(e);
-        if (t == 4 || t == 8 || t == 16 || t == 32 || t == 64) {
+        if (t == 4 || t == 8 || t == 16 || t == 32) {
             (void)apply_variant(ctx, t);
             ctx->settings.kernel_variant = t;
         }
@@ -851,7 +844,7 @@ extern "C" int uavqp_synchronize(uavqp_ctx* ctx) {
 }
 
 static int apply_variant(uavqp_ctx* ctx, int variant) {
-    if (variant == 4 || variant == 8 || variant == 16 || variant == 32 || variant == 64) {  // specialised kernel with a fixed tile shape
+    if (variant == 4 || variant == 8 || variant == 16 || variant == 32) {  // specialised kernel with a fixed tile shape
         ctx->variant = 2;
         ctx->tile_override = variant;
         return UAVQP_OK;
@@ -918,18 +911,6 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
         // 4.59 us, 2048: 5.16 vs 5.03 us.
         int tile = (n_traj <= 5 * ctx->num_cus) ? 4 : ((n_traj <= 28 * ctx->num_cus) ? 8 : (n_traj <= 72 * ctx->num_cus ? 16 : 32));
         if (ctx->tile_override) tile = ctx->tile_override;
-        if (tile == 64) {  // phase-split workgroup kernel (16 trajectories per 256-thread workgroup)
-            uavqp::twisted_fn pf = uavqp::find_phased(r, uniform_segments);
-            if (pf) {
-                a.ws = nullptr;
-                const int n_tiles = (n_traj + 15) / 16;
-                const int g = n_tiles < ctx->num_cus * 4 ? n_tiles : ctx->num_cus * 4;
-                hipLaunchKernelGGL(pf, dim3(g), dim3(256), 0, ctx->stream, a);
-                UAVQP_HIP(hipGetLastError());
-                return UAVQP_OK;
-            }
-            tile = 8;
-        }
         uavqp::twisted_fn fn = uavqp::find_twisted(r, uniform_segments, tile);
         if (fn) {
             a.ws = nullptr;
