@@ -110,7 +110,14 @@ def cpu_baseline(batch, r, n_sample):
         t0 = time.perf_counter()
         oracle.osqp_solve_batch(*args, threads=cores)
         dtn.append(time.perf_counter() - t0)
-    return {"value": n / dt1, "unit": "trajectories/s", "cores": 1, "kind": "port",
+    # second, stronger CPU baseline: the exact KKT solve of the same QPs (oracle/qp_oracle.c, binary128 LU:
+    # the checker of the parity tests), one core, a smaller sample
+    ne = min(n, 256)
+    t0 = time.perf_counter()
+    oracle.solve_exact_batch(r, so[: ne + 1], batch["waypoints"][:ne], batch["times"][:ne], batch["bc"][:ne])
+    dte = time.perf_counter() - t0
+    exact = {"value": ne / dte, "cores": 1, "sample": f"first {ne} trajectories, exact KKT solve in binary128 (the parity oracle), one pass of {dte:.2f} s"}
+    return {"value": n / dt1, "unit": "trajectories/s", "cores": 1, "kind": "port", "exact_kkt": exact,
             "sample": f"first {n} trajectories of the same batch (M={M}, r={r}); OSQP-port, reference settings "
                       f"(eps 1e-3, max_iter 1000), 3 x (setup+solve+cleanup) per trajectory; median of {passes} passes of {dt1:.2f} s on 1 core; "
                       f"median {int(np.median(iters))} ADMM iterations, {int((st == 1).sum())}/{n} reported solved",
@@ -444,6 +451,20 @@ def main():
         n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 4096
         cpu = cpu_baseline(batch, r, n_cpu) if (n_cpu > 0 and world == 1 and args.config == 2) else None
         traffic = measure_traffic(args) if (world == 1 and not args.no_traffic) else None
+        host_e2e = None
+        if world == 1 and args.config == 2 and n_cpu > 0:
+            # the same batch from HOST pointers (uavqp_solve_batch_host: staging copies over PCIe, solve, copy back, synchronise):
+            # what a caller without device-resident data sees.  Reported next to `value`, never as it.
+            hw, hT, hbc = np.asarray(batch["waypoints"]), np.asarray(batch["times"]), np.asarray(batch["bc"])
+            for _ in range(3):
+                ctx.solve_batch_host(r, None, hw, hT, hbc, uniform_segments=uni)
+            ht = []
+            for _ in range(15):
+                h0 = time.perf_counter()
+                ctx.solve_batch_host(r, None, hw, hT, hbc, uniform_segments=uni)
+                ht.append(time.perf_counter() - h0)
+            host_e2e = {"value": n_local / float(np.median(ht)), "unit": "trajectories/s", "ms_per_call": float(np.median(ht)) * 1e3,
+                        "bytes_over_the_host_link": int(bytes_local), "note": "pageable host buffers in and out, one call per batch, median of 15"}
         out = {
             "metric": {2: "trajectories/sec (8-seg 7th-order min-snap, 3-axis)", 4: "trajectories/sec (32768 ragged 4-24-seg min-snap, 3-axis, sharded)",
                        5: "trajectories/sec (16384 ragged min-snap through the SE(3)-corridor + time re-allocation pipeline, sharded)"}[args.config],
@@ -462,6 +483,7 @@ def main():
                        "variant": args.variant, "graph": bool(graph is not None), "buffer_sets": S, "buffer_set_bytes": int(set_bytes),
                        "repeats": R, "parallelism": f"shard{world}", "shard_bounds": bounds if world <= 16 else None},
             "timing": {"block_wall_ms_median": dt * 1e3, "block_event_ms_median": dt_evt * 1e3,
+                       "block_wall_ms_p10_p90": [float(np.percentile(wall, 10)) * 1e3, float(np.percentile(wall, 90)) * 1e3],
                        "block_wall_ms_min_max": [float(np.min(wall)) * 1e3, float(np.max(wall)) * 1e3], "repeats": R,
                        "note": "K-step block between barrier + synchronize, repeated; value and ms_per_step from the median wall time (MAX over ranks)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -474,6 +496,8 @@ def main():
                          "algorithmic_bytes_per_trajectory": bytes_local / max(n_local, 1)},
             "cpu_baseline": cpu,
         }
+        if host_e2e:
+            out["host_pointers"] = host_e2e
         if pipelined:
             out["pipelined"] = pipelined
         if gather:
