@@ -279,7 +279,7 @@ def main():
             s["T"].copy_(T0)                       # the re-allocation stretches the durations in place
             if "grid" not in pipe_state:           # one grid per map, built once (as a planner would)
                 pipe_state["grid"] = c.obstacle_grid_build(d_obs, d_obs.shape[0], 0.4 + 0.1)
-            res = corridor_pipeline_device(c, r, d_so, s["wp"], s["T"], s["bc"], d_obs, mx, grid=pipe_state["grid"])
+            res = corridor_pipeline_device(c, r, d_so, s["wp"], s["T"], s["bc"], d_obs, mx, grid=pipe_state["grid"], repair_rounds=0)   # BASELINE config 5 = boxes + <= 5 outer rounds (+ the check); the repair rounds are the pipeline's own extra
             s["out"], pipe_state["status"], pipe_state["res"] = res["coeff"], res["status"], res
             return
         c.solve_batch_device(r, n_local, uni, mx, d_so, s["wp"], s["T"], s["bc"], s["out"], d_st)
