@@ -17,12 +17,12 @@ CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "kkt_exact.json")))
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-@pytest.mark.parametrize("variant", [0, 1, 8, 64])
+@pytest.mark.parametrize("variant", [0, 1, 4, 8])
 def test_golden_fixture_through_c_abi(gpu_ctx, case, variant):
     """Tolerance: 1e-10 relative to max|coef| per axis (float64 direct solve vs exact rationals);
     the north star's budget is 1e-5."""
     r, M = case["r"], case["M"]
-    if variant >= 8 and (M < 2 or (r == 4 and M > 12) or M == 11):
+    if variant >= 4 and (M < 2 or (r == 4 and M > 12) or M == 11):
         pytest.skip("no specialised instantiation for this M")
     gpu_ctx.set_variant(variant)
     # replicate into a small batch so that partial tiles and both lanes of a pair are exercised

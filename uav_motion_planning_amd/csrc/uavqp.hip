@@ -365,48 +365,80 @@ struct EvalArgs {
 template <int R>
 __global__ __launch_bounds__(256) void eval_kernel(EvalArgs a) {
     constexpr int NC = 2 * R;
+    // the 256 lanes of a block own 256 consecutive (trajectory, sample) rows = one contiguous piece of the output: the rows go
+    // through LDS (row stride 9 doubles: conflict-free) and leave as 16-byte-per-lane linear stores instead of nine 8-byte stores
+    // at a 72-byte lane stride
+    __shared__ __attribute__((aligned(16))) double s_o[256 * 9];
     const long long total = (long long)a.n_traj * a.n_samples;
     const int K = __popc(a.what & 7);
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(g / a.n_samples), s = (int)(g - (long long)b * a.n_samples);
-        int s0, M;
-        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
-        double* o = a.out + (size_t)g * K * 3;
-        if (M < 1) {
-            for (int k = 0; k < 3 * K; ++k) o[k] = 0.0;
-            continue;
-        }
-        const double* __restrict__ T = a.times + s0;
-        // segment search exactly as PolyTraj::evaluatePos (poly_traj.hpp:77-88)
-        double t = a.t0 + s * a.dt;
-        int idx = 0;
-        while (idx < M && t > T[idx] + 1e-4) {
-            t -= T[idx];
-            ++idx;
-        }
-        if (idx == M) {
-            --idx;
-            t = T[idx];
-        }
-        const double* __restrict__ c = a.coeff + (size_t)3 * NC * s0 + (size_t)idx * NC;
-        int k = 0;
+    const int tid = threadIdx.x;
+    for (long long g0 = (long long)blockIdx.x * 256; g0 < total; g0 += (long long)gridDim.x * 256) {
+        const long long g = g0 + tid;
+        double res[9];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (!((a.what >> d) & 1)) continue;
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const double* ca = c + (size_t)ax * NC * M;
-                double acc = 0.0;
-#pragma unroll
-                for (int j = NC - 1; j >= d; --j) {  // Horner on the d-th derivative
-                    double f = 1.0;
-                    for (int q = 0; q < d; ++q) f *= (double)(j - q);
-                    acc = fma(acc, t, f * ca[j]);
+        for (int k = 0; k < 9; ++k) res[k] = 0.0;
+        if (g < total) {
+            const int b = (int)(g / a.n_samples), s = (int)(g - (long long)b * a.n_samples);
+            int s0, M;
+            if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+            if (M >= 1) {
+                const double* __restrict__ T = a.times + s0;
+                // segment search exactly as PolyTraj::evaluatePos (poly_traj.hpp:77-88); written without an early exit: the same
+                // subtractions in the same order, but the loads of T[i] do not depend on the comparisons
+                double t = a.t0 + s * a.dt;
+                int idx = 0;
+                bool going = true;
+                double Tlast = 0.0;
+                for (int i = 0; i < M; ++i) {
+                    const double Ti = T[i];
+                    const bool adv = going & (t > Ti + 1e-4);
+                    t = adv ? t - Ti : t;
+                    idx += adv ? 1 : 0;
+                    going = adv;
+                    Tlast = Ti;
                 }
-                o[k * 3 + ax] = acc;
+                if (idx == M) {
+                    --idx;
+                    t = Tlast;
+                }
+                const double* __restrict__ c = a.coeff + (size_t)3 * NC * s0 + (size_t)idx * NC;
+                int k = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    if (!((a.what >> d) & 1)) continue;
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const double* ca = c + (size_t)ax * NC * M;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int j = NC - 1; j >= d; --j) {  // Horner on the d-th derivative
+                            double f = 1.0;
+                            for (int q = 0; q < d; ++q) f *= (double)(j - q);
+                            acc = fma(acc, t, f * ca[j]);
+                        }
+                        res[k * 3 + ax] = acc;
+                    }
+                    ++k;
+                }
             }
-            ++k;
         }
+        const int row = 3 * K;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            if (k < row) s_o[tid * row + k] = res[k];
+        __syncthreads();
+        const long long left = total - g0;
+        const int n_rows = left < 256 ? (int)left : 256;
+        const int n_d = n_rows * row;                          // doubles of this block's piece (even: 256 rows, or handled below)
+        double* o = a.out + (size_t)g0 * row;
+        const bool al16 = ((reinterpret_cast<uintptr_t>(o)) & 15u) == 0;
+        if (al16) {
+            for (int i = tid; 2 * i + 1 < n_d; i += 256) *reinterpret_cast<double2*>(o + 2 * i) = *reinterpret_cast<const double2*>(s_o + 2 * i);
+            if ((n_d & 1) && tid == 0) o[n_d - 1] = s_o[n_d - 1];
+        } else {
+            for (int i = tid; i < n_d; i += 256) o[i] = s_o[i];
+        }
+        __syncthreads();
     }
 }
 
