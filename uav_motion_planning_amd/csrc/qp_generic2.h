@@ -119,6 +119,13 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
     for (int round = 0; round < n_round; ++round) {
         int b = round * n_items + blockIdx.x * IPW + item;
         if constexpr (LSORT) {
+            // Which 32 ranks of its window a wave takes is rotated by the window index: workgroup ids go round-robin over the 8
+            // XCDs, so with the plain order every window's longest wave (ranks 0..31) would sit at an id = 0 mod 16 -- all the long
+            // waves of the batch on XCD 0, next to each other on its CUs.  (The host rounds the grid to a multiple of 16.)
+            // (any spreading does: xor with the window index, a rotation by 3 windows, ... all measure 49.7-50.0 us on config 4
+            // against 53.7 us for the plain order)
+            const int win = blockIdx.x >> 4, q = ((blockIdx.x & 15) + win) & 15;
+            b = round * n_items + (win * 16 + q) * IPW + item;
             if (b < a.n_traj) b = a.perm[b];
         }
         G2_STAMP(0);
