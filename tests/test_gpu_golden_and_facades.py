@@ -58,6 +58,27 @@ def test_python_minimum_control_mirror(oracle):
     assert np.all(opt.getCoef1d() == 0)
 
 
+@pytest.mark.parametrize("order", [3, 4])
+def test_single_axis_latency_path_from_one_to_many_segments(oracle, order):
+    """uavqp_solve_axis_host runs over a pinned page mapped into the device (no copy calls): the page grows with the problem, every
+    kernel family reads its inputs from host memory there -- 1 segment (no interior knot), the specialised shapes, the lane-pair
+    kernel (13, 40 segments) and the one-lane kernel (100 segments) -- and a failed call leaves the previous result in place."""
+    opt = U.MinimumControl(order=order)
+    rng = np.random.default_rng(order)
+    for M in (1, 2, 7, 8, 13, 40, 100, 3):
+        pos = np.cumsum(rng.uniform(-1.0, 1.0, size=M + 1))
+        T = rng.uniform(0.5, 2.0, size=M)
+        bv, ba = rng.uniform(-1, 1, size=2), rng.uniform(-1, 1, size=2)
+        assert opt.solve(pos, bv, ba, T) is True
+        c = opt.getCoef1d()
+        bcs = np.array([bv[0], ba[0]] + ([0.0] if order == 4 else []))
+        bce = np.array([bv[1], ba[1]] + ([0.0] if order == 4 else []))
+        ref = oracle.solve_exact(order, pos, bcs, bce, T)
+        assert c.shape == (2 * order * M,) and np.max(np.abs(c - ref)) < 1e-8 * np.max(np.abs(ref)), M
+    prev = opt.getCoef1d()
+    assert opt.solve(pos, bv, ba, np.full(3, np.nan)) is False and np.array_equal(opt.getCoef1d(), prev)
+
+
 def test_python_traj_optimizer_batch_facade(oracle):
     b = W.ragged_batch(4, 40, 4, m_lo=2, m_hi=12)
     so = b["seg_offsets"]
