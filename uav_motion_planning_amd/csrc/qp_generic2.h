@@ -10,13 +10,16 @@
 //
 // Memory: a lane that walks its own trajectory with 8-byte loads pays one HBM/L2 round trip per knot (and the compiler's
 // s_waitcnt vmcnt(0) at the loop back-edge adds the round trip of the stores in flight): measured 3.6 us per own segment with
-// ALL stores compiled out.  So the wave first copies the waypoints and durations of its 32 trajectories into LDS with LDS-DMA
-// (global_load_lds_dword: no VGPRs, all copies in flight at once, contiguous runs per trajectory), and the sweeps read LDS.
-// Durations are validated where the forward sweep reads them.  The forward-sweep state (E_j, h_j of the own knots) goes through
-// the HBM workspace [wave][own knot][field][lane]; the forward loop has no vector-memory load, so its stores are never waited
-// on, and the backward loop consumes the record it prefetched at the END of the trip that issued the loads (wait counted in
-// the same basic block: vmcnt(number of coefficient stores issued since), not vmcnt(0)).
-// Ragged batches are dealt to the lane PAIRS by segment count inside windows (window_sort_kernel, 32 trajectories per wave).
+// ALL stores compiled out.  So the wave first copies the waypoints and durations of its 32 trajectories into LDS -- 8 lanes per
+// trajectory, 16 bytes per lane, every load in flight before the first LDS write (LDS-DMA was tried first: one copy instruction
+// per trajectory and run costs ~270 cycles of issue each) -- and the sweeps read LDS.  Durations are validated where the forward
+// sweep reads them.  The forward-sweep state (E_j, h_j of the own knots) goes through the HBM workspace
+// [wave][own knot][field pair][lane]; the forward loop has no vector-memory load, so its stores are never waited on; the
+// backward loop alternates between two register sets for the records, re-loads a set two trips ahead and retires the re-loads
+// in the basic block that follows the stores they must not wait for (vmcnt(N) past the stores, not vmcnt(0)).  Coefficients
+// leave through LDS as 64-byte (r = 3: 48-byte) chunks, 4 (3) lanes each, spelled as GLOBAL stores.
+// Ragged batches are dealt to the lane PAIRS by segment count inside windows (window_sort_kernel, 32 trajectories per wave);
+// the rank ranges are rotated by the window index so that the long waves spread over the XCDs.  DESIGN.md section 5.2.
 #pragma once
 #include "qp_device.h"
 
