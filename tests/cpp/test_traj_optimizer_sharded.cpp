@@ -1,0 +1,62 @@
+// The C++ batch facade's multi-GPU path on one GPU (world size 1: RCCL communicator of one rank) against its own host-pointer
+// solve: same coefficients, same statuses; with a corridor too.  Exercises uavqp_comm_unique_id / uavqp_comm_create /
+// uavqp_shard_bounds_ragged / uavqp_solve_*_batch_device on views / uavqp_allgather_coeffs / _status from C++, as a planner
+// process per GPU would call them.  Built and run by tests/test_gpu_comm.py.
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "traj_optimizer.h"
+
+int main() {
+    const int r = 4, n = 37;
+    std::mt19937_64 rng(20260925);
+    std::uniform_real_distribution<double> u(-1.0, 1.0), t(0.4, 2.0);
+    std::uniform_int_distribution<int> mm(1, 14);
+    std::vector<int32_t> wp_off(n + 1, 0);
+    for (int b = 0; b < n; ++b) wp_off[b + 1] = wp_off[b] + mm(rng) + 1;
+    const int rows = wp_off[n], segs = rows - n;
+    std::vector<double> xyz(3 * rows), T(segs), bc(static_cast<size_t>(n) * 2 * (r - 1) * 3), lo(3 * rows), hi(3 * rows);
+    for (int b = 0; b < n; ++b) {
+        double p[3] = {u(rng) * 10, u(rng) * 5, 1.5 + 0.5 * u(rng)};
+        for (int i = wp_off[b]; i < wp_off[b + 1]; ++i)
+            for (int a = 0; a < 3; ++a) {
+                p[a] += 1.5 * u(rng);
+                xyz[3 * i + a] = p[a];
+                lo[3 * i + a] = p[a] - 0.4;
+                hi[3 * i + a] = p[a] + 0.4;
+            }
+    }
+    for (auto& x : T) x = t(rng);
+    for (auto& x : bc) x = 0.3 * u(rng);
+
+    int bad = 0;
+    for (int corridor = 0; corridor < 2; ++corridor) {
+        traj_optimization::TrajOptimizer host(r), shard(r);
+        for (auto* o : {&host, &shard}) {
+            o->setWaypoints(xyz.data(), wp_off.data(), n);
+            o->setTimeAllocation(T.data());
+            o->setBoundary(bc.data());
+            if (corridor) o->setCorridor(lo.data(), hi.data());
+        }
+        uavqp_settings st;
+        uavqp_default_settings(&st);
+        st.max_iter = 1000;   // minimum_control.cpp:162
+        if (!shard.setSettings(st)) { std::printf("setSettings failed\n"); return 2; }
+        unsigned char id[UAVQP_UNIQUE_ID_BYTES];
+        if (!traj_optimization::TrajOptimizer::uniqueId(id) || !shard.initDistributed(0, 1, id)) { std::printf("comm init failed\n"); return 2; }
+        if (!host.solve() || !shard.solveSharded()) { std::printf("solve failed (corridor %d)\n", corridor); return 3; }
+        const size_t nc = static_cast<size_t>(3) * 2 * r * segs;
+        double worst = 0.0, scale = 0.0;
+        for (size_t i = 0; i < nc; ++i) {
+            worst = std::fmax(worst, std::fabs(host.getPolyCoeff()[i] - shard.getPolyCoeff()[i]));
+            scale = std::fmax(scale, std::fabs(host.getPolyCoeff()[i]));
+        }
+        std::printf("corridor %d: max |host - sharded| = %.3e (scale %.3e)\n", corridor, worst, scale);
+        if (!(worst <= 1e-12 * scale)) ++bad;
+        for (int b = 0; b < n; ++b) if (host.status()[b] != shard.status()[b]) ++bad;
+    }
+    std::printf(bad ? "FAILED\n" : "OK\n");
+    return bad ? 1 : 0;
+}

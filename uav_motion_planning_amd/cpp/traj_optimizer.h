@@ -6,11 +6,25 @@
 #ifndef UAVQP_TRAJ_OPTIMIZER_H_
 #define UAVQP_TRAJ_OPTIMIZER_H_
 
+#include <algorithm>
 #include <cstdint>
 #include <iostream>
 #include <vector>
 
 #include "../../include/uavqp.h"
+
+// The sharded (multi-GPU) entry keeps its buffers on the device and therefore needs the HIP runtime API for allocation and the
+// host <-> device copies at its two ends; everything else here is plain C ABI.  A planner that runs one process (or thread) per GPU
+// has it anyway.
+#if defined(__has_include)
+#if __has_include(<hip/hip_runtime_api.h>)
+#ifndef __HIP_PLATFORM_AMD__
+#define __HIP_PLATFORM_AMD__ 1
+#endif
+#include <hip/hip_runtime_api.h>
+#define UAVQP_TRAJ_OPTIMIZER_HAS_HIP 1
+#endif
+#endif
 
 namespace traj_optimization {
 
@@ -44,13 +58,17 @@ class TrajOptimizer {
         }
     }
 
+    // Solver settings (include/uavqp.h: the reference's warm_start / eps_prim_inf / max_iter, minimum_control.cpp:160-162, and the
+    // library's own knobs).  Applied to the context now, or when it is created.
+    bool setSettings(const uavqp_settings& st) {
+        settings_ = st;
+        have_settings_ = true;
+        return !ctx_ || uavqp_set_settings(ctx_, &settings_) == UAVQP_OK;
+    }
+
     bool solve() {
         if (n_traj_ <= 0 || T_.size() != static_cast<size_t>(seg_offsets_[n_traj_])) return false;
-        if (!ctx_ && uavqp_create(&ctx_, device_) != UAVQP_OK) {
-            std::cout << "solver init failed! (" << uavqp_last_error() << ")" << std::endl;
-            ctx_ = nullptr;
-            return false;
-        }
+        if (!ensureContext()) return false;
         if (bc_.empty()) bc_.assign(static_cast<size_t>(n_traj_) * 2 * (order_ - 1) * 3, 0.0);
         coef_.assign(static_cast<size_t>(3) * 2 * order_ * seg_offsets_[n_traj_], 0.0);
         status_.assign(n_traj_, 0);
@@ -75,8 +93,104 @@ class TrajOptimizer {
     int segOffset(int traj) const { return seg_offsets_[traj]; }
     const std::vector<int32_t>& status() const { return status_; }
 
+    // ---- multi-GPU: one process (or thread) per GPU, every rank holds the whole batch description, solves its contiguous shard
+    // (balanced by segment count) on its device and ends with ALL coefficients: uavqp_shard_bounds_ragged, uavqp_comm_create,
+    // uavqp_solve_*_batch_device on views, uavqp_allgather_coeffs / _status (RCCL over xGMI).  Rank 0 draws the id and ships it to
+    // the others with whatever the program has (MPI_Bcast, a socket, a file).
+    static bool uniqueId(unsigned char* id_out /* UAVQP_UNIQUE_ID_BYTES */) { return uavqp_comm_unique_id(id_out) == UAVQP_OK; }
+    bool initDistributed(int rank, int world, const unsigned char* unique_id) {
+        if (!ensureContext()) return false;
+        rank_ = rank;
+        world_ = world;
+        if (uavqp_comm_create(ctx_, rank, world, unique_id) != UAVQP_OK) {
+            std::cout << "solver init failed! (" << uavqp_last_error() << ")" << std::endl;
+            return false;
+        }
+        return true;
+    }
+#ifdef UAVQP_TRAJ_OPTIMIZER_HAS_HIP
+    bool solveSharded() {
+        if (n_traj_ <= 0 || world_ < 1 || !ctx_ || T_.size() != static_cast<size_t>(seg_offsets_[n_traj_])) return false;
+        if (bc_.empty()) bc_.assign(static_cast<size_t>(n_traj_) * 2 * (order_ - 1) * 3, 0.0);
+        std::vector<int32_t> bounds(world_ + 1);
+        if (uavqp_shard_bounds_ragged(seg_offsets_.data(), n_traj_, world_, bounds.data()) != UAVQP_OK) return false;
+        const int b0 = bounds[rank_], b1 = bounds[rank_ + 1], nl = b1 - b0;
+        const int32_t s0 = seg_offsets_[b0], s1 = seg_offsets_[b1];
+        const size_t nc = static_cast<size_t>(3) * 2 * order_, tot = static_cast<size_t>(seg_offsets_[n_traj_]);
+        std::vector<int32_t> so_l(nl + 1);
+        int mmax = 1;
+        for (int b = 0; b <= nl; ++b) so_l[b] = seg_offsets_[b0 + b] - s0;
+        for (int b = 0; b < nl; ++b) mmax = std::max(mmax, so_l[b + 1] - so_l[b]);
+        std::vector<int64_t> c_counts(world_), t_counts(world_);
+        size_t c_off = 0;
+        for (int g = 0; g < world_; ++g) {
+            c_counts[g] = static_cast<int64_t>(nc) * (seg_offsets_[bounds[g + 1]] - seg_offsets_[bounds[g]]);
+            t_counts[g] = bounds[g + 1] - bounds[g];
+            if (g < rank_) c_off += static_cast<size_t>(c_counts[g]);
+        }
+        const size_t n_wp = static_cast<size_t>(3) * ((s1 - s0) + nl), n_t = static_cast<size_t>(s1 - s0), n_bc = static_cast<size_t>(nl) * 2 * (order_ - 1) * 3;
+        int32_t *d_so = nullptr, *d_st = nullptr;
+        double *d_wp = nullptr, *d_T = nullptr, *d_bc = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_coef = nullptr;
+        bool ok = hipSetDevice(device_) == hipSuccess;
+        auto up = [&](void** d, const void* h, size_t bytes) {
+            ok = ok && hipMalloc(d, bytes ? bytes : 8) == hipSuccess && (bytes == 0 || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess);
+        };
+        up(reinterpret_cast<void**>(&d_so), so_l.data(), sizeof(int32_t) * (nl + 1));
+        up(reinterpret_cast<void**>(&d_wp), wp_.data() + static_cast<size_t>(3) * (s0 + b0), sizeof(double) * n_wp);
+        up(reinterpret_cast<void**>(&d_T), T_.data() + s0, sizeof(double) * n_t);
+        up(reinterpret_cast<void**>(&d_bc), bc_.data() + static_cast<size_t>(b0) * 2 * (order_ - 1) * 3, sizeof(double) * n_bc);
+        if (!lo_.empty()) {
+            up(reinterpret_cast<void**>(&d_lo), lo_.data() + static_cast<size_t>(3) * (s0 + b0), sizeof(double) * n_wp);
+            up(reinterpret_cast<void**>(&d_hi), hi_.data() + static_cast<size_t>(3) * (s0 + b0), sizeof(double) * n_wp);
+        }
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&d_coef), sizeof(double) * nc * tot) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(int32_t) * n_traj_) == hipSuccess;
+        int rc = ok ? UAVQP_OK : UAVQP_ERR_ALLOC;
+        if (ok && nl > 0) {   // this rank's shard, written straight into its slice of the full buffers
+            rc = lo_.empty()
+                ? uavqp_solve_batch_device(ctx_, order_, nl, 0, mmax, d_so, d_wp, d_T, d_bc, d_coef + c_off, d_st + b0)
+                : uavqp_solve_corridor_batch_device(ctx_, order_, nl, 0, mmax, d_so, d_wp, d_T, d_bc, d_lo, d_hi, d_coef + c_off, d_st + b0, nullptr);
+        }
+        if (rc == UAVQP_OK) rc = uavqp_allgather_coeffs(ctx_, d_coef + c_off, c_counts.data(), d_coef);
+        if (rc == UAVQP_OK) rc = uavqp_allgather_status(ctx_, d_st + b0, t_counts.data(), d_st);
+        if (rc == UAVQP_OK) rc = uavqp_synchronize(ctx_);
+        coef_.assign(nc * tot, 0.0);
+        status_.assign(n_traj_, 0);
+        if (rc == UAVQP_OK) {
+            ok = hipMemcpy(coef_.data(), d_coef, sizeof(double) * nc * tot, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(status_.data(), d_st, sizeof(int32_t) * n_traj_, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        for (void* p : {static_cast<void*>(d_so), static_cast<void*>(d_st), static_cast<void*>(d_wp), static_cast<void*>(d_T), static_cast<void*>(d_bc),
+                        static_cast<void*>(d_lo), static_cast<void*>(d_hi), static_cast<void*>(d_coef)})
+            if (p) (void)hipFree(p);
+        if (rc != UAVQP_OK || !ok) {
+            std::cout << "solver solve failed! (" << uavqp_last_error() << ")" << std::endl;
+            return false;
+        }
+        for (int32_t s : status_) if (s != UAVQP_SOLVED) return false;
+        return true;
+    }
+#endif
+
   private:
+    bool ensureContext() {
+        if (ctx_) return true;
+        if (uavqp_create(&ctx_, device_) != UAVQP_OK) {
+            std::cout << "solver init failed! (" << uavqp_last_error() << ")" << std::endl;
+            ctx_ = nullptr;
+            return false;
+        }
+        if (have_settings_ && uavqp_set_settings(ctx_, &settings_) != UAVQP_OK) {
+            std::cout << "solver init failed! (" << uavqp_last_error() << ")" << std::endl;
+            return false;
+        }
+        return true;
+    }
+
     int order_, device_, n_traj_ = 0;
+    int rank_ = 0, world_ = 1;
+    bool have_settings_ = false;
+    uavqp_settings settings_{};
     uavqp_ctx* ctx_ = nullptr;
     std::vector<int32_t> seg_offsets_, status_;
     std::vector<double> wp_, T_, bc_, coef_, lo_, hi_;
