@@ -212,7 +212,8 @@ int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  * degenerate problem ends with UAVQP_MAX_ITER_REACHED and the minimiser of the last regular working set (which need NOT satisfy
  * the remaining rows): either at uavqp_settings.max_iter (default 12 M (1 + rows_per_segment) + 30), or as soon as a row of the
  * working set is no longer on its bound after the solve -- the working set's KKT system has become singular to working
- * precision (rows that no free unknown can move, e.g. a position sample right behind the fixed start state).  M <= 63.
+ * precision (rows that no free unknown can move, e.g. a position sample right behind the fixed start state).  A single-segment
+ * trajectory has no free unknown at all: its rows are only checked (violated -> UAVQP_MAX_ITER_REACHED).  M <= 63.
  * Asynchronous. */
 int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                   const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
@@ -220,6 +221,14 @@ int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform
                                   const double* d_row_tau, const int32_t* d_row_deriv, const double* d_row_lo,
                                   const double* d_row_hi, double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
                                   uint64_t* d_active_out);
+/* The same solve from HOST pointers (staged through device memory, synchronous; a trajectory that is not solved comes back as
+ * zeros): what a caller of the reference's solver interface has -- it hands its rows to OSQP from host memory,
+ * minimum_control.cpp:164-170. */
+int uavqp_solve_rows_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                const int32_t* seg_offsets, const double* waypoints, const double* times, const double* bc,
+                                const double* corr_lo, const double* corr_hi, int rows_per_segment, const double* row_tau,
+                                const int32_t* row_deriv, const double* row_lo, const double* row_hi, double* coeff_out,
+                                int32_t* status_out, int32_t* iters_out);
 
 /* Time re-allocation step of the outer loop of BASELINE config 5 (north-star extension; the reference uses a
  * constant 1.0 s per segment, test_minimum_jerk.cpp:65-71, and has no such loop -- nothing to mirror, parity is

@@ -57,6 +57,54 @@ int main() {
         if (!(worst <= 1e-12 * scale)) ++bad;
         for (int b = 0; b < n; ++b) if (host.status()[b] != shard.status()[b]) ++bad;
     }
+    // general rows through the facade (setRows -> uavqp_solve_rows_batch_host): a velocity limit at mid-segment that binds somewhere,
+    // checked on the emitted polynomials
+    {
+        traj_optimization::TrajOptimizer rows(r);
+        rows.setWaypoints(xyz.data(), wp_off.data(), n);
+        rows.setTimeAllocation(T.data());
+        rows.setBoundary(bc.data());
+        std::vector<double> tau(segs, 0.5), rlo(3 * segs), rhi(3 * segs);
+        std::vector<int32_t> drv(segs, 1);
+        traj_optimization::TrajOptimizer free_(r);
+        free_.setWaypoints(xyz.data(), wp_off.data(), n);
+        free_.setTimeAllocation(T.data());
+        free_.setBoundary(bc.data());
+        if (!free_.solve()) { std::printf("plain solve failed\n"); return 3; }
+        auto vel_mid = [&](const traj_optimization::TrajOptimizer& o, int b, int a, int k, double Tk) {
+            const double* c = o.getPolyCoeff(b, a) + 2 * r * k;
+            double v = 0.0, tp = 1.0;
+            for (int q = 1; q < 2 * r; ++q) { v += q * c[q] * tp; tp *= 0.5 * Tk; }
+            return v;
+        };
+        int seg = 0, n_bind = 0;
+        for (int b = 0; b < n; ++b)
+            for (int k = 0; k < wp_off[b + 1] - wp_off[b] - 1; ++k, ++seg)
+                for (int a = 0; a < 3; ++a) {
+                    const double v = vel_mid(free_, b, a, k, T[seg]);
+                    const double lim = 0.85 * std::fabs(v) + 0.2;     // 15 % below the unconstrained mid-segment speed (plus slack)
+                    rlo[3 * seg + a] = -lim;
+                    rhi[3 * seg + a] = lim;
+                }
+        rows.setRows(1, tau.data(), drv.data(), rlo.data(), rhi.data());
+        const bool all_solved = rows.solve();
+        seg = 0;
+        int n_solved = 0;
+        double worst_over = -1.0;
+        for (int b = 0; b < n; ++b) {
+            const bool solved = rows.status()[b] == UAVQP_SOLVED;
+            n_solved += solved;
+            for (int k = 0; k < wp_off[b + 1] - wp_off[b] - 1; ++k, ++seg)
+                for (int a = 0; a < 3 && solved; ++a) {
+                    const double v = vel_mid(rows, b, a, k, T[seg]);
+                    const double over = std::fabs(v) - rhi[3 * seg + a];
+                    worst_over = std::fmax(worst_over, over / (1.0 + rhi[3 * seg + a]));
+                    if (std::fabs(over) < 1e-7 * (1.0 + rhi[3 * seg + a])) ++n_bind;
+                }
+        }
+        std::printf("rows: %d of %d solved (all %d), %d binding velocity rows, worst relative excess %.3e\n", n_solved, n, (int)all_solved, n_bind, worst_over);
+        if (n_solved < n / 2 || n_bind < 5 || worst_over > 1e-7) ++bad;
+    }
     std::printf(bad ? "FAILED\n" : "OK\n");
     return bad ? 1 : 0;
 }

@@ -211,3 +211,50 @@ def test_conflicting_rows_are_reported_not_solved(gpu_ctx):
     g = got.reshape(n, 3, M, 2 * r)
     assert np.max(np.abs(g[good] - c[good])) < 1e-9 * np.max(np.abs(c))         # their rows are slack: the equality solution
     assert it[bad].max() < 20                                                    # detected at once, not at the iteration cap
+
+
+def test_rows_from_host_pointers_equal_the_device_entry(gpu_ctx):
+    """uavqp_solve_rows_batch_host = the device entry behind staging copies: same coefficients, statuses and iteration counts;
+    uniform and ragged, with and without knot boxes."""
+    for r, ragged, boxes, K in ((3, False, True, 2), (4, True, False, 1), (4, True, True, 2)):
+        n = 30
+        b = W.ragged_batch(4, n, r, m_lo=2, m_hi=9) if ragged else W.uniform_batch(3, n, 7, r, time_mode="distance")
+        so = np.asarray(b["seg_offsets"])
+        S = int(so[-1])
+        wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+        lo = hi = None
+        if boxes:
+            lo, hi = wp - 0.4, wp + 0.4
+        rng = np.random.default_rng(7 + r)
+        tau = rng.uniform(0.2, 0.8, size=(S, K))
+        drv = np.tile(np.array([1, 0])[:K], (S, 1))
+        T = np.asarray(b["times"]).reshape(-1)
+        seg_traj = np.repeat(np.arange(n), np.diff(so))
+        chord = (wp[np.arange(S) + seg_traj + 1] - wp[np.arange(S) + seg_traj]) / T[:, None]
+        rlo, rhi = np.full((S, K, 3), -BIG), np.full((S, K, 3), BIG)
+        lim = np.abs(chord).max(axis=1, keepdims=True) * 1.3 + 0.3
+        rlo[:, 0], rhi[:, 0] = -lim, lim
+        uni = 0 if ragged else 7
+        dev_c, dev_st, dev_it, _ = run_rows(gpu_ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, uni)
+        c, st, it = gpu_ctx.solve_rows_batch_host(r, None if uni else so, wp, T, b["bc"], lo, hi, K, tau, drv, rlo, rhi, uniform_segments=uni)
+        assert np.array_equal(st, dev_st) and np.array_equal(it, dev_it)
+        solved = np.repeat(st == U.UAVQP_SOLVED, np.diff(so) * 6 * r)
+        assert np.array_equal(c[solved], dev_c[solved]) and solved.mean() > 0.8
+
+
+def test_single_segment_rows_are_checked(gpu_ctx):
+    """M = 1: the polynomial is fixed by the boundary data, its rows cannot be enforced, only checked -- a violated one reports
+    UAVQP_MAX_ITER_REACHED (infeasible), a satisfied one UAVQP_SOLVED; the coefficients are the equality solution either way."""
+    r, n, K = 4, 6, 1
+    b = W.uniform_batch(3, n, 1, r, time_mode="reference")
+    eq, _ = gpu_ctx.solve_batch_host(r, None, b["waypoints"], b["times"], b["bc"], uniform_segments=1)
+    c = eq.reshape(n, 3, 2 * r)
+    t = 0.5 * b["times"][:, 0]
+    v_mid = np.stack([sum(q * c[:, ax, q] * t ** (q - 1) for q in range(1, 2 * r)) for ax in range(3)], axis=1)
+    tau, drv = np.full((n, K), 0.5), np.ones((n, K), dtype=np.int32)
+    rlo, rhi = np.full((n, K, 3), -BIG), np.full((n, K, 3), BIG)
+    rhi[:, 0] = v_mid + 0.1
+    rhi[[2, 4], 0] = v_mid[[2, 4]] - 0.1                      # violated by the only possible trajectory
+    got, st, it, act = run_rows(gpu_ctx, r, b, None, None, K, tau, drv, rlo, rhi, 1)
+    assert list(st) == [U.UAVQP_SOLVED, U.UAVQP_SOLVED, U.UAVQP_MAX_ITER_REACHED, U.UAVQP_SOLVED, U.UAVQP_MAX_ITER_REACHED, U.UAVQP_SOLVED]
+    assert np.max(np.abs(got - eq)) < 1e-12 * np.max(np.abs(eq))

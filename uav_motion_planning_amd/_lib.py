@@ -43,6 +43,7 @@ SYMBOLS = (
     "uavqp_solve_corridor_batch_host",
     "uavqp_solve_corridor_warm_device",
     "uavqp_solve_rows_batch_device",
+    "uavqp_solve_rows_batch_host",
     "uavqp_time_reallocate_device",
     "uavqp_eval_batch_device",
     "uavqp_traj_length_device",
@@ -127,6 +128,7 @@ def lib():
     L.uavqp_solve_corridor_warm_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip, vp, i32]
     L.uavqp_solve_corridor_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, dp, ip, ip]
     L.uavqp_solve_rows_batch_device.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, i32, dp, ip, dp, dp, dp, ip, ip, vp]
+    L.uavqp_solve_rows_batch_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, dp, i32, dp, ip, dp, dp, dp, ip, ip]
     L.uavqp_time_reallocate_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, ctypes.c_double, ctypes.c_double, i32, ctypes.c_double, ip]
     L.uavqp_eval_batch_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, i32, dp]
     L.uavqp_traj_length_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, ctypes.c_double, dp, dp, ip]

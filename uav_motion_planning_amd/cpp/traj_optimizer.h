@@ -58,6 +58,20 @@ class TrajOptimizer {
         }
     }
 
+    // Optional general inequality rows (north-star extension; what the reference's solver interface accepts,
+    // minimum_control.cpp:146-147,164-180): per segment and slot j < rows_per_segment (1 or 2) a row
+    // lo <= p^(deriv)(tau * T_segment) <= hi per axis.  tau / deriv: [sum_b M_b][K], lo / hi: [sum_b M_b][K][3]; deriv < 0 = unused
+    // slot.  Needs setTimeAllocation first (sizes).  rows_per_segment = 0 removes them.
+    void setRows(int rows_per_segment, const double* tau, const int32_t* deriv, const double* lo, const double* hi) {
+        rows_k_ = rows_per_segment;
+        if (rows_k_ <= 0) { rows_k_ = 0; return; }
+        const size_t n = T_.size() * static_cast<size_t>(rows_k_);
+        row_tau_.assign(tau, tau + n);
+        row_deriv_.assign(deriv, deriv + n);
+        row_lo_.assign(lo, lo + 3 * n);
+        row_hi_.assign(hi, hi + 3 * n);
+    }
+
     // Solver settings (include/uavqp.h: the reference's warm_start / eps_prim_inf / max_iter, minimum_control.cpp:160-162, and the
     // library's own knobs).  Applied to the context now, or when it is created.
     bool setSettings(const uavqp_settings& st) {
@@ -72,11 +86,16 @@ class TrajOptimizer {
         if (bc_.empty()) bc_.assign(static_cast<size_t>(n_traj_) * 2 * (order_ - 1) * 3, 0.0);
         coef_.assign(static_cast<size_t>(3) * 2 * order_ * seg_offsets_[n_traj_], 0.0);
         status_.assign(n_traj_, 0);
-        const int rc = lo_.empty()
-            ? uavqp_solve_batch_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(),
-                                     coef_.data(), status_.data())
-            : uavqp_solve_corridor_batch_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(),
-                                              lo_.data(), hi_.data(), coef_.data(), status_.data(), nullptr);
+        int rc;
+        if (rows_k_ > 0)
+            rc = uavqp_solve_rows_batch_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(),
+                                             lo_.empty() ? nullptr : lo_.data(), lo_.empty() ? nullptr : hi_.data(), rows_k_, row_tau_.data(),
+                                             row_deriv_.data(), row_lo_.data(), row_hi_.data(), coef_.data(), status_.data(), nullptr);
+        else if (lo_.empty())
+            rc = uavqp_solve_batch_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(), coef_.data(), status_.data());
+        else
+            rc = uavqp_solve_corridor_batch_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(),
+                                                 lo_.data(), hi_.data(), coef_.data(), status_.data(), nullptr);
         if (rc != UAVQP_OK) {
             std::cout << "solver solve failed! (" << uavqp_last_error() << ")" << std::endl;
             return false;
@@ -193,7 +212,9 @@ class TrajOptimizer {
     uavqp_settings settings_{};
     uavqp_ctx* ctx_ = nullptr;
     std::vector<int32_t> seg_offsets_, status_;
-    std::vector<double> wp_, T_, bc_, coef_, lo_, hi_;
+    std::vector<double> wp_, T_, bc_, coef_, lo_, hi_, row_tau_, row_lo_, row_hi_;
+    std::vector<int32_t> row_deriv_;
+    int rows_k_ = 0;
 };
 
 }  // namespace traj_optimization

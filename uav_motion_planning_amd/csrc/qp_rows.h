@@ -207,8 +207,25 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
 
         // ---- dual active-set iterations
         it = 0;
-        done = (M == 1);   // a single segment has no free knot: nothing to decide (its rows cannot be influenced and are ignored)
+        done = (M == 1);   // a single segment has no free knot: nothing to decide -- its rows can only be CHECKED
         capped = false;
+        if (M == 1) {
+            // the polynomial is fixed by the boundary data; a row it violates makes the problem infeasible (reported like every
+            // other infeasible problem: UAVQP_MAX_ITER_REACHED, the trajectory itself is still emitted)
+            bool viol = false;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (!(rused[j] & 1ull)) continue;
+                double gl[R], gr[R];
+                row_functional<R>(T[0], rta(0, j), rdv(0, j), gl, gr);
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < R; ++c) v += gl[c] * x0[c] + gr[c] * xM[c];
+                const double l = rlo(0, j), h = rhi(0, j);
+                viol = viol || (l - v > 1e-9 * (1.0 + fabs(l))) || (v - h > 1e-9 * (1.0 + fabs(h)));
+            }
+            capped = viol;
+        }
         // what the next backward sweep does to the stored multipliers: lam_cur <- lam_cur + tpend (lam_new - lam_cur) for the
         // constraints in the masks of the PREVIOUS solve (ppin, pract), 0 for a constraint that has just joined
         tpend = 1.0;

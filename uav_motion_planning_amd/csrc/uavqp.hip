@@ -1532,6 +1532,83 @@ extern "C" int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj
     return UAVQP_OK;
 }
 
+extern "C" int uavqp_solve_rows_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                           const int32_t* seg_offsets, const double* waypoints, const double* times, const double* bc,
+                                           const double* corr_lo, const double* corr_hi, int rows_per_segment, const double* row_tau,
+                                           const int32_t* row_deriv, const double* row_lo, const double* row_hi, double* coeff_out,
+                                           int32_t* status_out, int32_t* iters_out) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0 || (rows_per_segment != 1 && rows_per_segment != 2))
+        return UAVQP_ERR_INVALID_ARG;
+    if (n_traj == 0) return UAVQP_OK;
+    if (!waypoints || !times || !bc || !coeff_out || !row_tau || !row_deriv || !row_lo || !row_hi) return UAVQP_ERR_INVALID_ARG;
+    if ((corr_lo == nullptr) != (corr_hi == nullptr)) return UAVQP_ERR_INVALID_ARG;
+    if (uniform_segments == 0 && !seg_offsets) return UAVQP_ERR_INVALID_ARG;
+    long long total_seg = 0;
+    int Mmax = uniform_segments;
+    if (uniform_segments > 0) total_seg = (long long)uniform_segments * n_traj;
+    else {
+        if (seg_offsets[0] != 0) return UAVQP_ERR_INVALID_ARG;
+        for (int b = 0; b < n_traj; ++b) {
+            const int M = seg_offsets[b + 1] - seg_offsets[b];
+            if (M < 0) return UAVQP_ERR_INVALID_ARG;
+            if (M > Mmax) Mmax = M;
+        }
+        total_seg = seg_offsets[n_traj];
+        if (max_segments > 0 && max_segments < Mmax) Mmax = max_segments;
+        if (Mmax < 1) Mmax = 1;
+    }
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    const int K = rows_per_segment;
+    const size_t n_wp = 3 * (size_t)(total_seg + n_traj), n_row = (size_t)total_seg * K;
+    const size_t b_off = uniform_segments > 0 ? 0 : align256(sizeof(int32_t) * (size_t)(n_traj + 1));
+    const size_t b_wp = align256(sizeof(double) * n_wp);
+    const size_t b_t = align256(sizeof(double) * (size_t)total_seg);
+    const size_t b_bc = align256(sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3);
+    const size_t b_rt = align256(sizeof(double) * n_row), b_rd = align256(sizeof(int32_t) * n_row), b_rb = align256(sizeof(double) * 3 * n_row);
+    const size_t b_out = align256(sizeof(double) * 3 * 2 * r * (size_t)total_seg);
+    const size_t b_st = align256(sizeof(int32_t) * (size_t)n_traj);
+    int rc = ensure_stage(ctx, b_off + 3 * b_wp + b_t + b_bc + b_rt + b_rd + 2 * b_rb + b_out + 2 * b_st);
+    if (rc != UAVQP_OK) return rc;
+    char* p = (char*)ctx->d_stage;
+    int32_t* d_off = uniform_segments > 0 ? nullptr : (int32_t*)p; p += b_off;
+    double* d_wp = (double*)p; p += b_wp;
+    double* d_lo = (double*)p; p += b_wp;
+    double* d_hi = (double*)p; p += b_wp;
+    double* d_t = (double*)p; p += b_t;
+    double* d_bc = (double*)p; p += b_bc;
+    double* d_rt = (double*)p; p += b_rt;
+    int32_t* d_rd = (int32_t*)p; p += b_rd;
+    double* d_rl = (double*)p; p += b_rb;
+    double* d_rh = (double*)p; p += b_rb;
+    double* d_out = (double*)p; p += b_out;
+    int32_t* d_st = (int32_t*)p; p += b_st;
+    int32_t* d_it = (int32_t*)p;
+    hipStream_t s = ctx->stream;
+    if (d_off) UAVQP_HIP(hipMemcpyAsync(d_off, seg_offsets, sizeof(int32_t) * (size_t)(n_traj + 1), hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_wp, waypoints, sizeof(double) * n_wp, hipMemcpyHostToDevice, s));
+    if (corr_lo) {
+        UAVQP_HIP(hipMemcpyAsync(d_lo, corr_lo, sizeof(double) * n_wp, hipMemcpyHostToDevice, s));
+        UAVQP_HIP(hipMemcpyAsync(d_hi, corr_hi, sizeof(double) * n_wp, hipMemcpyHostToDevice, s));
+    }
+    if (total_seg > 0) {
+        UAVQP_HIP(hipMemcpyAsync(d_t, times, sizeof(double) * (size_t)total_seg, hipMemcpyHostToDevice, s));
+        UAVQP_HIP(hipMemcpyAsync(d_rt, row_tau, sizeof(double) * n_row, hipMemcpyHostToDevice, s));
+        UAVQP_HIP(hipMemcpyAsync(d_rd, row_deriv, sizeof(int32_t) * n_row, hipMemcpyHostToDevice, s));
+        UAVQP_HIP(hipMemcpyAsync(d_rl, row_lo, sizeof(double) * 3 * n_row, hipMemcpyHostToDevice, s));
+        UAVQP_HIP(hipMemcpyAsync(d_rh, row_hi, sizeof(double) * 3 * n_row, hipMemcpyHostToDevice, s));
+    }
+    UAVQP_HIP(hipMemcpyAsync(d_bc, bc, sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3, hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * 3 * 2 * r * (size_t)total_seg, s));   // failed trajectories come back as zeros
+    rc = uavqp_solve_rows_batch_device(ctx, r, n_traj, uniform_segments, Mmax, d_off, d_wp, d_t, d_bc, corr_lo ? d_lo : nullptr,
+                                       corr_lo ? d_hi : nullptr, K, d_rt, d_rd, d_rl, d_rh, d_out, d_st, d_it, nullptr);
+    if (rc != UAVQP_OK) return rc;
+    if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(coeff_out, d_out, sizeof(double) * 3 * 2 * r * (size_t)total_seg, hipMemcpyDeviceToHost, s));
+    if (status_out) UAVQP_HIP(hipMemcpyAsync(status_out, d_st, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
+    if (iters_out) UAVQP_HIP(hipMemcpyAsync(iters_out, d_it, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
+    UAVQP_HIP(hipStreamSynchronize(s));
+    return UAVQP_OK;
+}
+
 extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
                                             double* d_times, const double* d_coeff, double v_max, double a_max,
                                             int samples_per_seg, double max_stretch, int32_t* d_changed_out) {

@@ -270,6 +270,38 @@ class Context:
         _lib.check(rc, "uavqp_solve_corridor_batch_host")
         return coeff, status, iters
 
+    def solve_rows_batch_host(self, r, seg_offsets, waypoints, times, bc, corr_lo, corr_hi, rows_per_segment, row_tau, row_deriv,
+                              row_lo, row_hi, uniform_segments=0):
+        """Knot boxes (or None, None: waypoint equalities) + general rows, numpy in / numpy out (uavqp_solve_rows_batch_host).
+        row_tau / row_deriv [segments][K], row_lo / row_hi [segments][K][3].  Returns (coeff_flat, status, iters)."""
+        waypoints = np.ascontiguousarray(waypoints, dtype=np.float64)
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        bc = np.ascontiguousarray(bc, dtype=np.float64)
+        lo = None if corr_lo is None else np.ascontiguousarray(corr_lo, dtype=np.float64)
+        hi = None if corr_hi is None else np.ascontiguousarray(corr_hi, dtype=np.float64)
+        tau = np.ascontiguousarray(row_tau, dtype=np.float64)
+        drv = np.ascontiguousarray(row_deriv, dtype=np.int32)
+        rlo = np.ascontiguousarray(row_lo, dtype=np.float64)
+        rhi = np.ascontiguousarray(row_hi, dtype=np.float64)
+        if uniform_segments > 0:
+            n_traj = times.size // uniform_segments
+            so, total, mmax = None, n_traj * uniform_segments, uniform_segments
+        else:
+            so = np.ascontiguousarray(seg_offsets, dtype=np.int32)
+            n_traj = so.size - 1
+            total = int(so[-1]) if n_traj > 0 else 0
+            mmax = int(np.max(np.diff(so))) if n_traj > 0 else 1
+        K = int(rows_per_segment)
+        assert waypoints.size == 3 * (total + n_traj) and tau.size == total * K == drv.size and rlo.size == 3 * total * K == rhi.size
+        coeff = np.zeros(3 * 2 * r * total, dtype=np.float64)
+        status = np.zeros(n_traj, dtype=np.int32)
+        iters = np.zeros(n_traj, dtype=np.int32)
+        rc = _lib.lib().uavqp_solve_rows_batch_host(self._h, r, n_traj, uniform_segments, max(mmax, 1), _ptr(so), _ptr(waypoints), _ptr(times),
+                                                    _ptr(bc), _ptr(lo), _ptr(hi), K, _ptr(tau), _ptr(drv), _ptr(rlo), _ptr(rhi),
+                                                    _ptr(coeff), _ptr(status), _ptr(iters))
+        _lib.check(rc, "uavqp_solve_rows_batch_host")
+        return coeff, status, iters
+
     def solve_axis_host(self, r, pos_1d, bound_vel, bound_acc, time_vec, bound_jerk=None):
         pos = np.ascontiguousarray(pos_1d, dtype=np.float64)
         bv = np.ascontiguousarray(bound_vel, dtype=np.float64)
