@@ -258,3 +258,40 @@ def test_single_segment_rows_are_checked(gpu_ctx):
     got, st, it, act = run_rows(gpu_ctx, r, b, None, None, K, tau, drv, rlo, rhi, 1)
     assert list(st) == [U.UAVQP_SOLVED, U.UAVQP_SOLVED, U.UAVQP_MAX_ITER_REACHED, U.UAVQP_SOLVED, U.UAVQP_MAX_ITER_REACHED, U.UAVQP_SOLVED]
     assert np.max(np.abs(got - eq)) < 1e-12 * np.max(np.abs(eq))
+
+
+def test_python_traj_optimizer_facade_with_rows():
+    """TrajOptimizer.setRows (the Python mirror of the C++ facade's method): a mid-segment velocity limit 15 % under the
+    unconstrained speed; checked on the emitted polynomials."""
+    r = 4
+    b = W.ragged_batch(4, 25, r, m_lo=2, m_hi=9)
+    so = np.asarray(b["seg_offsets"])
+    n, S = so.size - 1, int(so[-1])
+    wp_off = so + np.arange(n + 1)
+    opt = U.TrajOptimizer(order=r)
+    opt.setWaypoints(b["waypoints"], wp_off)
+    opt.setTimeAllocation(b["times"])
+    opt.setBoundary(b["bc"])
+    assert opt.solve()
+    T = np.asarray(b["times"]).reshape(-1)
+
+    def vel_mid(o):
+        out = np.zeros((S, 3))
+        for k in range(n):
+            c = o.getPolyCoeff(k)                                     # [3][M][2r]
+            for s in range(so[k + 1] - so[k]):
+                t = 0.5 * T[so[k] + s]
+                out[so[k] + s] = sum(q * c[:, s, q] * t ** (q - 1) for q in range(1, 2 * r))
+        return out
+    v0 = vel_mid(opt)
+    lim = 0.85 * np.abs(v0) + 0.2
+    opt.setRows(1, np.full((S, 1), 0.5), np.ones((S, 1), dtype=np.int32), -lim[:, None, :], lim[:, None, :])
+    ok = opt.solve()
+    solved = opt.status == U.UAVQP_SOLVED
+    assert solved.mean() > 0.7 and (ok == bool(solved.all()))
+    v1 = vel_mid(opt)
+    seg_solved = np.repeat(solved, np.diff(so))
+    assert np.all(np.abs(v1[seg_solved]) <= lim[seg_solved] * (1 + 1e-9) + 1e-9)
+    assert (np.abs(np.abs(v1[seg_solved]) - lim[seg_solved]) < 1e-7).sum() > 10      # the rows bind
+    opt.setRows(0)
+    assert opt.solve() and np.allclose(vel_mid(opt), v0, rtol=0, atol=1e-12)

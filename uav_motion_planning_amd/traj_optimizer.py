@@ -370,6 +370,9 @@ class TrajOptimizer:
     setBoundary(bc)                  bc [n_traj][2][r-1][3]; default: all zero (test_minimum_jerk.cpp:59-63)
     setCorridor(lo, hi)              optional boxes [sum(M_b+1)][3] replacing the interior-waypoint equalities
                                      (north-star extension; None, None restores the reference's equality rows)
+    setRows(K, tau, deriv, lo, hi)   optional general rows lo <= p^(deriv)(tau T) <= hi per segment, slot and axis (K = 1 or 2 slots;
+                                     tau / deriv [sum M_b][K], lo / hi [sum M_b][K][3]; K = 0 removes them) -- the same method as the
+                                     C++ facade's (cpp/traj_optimizer.h)
     solve() -> bool                  True iff every trajectory solved (statuses in .status)
     getPolyCoeff()                   flat float64 array, trajectory b at 3*2r*seg_offsets[b], [axis][seg][2r]
     """
@@ -381,6 +384,7 @@ class TrajOptimizer:
         self._ctx = None
         self._wp = self._T = self._bc = self._so = None
         self._lo = self._hi = None
+        self._rows = None
         self._coef = np.zeros(0)
         self.status = np.zeros(0, dtype=np.int32)
         self.iterations = np.zeros(0, dtype=np.int32)
@@ -409,6 +413,14 @@ class TrajOptimizer:
         self._lo = np.ascontiguousarray(lo, dtype=np.float64).reshape(-1, 3)
         self._hi = np.ascontiguousarray(hi, dtype=np.float64).reshape(-1, 3)
 
+    def setRows(self, rows_per_segment, tau=None, deriv=None, lo=None, hi=None):
+        if not rows_per_segment:
+            self._rows = None
+            return
+        K = int(rows_per_segment)
+        self._rows = (K, np.ascontiguousarray(tau, dtype=np.float64).reshape(-1, K), np.ascontiguousarray(deriv, dtype=np.int32).reshape(-1, K),
+                      np.ascontiguousarray(lo, dtype=np.float64).reshape(-1, K, 3), np.ascontiguousarray(hi, dtype=np.float64).reshape(-1, K, 3))
+
     def solve(self):
         if self._wp is None or self._T is None:
             return False
@@ -422,7 +434,13 @@ class TrajOptimizer:
             self._ctx = Context(self._device)  # raises UavqpError without libuavqp.so / without a GPU
             # the three settings the reference passes to its solver (minimum_control.cpp:160-162)
             self._ctx.set_settings(warm_start=1, eps_prim_inf=1e-3, max_iter=1000)
-        if self._lo is not None:
+        if self._rows is not None:
+            K, tau, drv, rlo, rhi = self._rows
+            if tau.shape[0] != self._T.size:
+                return False
+            self._coef, self.status, self.iterations = self._ctx.solve_rows_batch_host(
+                self._r, self._so, self._wp, self._T, bc, self._lo, self._hi, K, tau, drv, rlo, rhi)
+        elif self._lo is not None:
             self._coef, self.status, self.iterations = self._ctx.solve_corridor_batch_host(
                 self._r, self._so, self._wp, self._T, bc, self._lo, self._hi)
         else:
