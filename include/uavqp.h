@@ -112,6 +112,8 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *                          3 = one lane per (trajectory, axis)
  *   generic_waves_per_cu   0 auto, > 0: resident waves per CU of the generic kernel
  *   corridor_pdas_rounds   block-pivoting rounds before the single-pivot active-set phase (default 3)
+ *   corridor_initial_guess 1 (default): a cold corridor solve starts from the knots whose boxes the end-state polynomial misses
+ *                          (closed form) instead of the empty working set; 0: empty set.  Same result.
  *   realloc_dead_band      uavqp_time_reallocate_device stretches only when the limit ratio exceeds this (default 1.01)
  *   realloc_overshoot      ... and then by overshoot * ratio (default 1.02) */
 typedef struct uavqp_settings {
@@ -124,6 +126,7 @@ typedef struct uavqp_settings {
     int32_t generic_lanes_per_traj;
     int32_t generic_waves_per_cu;
     int32_t corridor_pdas_rounds;
+    int32_t corridor_initial_guess;
     double realloc_dead_band;
     double realloc_overshoot;
 } uavqp_settings;

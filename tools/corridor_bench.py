@@ -35,18 +35,21 @@ for cfg in (3, 5):
 
     def run():
         ctx.solve_corridor_device(r, n, uni, mx, None if uni else d_so, d["waypoints"], d["times"], d["bc"], d_lo, d_hi, out, st, it)
-    for _ in range(2):
-        run()
-    torch.cuda.synchronize()
-    ms = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        run()
-        e1.record()
+    modes = (1, 0, 1, 0) if len(sys.argv) > 2 and sys.argv[2] == "ab" else (1,)   # A/B of uavqp_settings.corridor_initial_guess in one process
+    for guess in modes:
+        ctx.set_settings(corridor_initial_guess=guess)
+        for _ in range(2):
+            run()
         torch.cuda.synchronize()
-        ms.append(e0.elapsed_time(e1))
-    itn = it.cpu().numpy()
-    print(json.dumps({"config": cfg, "n": n, "r": r, "ms_median": float(np.median(ms)), "ms_min": float(np.min(ms)),
-                      "solved": int((st == U.UAVQP_SOLVED).sum().item()), "iters_mean": float(itn.mean()), "iters_max": int(itn.max()),
-                      "checksum": float(out.abs().sum().item())}))
+        ms = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        itn = it.cpu().numpy()
+        print(json.dumps({"config": cfg, "initial_guess": guess, "n": n, "r": r, "ms_median": float(np.median(ms)), "ms_min": float(np.min(ms)),
+                          "solved": int((st == U.UAVQP_SOLVED).sum().item()), "iters_mean": float(itn.mean()), "iters_max": int(itn.max()),
+                          "checksum": float(out.abs().sum().item())}))

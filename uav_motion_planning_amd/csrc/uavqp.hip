@@ -763,6 +763,7 @@ extern "C" void uavqp_default_settings(uavqp_settings* out) {
     out->generic_lanes_per_traj = 0;
     out->generic_waves_per_cu = 0;
     out->corridor_pdas_rounds = 3;
+    out->corridor_initial_guess = 1;
     out->realloc_dead_band = 1.01;
     out->realloc_overshoot = 1.02;
 }
@@ -781,6 +782,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     ctx->settings = *st;
     ctx->settings.warm_start = st->warm_start ? 1 : 0;
     ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
+    ctx->settings.corridor_initial_guess = st->corridor_initial_guess ? 1 : 0;
     return UAVQP_OK;
 }
 
@@ -1311,8 +1313,11 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort;
     const size_t b_order = deal_by_length ? align256(sizeof(int32_t) * (size_t)n_traj) + 2048 : 0;   // order + histogram + cursors
     const size_t b_state = sizeof(double) * (size_t)ws_knots * F * (size_t)grid * 64;
-    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state);
+    const bool guess = !warm_start && ctx->settings.corridor_initial_guess != 0;     // cold start from the closed-form set of the prep kernel
+    const size_t b_guess = guess ? align256(sizeof(unsigned long long) * 6 * (size_t)n_traj) : 0;
+    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state + b_guess);
     if (rc != UAVQP_OK) return rc;
+    a.guess = guess ? (unsigned long long*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order + b_state) : nullptr;
     a.coeff = d_coeff_out;
     a.xsol = ctx->ws;
     a.queue = (unsigned int*)((char*)ctx->ws + b_xsol);
@@ -1346,7 +1351,8 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     {
         long long pgrid = (pairs + 255) / 256;
         if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
-        hipLaunchKernelGGL(uavqp::corridor_prep_kernel, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
+        if (r == 3) hipLaunchKernelGGL(uavqp::corridor_prep_kernel<3>, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(uavqp::corridor_prep_kernel<4>, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
     }
     if (r == 3) {
         if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
