@@ -78,8 +78,24 @@ def disagreement(g):
     return 100.0 * np.mean([bin(int((a ^ b_) & 0xFFFE)).count("1") for a, b_ in zip(true_act[:4000, :, 0].ravel(), g[:4000, :, 0].ravel())]) / (M - 1)
 
 
+def end_state_guess(beta):
+    """active where the end-state polynomial leaves the box scaled by beta about its centre (beta = 0: every knot active)"""
+    g = np.zeros((n, 3, 2), dtype=np.int64)
+    h = 0.5 * (hi[:, 1:M] - lo[:, 1:M]); c = 0.5 * (hi[:, 1:M] + lo[:, 1:M])
+    up_ = q > c + beta * h
+    dn_ = q < c - beta * h
+    if beta == 0.0:
+        dn_ = ~up_
+    for k in range(1, M):
+        g[:, :, 0] |= ((up_[:, k - 1] | dn_[:, k - 1]).astype(np.int64) << k)
+        g[:, :, 1] |= (up_[:, k - 1].astype(np.int64) << k)
+    return g
+
+
 guesses = {"end-state polynomial": act}
-for alpha in (0.5, 1.0, 1.5):
+for beta in (0.0, 0.5, 1.5, 2.5):
+    guesses["end-state beta %.1f" % beta] = end_state_guess(beta)
+for alpha in (1.0,):
     guesses["local chord %.1f" % alpha] = local_chord_guess(alpha)
 res = {}
 for name, g in [("cold", None)] + list(guesses.items()):
