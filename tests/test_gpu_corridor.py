@@ -283,3 +283,33 @@ def test_corridor_stress_time_allocation_and_tiny_boxes(gpu_ctx, oracle, r, M):
                                                b["bc"][k, 1, :, ax], lo[k, 1:M, ax], hi[k, 1:M, ax])
             worst = np.maximum(worst, [prim, stat, comp])
     assert worst[0] < 1e-9 and worst[1] < 1e-6 and worst[2] < 1e-5, worst
+
+
+def test_cold_start_guess_changes_iterations_not_results(gpu_ctx):
+    """uavqp_settings.corridor_initial_guess: the closed-form starting set of a cold solve (knots whose boxes the end-state
+    polynomial misses).  Any starting set is admissible -- the minimiser and the reported working set are the same to the last
+    bit with and without it; on config-3-like problems it saves iterations on average."""
+    import torch
+    r, M, n = 3, 16, 600
+    b = W.uniform_batch(3, n, M, r, time_mode="distance")
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_wp, d_T, d_bc, d_lo, d_hi = up(b["waypoints"].reshape(-1, 3)), up(b["times"].reshape(-1)), up(b["bc"]), up(lo.reshape(-1, 3)), up(hi.reshape(-1, 3))
+    res = {}
+    assert gpu_ctx.get_settings().corridor_initial_guess == 1
+    try:
+        for g in (1, 0):
+            gpu_ctx.set_settings(corridor_initial_guess=g)
+            out = torch.zeros(n * 3 * M * 2 * r, dtype=torch.float64, device=dev)
+            st = torch.zeros(n, dtype=torch.int32, device=dev)
+            it = torch.zeros(n, dtype=torch.int32, device=dev)
+            act = torch.zeros((n, 3, 2), dtype=torch.int64, device=dev)
+            gpu_ctx.solve_corridor_device(r, n, M, M, None, d_wp, d_T, d_bc, d_lo, d_hi, out, st, it, act, False)
+            gpu_ctx.synchronize()
+            res[g] = (out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), act.cpu().numpy())
+    finally:
+        gpu_ctx.set_settings(corridor_initial_guess=1)
+    assert np.all(res[1][1] == U.UAVQP_SOLVED) and np.all(res[0][1] == U.UAVQP_SOLVED)
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][3], res[0][3])
+    assert res[1][2].mean() < res[0][2].mean()
