@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
         const double* hi = a.corr_hi + base3;
         const double* T = a.times + s0;
         bool ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;  // pin masks are 64-bit
-        unsigned long long eq = 0ull;
+        unsigned long long eq = 0ull, g_act = 0ull, g_up = 0ull;
         double Ttot = 0.0;
         if (ok) {
             for (int i = 0; i < M; ++i) {
@@ -170,39 +170,43 @@ __global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
                 ok = ok & (t > 0.0) & (t < INFINITY);
                 Ttot += t;
             }
+        }
+        if (ok) {
+            // one pass over the boxes: bounds check, equality rows, and the starting set
+            double c[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) c[j] = 0.0;
+            const bool want = a.guess != nullptr && M >= 2;
+            if (want) {
+                const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+                double ys[ND], ye[ND];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { ys[d] = bc[d * 3]; ye[d] = bc[(ND + d) * 3]; }
+                segment_coeffs<R>(a.waypoints[base3], ys, a.waypoints[base3 + 3 * M], ye, Ttot, fast_rcp(Ttot), c);
+            }
+            double t = 0.0;
             for (int k = 1; k < M; ++k) {
                 const double l = lo[3 * k], h = hi[3 * k];
                 ok = ok & (l <= h);
                 eq |= (unsigned long long)(l == h) << k;
+                t += T[k - 1];
+                double p = c[NC - 1];
+#pragma unroll
+                for (int j = NC - 2; j >= 0; --j) p = fma(p, t, c[j]);
+                const bool above = p > h, below = p < l;
+                g_act |= (unsigned long long)(above | below) << k;
+                g_up |= (unsigned long long)above << k;
             }
+            g_act &= ~eq;
+            g_up &= g_act;
         }
         if (!ok) atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
         // no interior knot (M = 1): nothing to solve, the emission kernel builds the segment from the boundary data
         if (ok && M == 1 && a.active) { a.active[2 * q] = 0ull; a.active[2 * q + 1] = 0ull; }
         a.desc[q] = (ok && M >= 2) ? (eq | 1ull) : 0ull;
         if (a.guess) {
-            unsigned long long g_act = 0ull, g_up = 0ull;
-            if (ok && M >= 2) {
-                const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
-                double ys[ND], ye[ND], c[NC];
-#pragma unroll
-                for (int d = 0; d < ND; ++d) { ys[d] = bc[d * 3]; ye[d] = bc[(ND + d) * 3]; }
-                segment_coeffs<R>(a.waypoints[base3], ys, a.waypoints[base3 + 3 * M], ye, Ttot, fast_rcp(Ttot), c);
-                double t = 0.0;
-                for (int k = 1; k < M; ++k) {
-                    t += T[k - 1];
-                    double p = c[NC - 1];
-#pragma unroll
-                    for (int j = NC - 2; j >= 0; --j) p = fma(p, t, c[j]);
-                    const bool above = p > hi[3 * k], below = p < lo[3 * k];
-                    g_act |= (unsigned long long)(above | below) << k;
-                    g_up |= (unsigned long long)above << k;
-                }
-                g_act &= ~eq;
-                g_up &= g_act;
-            }
-            a.guess[2 * q] = g_act;
-            a.guess[2 * q + 1] = g_up;
+            a.guess[2 * q] = (ok && M >= 2) ? g_act : 0ull;
+            a.guess[2 * q + 1] = (ok && M >= 2) ? g_up : 0ull;
         }
     }
 }
@@ -882,66 +886,89 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // Hermite solution -> monomial coefficients (ascending powers, segment-local time: the reference's coef_1d_ layout,
 // minimum_control.cpp:186).  One lane per (trajectory, axis, segment): lane e writes the e-th 2r-coefficient chunk of
-// the output, so consecutive lanes write consecutive 48- / 64-byte chunks.
+// the output, so consecutive lanes own consecutive 48- / 64-byte chunks (written out through LDS, coalesced).
 // ---------------------------------------------------------------------------------------------------
 template <int R>
 __global__ __launch_bounds__(256) void corridor_emit_kernel(CorridorArgs a, long long total_chunks) {
     constexpr int ND = R - 1, NC = 2 * R;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total_chunks; e += (long long)gridDim.x * blockDim.x) {
-        int b, s0, M;
-        if (a.uniform > 0) {
-            M = a.uniform;
-            b = (int)(e / (3LL * M));
-            s0 = b * M;
-        } else {
-            // chunk e belongs to the trajectory b with 3 seg_offsets[b] <= e < 3 seg_offsets[b+1]
-            int lo_b = 0, hi_b = a.n_traj - 1;
-            while (lo_b < hi_b) {
-                const int mid = (lo_b + hi_b + 1) >> 1;
-                if (3LL * a.seg_offsets[mid] <= e) lo_b = mid; else hi_b = mid - 1;
-            }
-            b = lo_b;
-            s0 = a.seg_offsets[b];
-            M = a.seg_offsets[b + 1] - s0;
-        }
-        const int st = a.status[b];
-        if (st == UAVQP_INVALID_INPUT || M < 1) continue;  // left untouched
-        const int rem = (int)(e - 3LL * s0), ax = rem / M, k = rem - ax * M;
-        const size_t row0 = (size_t)(s0 + b);
-        const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
-        double p0, p1, ys[ND], ye[ND];
-        if (k == 0) {
-            p0 = a.waypoints[3 * row0 + ax];
-#pragma unroll
-            for (int d = 0; d < ND; ++d) ys[d] = bc[d * 3];
-        } else {
-            const double* x = a.xsol + (3 * (row0 + k) + ax) * R;
-            p0 = x[0];
-#pragma unroll
-            for (int d = 0; d < ND; ++d) ys[d] = x[d + 1];
-        }
-        if (k == M - 1) {
-            p1 = a.waypoints[3 * (row0 + M) + ax];
-#pragma unroll
-            for (int d = 0; d < ND; ++d) ye[d] = bc[(ND + d) * 3];
-        } else {
-            const double* x = a.xsol + (3 * (row0 + k + 1) + ax) * R;
-            p1 = x[0];
-#pragma unroll
-            for (int d = 0; d < ND; ++d) ye[d] = x[d + 1];
-        }
-        const double Tk = a.times[s0 + k];
+    // the 256 lanes of a block own 256 consecutive chunks = one contiguous piece of the output: the coefficients go through LDS
+    // (row stride NC + 1 doubles) and leave as linear 16-byte-per-lane stores instead of NC / 2 stores at a 48- / 64-byte lane stride
+    __shared__ __attribute__((aligned(16))) double s_c[256 * NC];
+    __shared__ unsigned char s_keep[256];
+    const int tid = threadIdx.x;
+    const bool al16 = (reinterpret_cast<uintptr_t>(a.coeff) & 15u) == 0;
+    for (long long e0 = (long long)blockIdx.x * 256; e0 < total_chunks; e0 += (long long)gridDim.x * 256) {
+        const long long e = e0 + tid;
+        bool keep = false;
         double c[NC];
-        segment_coeffs<R>(p0, ys, p1, ye, Tk, fast_rcp(Tk), c);
-        double* o = a.coeff + (size_t)e * NC;
-        if ((reinterpret_cast<uintptr_t>(a.coeff) & 15u) == 0) {  // uniform: 16-byte stores unless the caller passed an odd view
 #pragma unroll
-            for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(o + q) = make_double2(c[q], c[q + 1]);
-        } else {
+        for (int q = 0; q < NC; ++q) c[q] = 0.0;
+        if (e < total_chunks) {
+            int b, s0, M;
+            if (a.uniform > 0) {
+                M = a.uniform;
+                b = (int)(e / (3LL * M));
+                s0 = b * M;
+            } else {
+                // chunk e belongs to the trajectory b with 3 seg_offsets[b] <= e < 3 seg_offsets[b+1]
+                int lo_b = 0, hi_b = a.n_traj - 1;
+                while (lo_b < hi_b) {
+                    const int mid = (lo_b + hi_b + 1) >> 1;
+                    if (3LL * a.seg_offsets[mid] <= e) lo_b = mid; else hi_b = mid - 1;
+                }
+                b = lo_b;
+                s0 = a.seg_offsets[b];
+                M = a.seg_offsets[b + 1] - s0;
+            }
+            const int st = a.status[b];
+            if (!(st == UAVQP_INVALID_INPUT || M < 1)) {   // (those are left untouched)
+                keep = true;
+                const int rem = (int)(e - 3LL * s0), ax = rem / M, k = rem - ax * M;
+                const size_t row0 = (size_t)(s0 + b);
+                const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+                double p0, p1, ys[ND], ye[ND];
+                if (k == 0) {
+                    p0 = a.waypoints[3 * row0 + ax];
 #pragma unroll
-            for (int q = 0; q < NC; ++q) o[q] = c[q];
+                    for (int d = 0; d < ND; ++d) ys[d] = bc[d * 3];
+                } else {
+                    const double* x = a.xsol + (3 * (row0 + k) + ax) * R;
+                    p0 = x[0];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) ys[d] = x[d + 1];
+                }
+                if (k == M - 1) {
+                    p1 = a.waypoints[3 * (row0 + M) + ax];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) ye[d] = bc[(ND + d) * 3];
+                } else {
+                    const double* x = a.xsol + (3 * (row0 + k + 1) + ax) * R;
+                    p1 = x[0];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) ye[d] = x[d + 1];
+                }
+                const double Tk = a.times[s0 + k];
+                segment_coeffs<R>(p0, ys, p1, ye, Tk, fast_rcp(Tk), c);
+                if (!((fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY))) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+            }
         }
-        if (!((fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY))) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+        double* o = a.coeff + (size_t)e0 * NC;
+        if (al16) {
+            s_keep[tid] = keep ? 1 : 0;
+#pragma unroll
+            for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(s_c + tid * NC + q) = make_double2(c[q], c[q + 1]);
+            __syncthreads();
+            const long long left = total_chunks - e0;
+            const int n_ch = left < 256 ? (int)left : 256;
+            for (int i = tid; i < n_ch * (NC / 2); i += 256) {
+                const int ch = i / (NC / 2);
+                if (s_keep[ch]) *reinterpret_cast<double2*>(o + 2 * i) = *reinterpret_cast<const double2*>(s_c + 2 * i);
+            }
+            __syncthreads();
+        } else if (keep) {   // the caller passed a view that starts at an odd double
+#pragma unroll
+            for (int q = 0; q < NC; ++q) o[(size_t)tid * NC + q] = c[q];
+        }
     }
 }
 
