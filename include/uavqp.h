@@ -334,6 +334,24 @@ int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_traj, int unif
                                      const double* d_obstacles, int n_obs, double robot_r, double robot_h, double h_max,
                                      double* d_corr_lo, double* d_corr_hi, double* d_clearance);
 
+/* quadrotor_msgs/PolynomialTrajectory packer.  HOST function, no ctx, no device: turns ONE solved
+ * trajectory (the [axis][segment][2r] slice of coeff_out that belongs to it) into the arrays of the message the rest of the
+ * reference stack consumes -- src/simulator/utils/quadrotor_msgs/msg/PolynomialTrajectory.msg:1-28; the only consumer in the
+ * reference is trajCallback, src/planner/traj_server/src/poly_traj_server.cpp:57-81, which reads num_order + 1 coefficients per
+ * segment and axis from coef_x / coef_y / coef_z (ascending powers, segment-local time: the layout of coef_1d_,
+ * minimum_control.cpp:186) and the segment durations from time[].  Nobody in the reference PRODUCES this message; this closes
+ * the loop from the solver to poly_traj_server.
+ *   coeff_traj  [3][n_seg][2r]   one trajectory of uavqp_solve_*'s coeff_out
+ *   times       [n_seg]
+ *   coef_x / coef_y / coef_z [n_seg * 2r], time_out [n_seg], order_out [n_seg] (uint32, = 2r - 1 each): caller-allocated
+ *   num_order_out = 2r - 1, num_segment_out = n_seg (the message's scalar fields; trajectory_id, action = ACTION_ADD (1),
+ *   start_yaw / final_yaw, mag_coeff, header.stamp are the caller's).
+ * Returns UAVQP_ERR_INVALID_ARG for r not in {3, 4}, n_seg < 1, a null pointer, or a non-positive / non-finite duration
+ * (poly_traj_server would walk off the end of such a trajectory). */
+int uavqp_pack_polynomial_trajectory(int r, int n_seg, const double* coeff_traj, const double* times, double* coef_x, double* coef_y,
+                                     double* coef_z, double* time_out, uint32_t* order_out, uint32_t* num_order_out,
+                                     uint32_t* num_segment_out);
+
 /* ---- Multi-GPU: contiguous shards of the batch, one process (or thread) and one ctx per GPU ----
  * Trajectories are independent QPs, so the solve itself needs no collective: every rank solves its own slice with the entry
  * points above.  The one exchange step is the all-gather of the solved coefficient shards over xGMI (RCCL).  The reference has

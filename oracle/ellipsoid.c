@@ -7,7 +7,12 @@
  *   :747-755  radius search robot_r + 0.1 around pt; collision if |E^-1 (o - pt)| <= 1 for a found point
  * The PCL kd-tree radius search is replaced by an exhaustive scan over the obstacle points (identical candidate
  * set up to float rounding at the radius boundary, which cannot matter: the ellipsoid lies inside radius robot_r).
- * PARITY UNPINNED: no recorded outputs in the reference; Eigen / PCL absent, so restated, not compiled.
+ * Pinned on the reference's OWN code: oracle/_ref/libref_kino.so is KinoAstar::isCollisionFree + toPCL cut out of
+ * kino_astar.cpp at build time and compiled inside the reference's own class declaration (oracle/Makefile,
+ * ref_shim/ref_kino_capi.cpp; Eigen and PCL are stand-ins with Eigen's formulas for normalized() / 3 x 3 inverse() and a
+ * float exhaustive radius search); tests/test_ellipsoid_oracle_vs_reference_source.py checks this restatement against it on
+ * random clouds, on points straddling the float search sphere and on the ellipsoid surface.  The reference holds no recorded
+ * outputs for this function.
  */
 #include <math.h>
 

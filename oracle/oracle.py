@@ -299,3 +299,89 @@ def ref_polytraj_eval(nc, times, coef_traj, t):
     out = np.zeros(9)
     _ref.ref_polytraj_eval(int(nc), int(T.size), pT, pc, ctypes.c_double(t), out.ctypes.data_as(_dp))
     return out.reshape(3, 3)
+
+
+# ---- oracle/_ref/libref_kino.so: the reference's own KinoAstar::isCollisionFree + toPCL (function bodies cut out of
+# kino_astar.cpp:721-774 at build time, compiled inside the reference's own class declaration; ref_shim/ref_kino_capi.cpp) -------
+_REF_KINO_PATH = os.path.join(_HERE, "_ref", "libref_kino.so")
+_ref_kino = None
+
+
+def ref_kino_available():
+    return os.path.exists(_REF_KINO_PATH)
+
+
+class RefKino:
+    """One KinoAstar object of the reference with its cloud loaded (obs_ + kd-tree as localCloudCallback builds them).
+    as_float=True: the cloud is narrowed to float32 first, as the reference receives it over ROS."""
+
+    def __init__(self, obstacles, robot_r, robot_h, as_float=True):
+        global _ref_kino
+        if _ref_kino is None:
+            _ref_kino = ctypes.CDLL(_REF_KINO_PATH)
+            _ref_kino.ref_kino_create.restype = ctypes.c_void_p
+        o, po = _d(np.asarray(obstacles, dtype=np.float64).reshape(-1))
+        self._h = ctypes.c_void_p(_ref_kino.ref_kino_create(po, o.size // 3, ctypes.c_double(robot_r), ctypes.c_double(robot_h), int(bool(as_float))))
+
+    def is_collision_free(self, pts, accs):
+        """pts, accs [n,3] -> bool [n]: the reference's verdict per (position, acceleration)."""
+        p, pp = _d(np.asarray(pts, dtype=np.float64).reshape(-1))
+        a, pa = _d(np.asarray(accs, dtype=np.float64).reshape(-1))
+        n = p.size // 3
+        out = np.zeros(n, dtype=np.int32)
+        _ref_kino.ref_kino_is_collision_free_batch(self._h, n, pp, pa, out.ctypes.data_as(_ip))
+        return out.astype(bool)
+
+    def close(self):
+        if self._h:
+            _ref_kino.ref_kino_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- oracle/_ref/libref_traj_server.so: the reference's own poly_traj_server.cpp compiled whole (ref_shim/ref_traj_server_capi.cpp):
+# the consumer of quadrotor_msgs/PolynomialTrajectory ---------------------------------------------------------------------------
+_REF_TS_PATH = os.path.join(_HERE, "_ref", "libref_traj_server.so")
+_ref_ts = None
+
+
+def ref_traj_server_available():
+    return os.path.exists(_REF_TS_PATH)
+
+
+def _ts():
+    global _ref_ts
+    if _ref_ts is None:
+        _ref_ts = ctypes.CDLL(_REF_TS_PATH)
+        _ref_ts.ref_traj_server_total_time.restype = ctypes.c_double
+    return _ref_ts
+
+
+def ref_traj_server_feed(trajectory_id, num_order, num_segment, coef_x, coef_y, coef_z, time, stamp=0.0):
+    """Hands one quadrotor_msgs/PolynomialTrajectory (the given field values) to the reference's trajCallback
+    (poly_traj_server.cpp:57-81)."""
+    cx, px = _d(coef_x)
+    cy, py = _d(coef_y)
+    cz, pz = _d(coef_z)
+    t, pt = _d(time)
+    assert cx.size == cy.size == cz.size
+    _ts().ref_traj_server_feed(ctypes.c_uint(trajectory_id), ctypes.c_uint(num_order), ctypes.c_uint(num_segment), px, py, pz, pt,
+                               int(cx.size), ctypes.c_double(stamp))
+
+
+def ref_traj_server_tick(odom_stamp):
+    """One tick of the reference's command timer (cmdPubCallback, poly_traj_server.cpp:23-55) at odometry time odom_stamp.
+    Returns (pos_vel_acc [3,3], (trajectory_id, num_order, num_segment)) or None if nothing was published."""
+    out = np.zeros(9)
+    ids = np.zeros(3, dtype=np.int32)
+    ok = _ts().ref_traj_server_tick(ctypes.c_double(odom_stamp), out.ctypes.data_as(_dp), ids.ctypes.data_as(_ip))
+    return (out.reshape(3, 3), tuple(int(v) for v in ids)) if ok else None
+
+
+def ref_traj_server_total_time():
+    return float(_ts().ref_traj_server_total_time())

@@ -30,6 +30,18 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().uavqp_version()
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """library is a subset of the header too: the probe builds' debug entry points (uavqp_debug_corridor_stamps / uavqp_debug_generic2_stamps,
+    compiled only under -DUAVQP_CORRIDOR_TIMING / -DG2_TIMING into tools/ubench/) must not leak into the product library."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    from uav_motion_planning_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW" and ln.split()[-1].startswith("uavqp_")})
+    assert exported == header_symbols(), sorted(set(exported) ^ set(header_symbols()))
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

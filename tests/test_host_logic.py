@@ -1,5 +1,6 @@
 """CPU: host-side logic that needs no device -- workload generators, facade bookkeeping, sharding."""
 import numpy as np
+import pytest
 
 from uav_motion_planning_amd import TrajOptimizer
 from uav_motion_planning_amd import distributed as D
@@ -77,17 +78,21 @@ def test_adapters_flatten_paths_and_empty_rrt_star_path():
     assert bc.shape == (2, 2, 3, 3) and np.all(bc[:, 1] == 0) and list(bc[1, 0, 0]) == [4, 5, 6]
 
 
-def test_polynomial_trajectory_packer_round_trip():
+def test_polynomial_trajectory_packer_fields():
+    """Field values and sizes of the message (PolynomialTrajectory.msg:1-28); what the reference's CONSUMER makes of them is checked
+    on the reference's own poly_traj_server.cpp in tests/test_n3_packer_vs_reference_consumer.py."""
     from uav_motion_planning_amd import adapters as A
+    import uav_motion_planning_amd as U
     r, m = 3, 4
     c = np.arange(3 * m * 2 * r, dtype=np.float64)
     msg = A.pack_polynomial_trajectory(c, [1.0, 2.0, 0.5, 1.5], r, trajectory_id=7)
     assert (msg["num_order"], msg["num_segment"], msg["action"], msg["trajectory_id"]) == (5, 4, 1, 7)
-    segs = A.unpack_like_traj_server(msg)           # poly_traj_server.cpp:66-78 indexing
-    cc = c.reshape(3, m, 2 * r)
-    for i, (cx, cy, cz, t) in enumerate(segs):
-        assert np.array_equal(cx, cc[0, i]) and np.array_equal(cy, cc[1, i]) and np.array_equal(cz, cc[2, i])
-    assert [s[3] for s in segs] == [1.0, 2.0, 0.5, 1.5]
+    assert msg["coef_x"].size == msg["coef_y"].size == msg["coef_z"].size == m * 2 * r and msg["order"] == [5] * m
+    assert list(msg["time"]) == [1.0, 2.0, 0.5, 1.5] and msg["mag_coeff"] == 1.0
+    with pytest.raises(U.UavqpError):
+        A.pack_polynomial_trajectory(c, [1.0, 0.0, 0.5, 1.5], r)          # a zero duration: the server would walk off the end
+    with pytest.raises(ValueError):
+        A.pack_polynomial_trajectory(c[:-1], [1.0, 2.0, 0.5, 1.5], r)
 
 
 def test_refine_with_mid_knots_layout():

@@ -52,6 +52,7 @@ SYMBOLS = (
     "uavqp_obstacle_grid_build_device",
     "uavqp_obstacle_grid_destroy",
     "uavqp_ellipsoid_check_grid_device",
+    "uavqp_pack_polynomial_trajectory",
     "uavqp_shard_bounds",
     "uavqp_shard_bounds_ragged",
     "uavqp_comm_unique_id",
@@ -140,6 +141,7 @@ def lib():
     L.uavqp_obstacle_grid_destroy.argtypes = [vp, vp]
     L.uavqp_ellipsoid_check_grid_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, vp,
                                                     ctypes.c_double, ctypes.c_double, ip, vp]
+    L.uavqp_pack_polynomial_trajectory.argtypes = [i32, i32, dp, dp, dp, dp, dp, dp, vp, vp, vp]
     L.uavqp_shard_bounds.argtypes = [i32, i32, ip]
     L.uavqp_shard_bounds_ragged.argtypes = [ip, i32, i32, ip]
     L.uavqp_comm_unique_id.argtypes = [vp]

@@ -63,14 +63,25 @@ def boundary_from_odometry(n_traj, r, start_velocity=None):
 
 def pack_polynomial_trajectory(coeff_traj, times, r, trajectory_id=1, start_yaw=0.0, final_yaw=0.0):
     """One trajectory of the solver output ([axis][segment][2r], ascending powers) -> the fields of
-    quadrotor_msgs/PolynomialTrajectory as a plain dict (no ROS needed to build or test it)."""
-    times = np.asarray(times, dtype=np.float64).reshape(-1)
+    quadrotor_msgs/PolynomialTrajectory as a plain dict.  A binding of the C-ABI packer uavqp_pack_polynomial_trajectory
+    (include/uavqp.h; host function, no device) -- the same code a C++ node reaches through cpp/traj_adapters.h."""
+    import ctypes
+    from . import _lib
+    times = np.ascontiguousarray(times, dtype=np.float64).reshape(-1)
     m, nc = times.size, 2 * r
-    c = np.asarray(coeff_traj, dtype=np.float64).reshape(3, m, nc)
-    return dict(trajectory_id=int(trajectory_id), action=ACTION_ADD, num_order=nc - 1, num_segment=m,
-                start_yaw=float(start_yaw), final_yaw=float(final_yaw),
-                coef_x=c[0].reshape(-1).copy(), coef_y=c[1].reshape(-1).copy(), coef_z=c[2].reshape(-1).copy(),
-                time=times.copy(), mag_coeff=1.0, order=[nc - 1] * m, debug_info="")
+    c = np.ascontiguousarray(coeff_traj, dtype=np.float64).reshape(-1)
+    if c.size != 3 * m * nc:
+        raise ValueError(f"coeff_traj holds {c.size} values, expected 3 x {m} x {nc}")
+    cx, cy, cz, t = np.zeros(m * nc), np.zeros(m * nc), np.zeros(m * nc), np.zeros(m)
+    order = np.zeros(m, dtype=np.uint32)
+    n_ord, n_seg = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    rc = _lib.lib().uavqp_pack_polynomial_trajectory(int(r), int(m), c.ctypes.data, times.ctypes.data, cx.ctypes.data, cy.ctypes.data,
+                                                     cz.ctypes.data, t.ctypes.data, order.ctypes.data, ctypes.addressof(n_ord),
+                                                     ctypes.addressof(n_seg))
+    _lib.check(rc, "uavqp_pack_polynomial_trajectory")
+    return dict(trajectory_id=int(trajectory_id), action=ACTION_ADD, num_order=int(n_ord.value), num_segment=int(n_seg.value),
+                start_yaw=float(start_yaw), final_yaw=float(final_yaw), coef_x=cx, coef_y=cy, coef_z=cz,
+                time=t, mag_coeff=1.0, order=[int(v) for v in order], debug_info="")
 
 
 def unpack_like_traj_server(msg):

@@ -1839,6 +1839,29 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
 }
 
 // ===================================================================================================
+// N3: quadrotor_msgs/PolynomialTrajectory packer (host only)
+// ===================================================================================================
+extern "C" int uavqp_pack_polynomial_trajectory(int r, int n_seg, const double* coeff_traj, const double* times, double* coef_x,
+                                                double* coef_y, double* coef_z, double* time_out, uint32_t* order_out,
+                                                uint32_t* num_order_out, uint32_t* num_segment_out) {
+    if ((r != 3 && r != 4) || n_seg < 1 || !coeff_traj || !times || !coef_x || !coef_y || !coef_z || !time_out) return UAVQP_ERR_INVALID_ARG;
+    for (int i = 0; i < n_seg; ++i)
+        if (!(times[i] > 0.0) || !(times[i] < INFINITY)) return UAVQP_ERR_INVALID_ARG;
+    const size_t per_axis = (size_t)n_seg * 2 * r;
+    // each axis slice of the solver output IS the message's per-axis array: coef[i * (num_order + 1) + j] multiplies t^j in segment i
+    // (poly_traj_server.cpp:68-78 reads exactly that index)
+    std::memcpy(coef_x, coeff_traj, sizeof(double) * per_axis);
+    std::memcpy(coef_y, coeff_traj + per_axis, sizeof(double) * per_axis);
+    std::memcpy(coef_z, coeff_traj + 2 * per_axis, sizeof(double) * per_axis);
+    std::memcpy(time_out, times, sizeof(double) * (size_t)n_seg);
+    if (order_out)
+        for (int i = 0; i < n_seg; ++i) order_out[i] = (uint32_t)(2 * r - 1);
+    if (num_order_out) *num_order_out = (uint32_t)(2 * r - 1);
+    if (num_segment_out) *num_segment_out = (uint32_t)n_seg;
+    return UAVQP_OK;
+}
+
+// ===================================================================================================
 // Multi-GPU entry points (uavqp_comm.h)
 // ===================================================================================================
 extern "C" int uavqp_shard_bounds(int n_traj, int world, int32_t* bounds) {
