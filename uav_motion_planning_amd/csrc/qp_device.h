@@ -67,8 +67,13 @@ struct SegBlocks {
     double A01[ND][ND];
     double gw[ND];
     __device__ __forceinline__ void build(double T) {
+        double ip[2 * R];
+        build(T, ip);
+    }
+    // same, handing out the inverse powers ip[j] = T^-j (j = 0..2R-1) it computes on the way: the emission needs T^-1 and
+    // T^-R..T^-(2R-1) of the same segment again (segment_coeffs_ip)
+    __device__ __forceinline__ void build(double T, double (&ip)[2 * R]) {
         const double it = fast_rcp(T);
-        double ip[2 * R];  // ip[j] = T^-j
         ip[0] = 1.0;
 #pragma unroll
         for (int j = 1; j < 2 * R; ++j) ip[j] = ip[j - 1] * it;
@@ -250,6 +255,42 @@ __device__ __forceinline__ void segment_coeffs(double p0, const double (&ys)[R -
         for (int d = 0; d < R; ++d) q += Tab<R>::K(j, d) * e[d];
         c[R + j] = q * ipw;
         ipw *= it;
+    }
+}
+
+// segment_coeffs with the inverse powers of the duration supplied (ip[j] = T^-j, from SegBlocks::build): no reciprocal, no power chain.
+template <int R>
+__device__ __forceinline__ void segment_coeffs_ip(double p0, const double (&ys)[R - 1], double p1, const double (&ye)[R - 1], double T,
+                                                  const double (&ip)[2 * R], double (&c)[2 * R]) {
+    double tp[R];  // T^d
+    tp[0] = 1.0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) tp[d] = tp[d - 1] * T;
+    double s0[R], s1[R];
+    s0[0] = 0.0;
+    s1[0] = p1 - p0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) {
+        s0[d] = tp[d] * ys[d - 1];
+        s1[d] = tp[d] * ye[d - 1];
+    }
+    double e[R];
+#pragma unroll
+    for (int d = 0; d < R; ++d) {
+        double acc = s1[d];
+#pragma unroll
+        for (int k = (d > 1 ? d : 1); k < R; ++k) acc -= s0[k] * inv_fact(k - d);
+        e[d] = acc;
+    }
+    c[0] = p0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) c[d] = ys[d - 1] * inv_fact(d);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        double q = 0.0;
+#pragma unroll
+        for (int d = 0; d < R; ++d) q += Tab<R>::K(j, d) * e[d];
+        c[R + j] = q * ip[R + j];
     }
 }
 

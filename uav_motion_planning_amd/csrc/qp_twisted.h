@@ -19,10 +19,12 @@
 
 #include "qp_device.h"
 
+#ifndef UAVQP_STAMP   // (probe builds under tools/ubench define their own: per-wave timelines)
 #ifdef UAVQP_PHASE_TIMING
 #define UAVQP_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define UAVQP_STAMP(i) do {} while (0)
+#endif
 #endif
 
 namespace uavqp {
@@ -53,7 +55,11 @@ struct TwistedCfg {
     // (measured, 1 M batch: aliasing wins for r = 3 -- (3,16) 3.85 vs 3.71, (3,12) 3.97 vs 3.43 TB/s -- but the
     // register cost of the pre-loaded positions spills for r = 4, M = 12: 3.46 vs 3.92 TB/s with 3 waves/CU)
     static constexpr bool ALIAS = LPT == 2 && R == 3 && (2 * IN_D + STAGE_D) * 8 > 40448;
-    static constexpr int OUT_D = (LPT == 2 && !ALIAS) ? STAGE_D : 2;
+    // LPT >= 8 (latency shapes): every emission step leaves one NC-double chunk per working lane (6 * LPT / 8 per trajectory:
+    // TILE * 6 * LPT / 8 = 48 rows for both shapes) in an LDS row of stride 10 doubles (20 dwords: the b128 writes of 16 rows tile
+    // the 64 banks), read back linearly by the wave for the software-pipelined copy-out; rows 48.. take the writes of the idle pairs.
+    static constexpr int ROWS8 = LPT >= 8 ? TILE * 6 * (LPT / 8) : 0, RS8 = 10;
+    static constexpr int OUT_D = LPT >= 8 ? (ROWS8 + 16) * RS8 : ((LPT == 2 && !ALIAS) ? STAGE_D : 2);
     static_assert(!ALIAS || STAGE_D <= IN_D, "aliased staging rows must fit the input buffer");
     static_assert(WP_D % 2 == 0 && T_D % 2 == 0 && BC_D % 2 == 0, "tile arrays must be whole 16-B pairs");
 };
@@ -85,20 +91,23 @@ __device__ __forceinline__ void store_pair(double* dst, double2 v) { *reinterpre
 __device__ __forceinline__ void store_pair_wt(double* dst, double2 v) {
     typedef double wt_v2 __attribute__((ext_vector_type(2)));
     wt_v2 w = {v.x, v.y};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+    // (s_nop 1: the store reads its data registers after issue -- two wait states before anything may overwrite them on gfx940+,
+    //  and the compiler cannot see through the string)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
 }
 
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 
-// Asynchronous HBM -> LDS copy of ND_ doubles (full tile): one global_load_lds_dwordx4 per 1 KiB.
-template <int ND_>
+// Asynchronous HBM -> LDS copy of ND_ doubles (full tile): one global_load_lds_dwordx4 per 1 KiB.  AUX = 2: non-temporal (the
+// latency shapes read every input byte exactly once: measured 5.49 -> 5.24 us on the 4096 batch, tools/ubench/tw).
+template <int ND_, int AUX = 0>
 __device__ __forceinline__ void dma_tile(const double* __restrict__ g, double* s, int lane) {
     constexpr int NP = ND_ / 2, NL = (NP + 63) / 64;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
         const int p = lane + 64 * k;
-        if (p < NP) __builtin_amdgcn_global_load_lds((gas_ptr)(g + 2 * p), (las_ptr)(s + 128 * k), 16, 0, 0);
+        if (p < NP) __builtin_amdgcn_global_load_lds((gas_ptr)(g + 2 * p), (las_ptr)(s + 128 * k), 16, 0, AUX);
     }
 }
 
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
     static_assert((LPT == 2 && (TILE == 32 || TILE == 16)) || (LPT == 8 && TILE == 8) || (LPT == 16 && TILE == 4), "tile shapes: 2 lanes x 32|16, 8 lanes x 8, 16 lanes x 4");
 
     __shared__ __attribute__((aligned(16))) double s_in[2][C::IN_D];
-    __shared__ __attribute__((aligned(16))) double s_out[LPT == 2 ? C::OUT_D : 2];
+    __shared__ __attribute__((aligned(16))) double s_out[C::OUT_D];
     (void)s_out;
 
     const int lane = threadIdx.x;
@@ -130,14 +139,23 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
     const int m = isR ? mR : mL;
     const int n_tiles = (a.n_traj + TILE - 1) / TILE;
 
+    // A partial last tile is SHIFTED back so that it ends at the batch end (n_traj >= TILE): it stays on the LDS-DMA path and
+    // re-solves a few trajectories of its neighbour -- identical values written twice -- instead of sending one wave through the
+    // guarded element-wise loads (measured on 4093 trajectories: 6.43 -> 5.03 us: that one wave was the kernel's critical path).
+    // Batches smaller than one tile keep the guarded path.
+    auto tile_base = [&](int tile) {
+        const int b_ = tile * TILE;
+        return (a.n_traj >= TILE && b_ + TILE > a.n_traj) ? a.n_traj - TILE : b_;
+    };
+    constexpr int DMA_AUX = LPT >= 8 ? 2 : 0;
     auto issue_tile = [&](int tile, int buf) {
-        const int base = tile * TILE;
+        const int base = tile_base(tile);
         const int nv = min(TILE, a.n_traj - base);
         double* s = s_in[buf];
         if (nv == TILE) {
-            dma_tile<C::WP_D>(a.waypoints + (size_t)base * NK * 3, s, lane);
-            dma_tile<C::T_D>(a.times + (size_t)base * M, s + C::T_OFF, lane);
-            dma_tile<C::BC_D>(a.bc + (size_t)base * 2 * ND * 3, s + C::BC_OFF, lane);
+            dma_tile<C::WP_D, DMA_AUX>(a.waypoints + (size_t)base * NK * 3, s, lane);
+            dma_tile<C::T_D, DMA_AUX>(a.times + (size_t)base * M, s + C::T_OFF, lane);
+            dma_tile<C::BC_D, DMA_AUX>(a.bc + (size_t)base * 2 * ND * 3, s + C::BC_OFF, lane);
         } else {
             load_tile_guarded<C::WP_D>(a.waypoints + (size_t)base * NK * 3, nv * NK * 3, s, lane, 0.0);
             load_tile_guarded<C::T_D>(a.times + (size_t)base * M, nv * M, s + C::T_OFF, lane, 1.0);
@@ -146,12 +164,19 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
     };
 
     int buf = 0;
+    UAVQP_STAMP(5);
     if ((int)blockIdx.x < n_tiles) issue_tile(blockIdx.x, 0);
-    wait_vmcnt0();
-    wave_lds_sync();
+    UAVQP_STAMP(6);
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
-        const int base = tile * TILE;
+        // The wait for the FIRST tile sits inside the loop: everything loop-invariant (lane indices, table constants, addresses --
+        // ~130 instructions) lands in the loop pre-header, i.e. between the issue of the first loads and this wait, instead of
+        // behind it (measured: load wait 2150 -> 1230 cycles per wave, 5.49 -> 5.05 us on the 4096 batch).
+        if (tile == (int)blockIdx.x) {
+            wait_vmcnt0();
+            wave_lds_sync();
+        }
+        const int base = tile_base(tile);
         const int nv = min(TILE, a.n_traj - base);
         UAVQP_STAMP(0);
         // prefetch the next tile into the other buffer; it lands while this tile is eliminated
@@ -198,14 +223,25 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
         }
         // (LPT == 2: the own durations stay in registers for the emission -- the duration tile has a row stride of M doubles, a
         // 4-way bank conflict per read for M = 8)
-        double Town[LPT == 2 ? mL : 1];
+        // (LPT == 8: also their inverse powers T^-R..T^-(2R-1), which SegBlocks::build computes anyway and the emission needs again)
+        constexpr bool KEEP_T = LPT == 2 || LPT == 8;
+        double Town[KEEP_T ? mL : 1], Tip[LPT == 8 ? mL : 1][R];
 #pragma unroll
-        for (int j = 0; j < (LPT == 2 ? mL : 1); ++j) Town[j] = 1.0;
+        for (int j = 0; j < (KEEP_T ? mL : 1); ++j) Town[j] = 1.0;
+#pragma unroll
+        for (int j = 0; j < (LPT == 8 ? mL : 1); ++j)
+#pragma unroll
+            for (int k = 0; k < R; ++k) Tip[j][k] = 1.0;
         SegBlocks<R> sa;
         {
             const double t0 = Tof(0);
             Town[0] = t0;
-            sa.build(t0);
+            double ipw[NC];
+            sa.build(t0, ipw);
+            if constexpr (LPT == 8) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) Tip[0][k] = ipw[R + k];
+            }
         }
         double pb[NAX], dpa[NAX];
 #pragma unroll
@@ -219,8 +255,13 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                 SegBlocks<R> sb;
                 {
                     const double tj = Tof(j);
-                    if constexpr (LPT == 2) Town[j] = tj;
-                    sb.build(tj);
+                    if constexpr (KEEP_T) Town[j] = tj;
+                    double ipw[NC];
+                    sb.build(tj, ipw);
+                    if constexpr (LPT == 8) {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) Tip[j][k] = ipw[R + k];
+                    }
                 }
                 double dpb[NAX];
 #pragma unroll
@@ -344,9 +385,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
         double* __restrict__ out = a.coeff + (size_t)base * 3 * M * NC;
 
         if constexpr (LPT >= 8) {
-            // one axis per lane pair: coefficients go straight from registers to HBM (4 x 16 B per segment);
-            // at the batch sizes this shape is used for, store efficiency is irrelevant, latency is not.
-            // Back-substitution first (in place, h[j] <- y_j), so that the mL segment evaluations below are
+            // one axis per lane pair.  Back-substitution first (in place, h[j] <- y_j), so that the mL segment evaluations below are
             // independent of each other and the scheduler can overlap their dependent FP64 chains.
 #pragma unroll
             for (int j = mL - 1; j >= 1; --j) {
@@ -361,17 +400,66 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                 }
             }
             // LPT == 16: two lane pairs per (trajectory, axis) repeat elimination and back-substitution and split the EMISSION --
-            // pair `sub` evaluates and stores the own segments sub * H .. sub * H + H - 1 (selects between the two compile-time
-            // candidates, one instruction stream): 4 trajectories per wave, so a 4096-trajectory batch fills all 1024 SIMDs and
-            // the longest part of the wave (emission: ~60 % of its cycles) is halved.
+            // pair `sub` evaluates the own segments sub * H .. sub * H + H - 1 (selects between the two compile-time candidates, one
+            // instruction stream): 4 trajectories per wave, a 4096-trajectory batch fills all 1024 SIMDs.
+            //
+            // Copy-out, software-pipelined (what the per-wave timelines of tools/ubench/tw asked for: a vector-memory store costs the
+            // wave ~100 cycles of issue, sixteen scattered quarter-chunk stores per lane were 1100 of the emission's 3400 cycles and left
+            // 6.3 MB dirty in L2 for the kernel boundary to write back):
+            //   * the NC-double chunk a lane produces in step s goes to its own LDS row at the end of the step;
+            //   * at the START of step s + 1 the wave reads the 48 rows back linearly (16 bytes per lane: whole chunks from adjacent
+            //     lanes) and its NIT write-through stores are interleaved with that step's arithmetic (sched_group_barrier): only the
+            //     last step's stores are exposed;
+            //   * buffer stores through a per-tile descriptor: pieces of an invalid trajectory, of a lane without a segment in that
+            //     step (odd M) and -- for batches smaller than a tile -- of trajectories past the end get an out-of-range offset and
+            //     are dropped by the hardware: no branch, no sink traffic.
+            // 4096 x (M = 8, r = 4), us per launch over rotating buffers: 6.45 (direct stores) -> 5.80 (two-step chunks through LDS,
+            // write-through) -> 5.52 (this) for 8 lanes per trajectory, 5.30 for 16.
             constexpr int NSUB = LPT / 8, H = (mL + NSUB - 1) / NSUB;
+            constexpr int RPT = 6 * NSUB, ROWS = C::ROWS8, RS = C::RS8, PPR = NC / 2, NP = ROWS * PPR, NIT = (NP + 63) / 64;
+            const unsigned tile_bytes = (unsigned)nv * 3u * M * NC * 8u;
+            const unsigned long long obase = (unsigned long long)out;
+            const unsigned ob_lo = __builtin_amdgcn_readfirstlane((unsigned)obase), ob_hi = __builtin_amdgcn_readfirstlane((unsigned)(obase >> 32));
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)ob_hi << 32) | ob_lo), 0,
+                                                                __builtin_amdgcn_readfirstlane(tile_bytes), 0x00020000);
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            unsigned poff[NIT];   // byte offset of this lane's piece `it` without the segment term; 0xFFFFFFF0 = never stored
+            int prow[NIT], pjv[NIT], pm[NIT];
+            bool prev[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int g = it * 64 + lane;
+                const int row = g / PPR, col = g - row * PPR;
+                const int ctl = row / RPT, rem = row - ctl * RPT, csub = rem / 6, rem2 = rem - csub * 6, cax = rem2 >> 1;
+                prev[it] = rem2 & 1;
+                pjv[it] = csub * H;
+                pm[it] = prev[it] ? mR : mL;
+                prow[it] = g < NP ? row : 0;
+                const bool keep = g < NP && ((okmask >> (LPT * (ctl < TILE ? ctl : 0))) & 1ull);
+                poff[it] = keep ? (unsigned)((((ctl * 3 + cax) * M) * NC + 2 * col) * 8) : 0xFFFFFFF0u;
+            }
+            const int myrow = axl < 3 ? tlc * RPT + sub * 6 + axl * 2 + isR : ROWS + (lane & 15);
+            auto flush = [&](int sp) {   // copy-out of step sp: NIT LDS reads, NIT stores
+                double2 v[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const double2*>(s_out + prow[it] * RS + 2 * ((it * 64 + lane) % PPR));
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int jv = pjv[it] + sp;                                  // own segment of the producing lane
+                    const int cseg = prev[it] ? (M - 1 - jv) : jv;
+                    const unsigned off = (jv < pm[it] && poff[it] != 0xFFFFFFF0u) ? poff[it] + (unsigned)(cseg * NC * 8) : 0xFFFFFFF0u;
+                    u32x4 w;
+                    w.x = (unsigned)__double2loint(v[it].x); w.y = (unsigned)__double2hiint(v[it].x);
+                    w.z = (unsigned)__double2loint(v[it].y); w.w = (unsigned)__double2hiint(v[it].y);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, off, 0, 17 /* sc0 sc1: write-through, nothing left dirty for the kernel boundary */);
+                }
+            };
 #pragma unroll
             for (int s = 0; s < H; ++s) {
+                if (s > 0) flush(s - 1);
                 const int j = s + sub * H;
                 const bool act = (j < m);
                 const int jc = act ? j : (m > 0 ? m - 1 : 0);
-                const double Tj = Tof(jc);
-                const double itj = fast_rcp(Tj);
                 const double pj = pos(jc, 0), pj1 = pos(jc + 1, 0);
                 double ys[ND], ye[ND], c8[NC];
 #pragma unroll
@@ -387,14 +475,37 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                     ys[d] = isR ? fs * yj1 : yj;
                     ye[d] = isR ? fs * yj : yj1;
                 }
-                segment_coeffs<R>(isR ? pj1 : pj, ys, isR ? pj : pj1, ye, Tj, itj, c8);
-                if (act) finite = finite && (fabs(c8[NC - 1]) < INFINITY) && (fabs(c8[R]) < INFINITY);
-                const int seg = isR ? (M - 1 - jc) : jc;
-                if (ok && act) {  // idle pairs / invalid trajectories simply do not store (no LDS-DMA is pending here)
-                    double* dst = out + (((size_t)tlc * 3 + ax0) * M + seg) * NC;
+                if constexpr (LPT == 8) {
+                    // the duration and its inverse powers were kept from the elimination (SegBlocks::build): no reciprocal, no power chain
+                    double ipj[NC];
 #pragma unroll
-                    for (int k = 0; k < NC; k += 2) store_pair(dst + k, make_double2(c8[k], c8[k + 1]));
+                    for (int k = 0; k < R; ++k) { ipj[k] = 1.0; ipj[R + k] = Tip[s][k]; }
+                    segment_coeffs_ip<R>(isR ? pj1 : pj, ys, isR ? pj : pj1, ye, Town[s], ipj, c8);
+                } else {
+                    const double Tj = Tof(jc);
+                    segment_coeffs<R>(isR ? pj1 : pj, ys, isR ? pj : pj1, ye, Tj, fast_rcp(Tj), c8);
                 }
+                if (act) finite = finite && (fabs(c8[NC - 1]) < INFINITY) && (fabs(c8[R]) < INFINITY);
+                if (s > 0) {
+                    // the previous step's copy-out between this step's arithmetic: LDS reads first, then one store per ~24 VALU instructions
+                    __builtin_amdgcn_sched_group_barrier(0x100, NIT, 0);
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        __builtin_amdgcn_sched_group_barrier(0x2, 24, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x40, 1, 0);
+                    }
+                }
+                {
+                    // (idle pairs and lanes without a segment in this step write too -- rows / chunks that are never copied out)
+                    double* so = s_out + myrow * RS;
+#pragma unroll
+                    for (int k = 0; k < NC; k += 2) *reinterpret_cast<double2*>(so + k) = make_double2(c8[k], c8[k + 1]);
+                }
+                // single-wave workgroup: LDS operations execute in issue order; this only pins the compiler's order of the accesses
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (s == H - 1) flush(s);
             }
         } else {
             // ---------------- chunk mode (LPT == 2): CH own segments x one axis per emission unit ----------------
