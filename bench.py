@@ -240,7 +240,7 @@ def main():
         if args.config == 5:
             # the whole device pipeline per step (uav_motion_planning_amd/pipeline.py): plain solve -> corridor boxes from the pillar
             # cloud (SE(3) robot ellipsoid) -> <= 5 x (warm-started corridor solve + time re-allocation) -> grid collision check
-            # (+ repair of what it flags).  Host-sequenced (it synchronises between rounds): no graph, no pipelined sub-record.
+            # (+ repair of what it flags).  Host-sequenced in C++ behind the C ABI (one counter read-back per round): no graph, no pipelined sub-record.
             obstacles = W.pillar_cloud(5, n_pillars=60, resolution=0.2)       # the same map on every rank (seeded)
             bytes_local += int(sum(8 * 2 * 3 * (int(m) - 1) for m in Ms))     # corridor rows
             args.graph = 0
@@ -279,7 +279,11 @@ def main():
             s["T"].copy_(T0)                       # the re-allocation stretches the durations in place
             if "grid" not in pipe_state:           # one grid per map, built once (as a planner would)
                 pipe_state["grid"] = c.obstacle_grid_build(d_obs, d_obs.shape[0], 0.4 + 0.1)
-            res = corridor_pipeline_device(c, r, d_so, s["wp"], s["T"], s["bc"], d_obs, mx, grid=pipe_state["grid"], repair_rounds=0)   # BASELINE config 5 = boxes + <= 5 outer rounds (+ the check); the repair rounds are the pipeline's own extra
+            # BASELINE config 5 = boxes + <= 5 outer rounds (+ the check); the repair rounds are the pipeline's own extra.  ONE C-ABI call
+            # (uavqp_corridor_pipeline_device: the sequencing is host C++), output buffers reused from step to step
+            res = corridor_pipeline_device(c, r, d_so, s["wp"], s["T"], s["bc"], d_obs, mx, grid=pipe_state["grid"], repair_rounds=0,
+                                           out=pipe_state.get("out"))
+            pipe_state["out"] = {k: res[k] for k in ("coeff", "status", "corr_lo", "corr_hi", "first_hit")}
             s["out"], pipe_state["status"], pipe_state["res"] = res["coeff"], res["status"], res
             return
         c.solve_batch_device(r, n_local, uni, mx, d_so, s["wp"], s["T"], s["bc"], s["out"], d_st)

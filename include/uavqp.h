@@ -171,6 +171,9 @@ int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const double* pos_1d
  *                          lo == hi pins that waypoint (so lo = hi = waypoints reproduces uavqp_solve_batch_device).
  *   d_waypoints            start/end positions, and the initial guess (clipped into the box) elsewhere.
  *   d_iters_out            [n_traj] active-set iterations (max over axes), may be NULL.
+ * Asynchronous for uniform batches; for a RAGGED batch the device entry points read the last CSR offset back first (4 bytes, one
+ * stream synchronisation: workspaces are sized by the batch's total segment count) -- the host entries and the pipeline, which know
+ * the total, do not.
  * Exact primal active-set solve in the Hermite variables; status UAVQP_MAX_ITER_REACHED
  * (uavqp_settings.max_iter, default 8 M + 20 iterations) leaves a feasible, smooth, possibly sub-optimal trajectory. */
 int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
@@ -217,15 +220,16 @@ int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  * working set is no longer on its bound after the solve -- the working set's KKT system has become singular to working
  * precision (rows that no free unknown can move, e.g. a position sample right behind the fixed start state).  A single-segment
  * trajectory has no free unknown at all: its rows are only checked (violated -> UAVQP_MAX_ITER_REACHED).  M <= 63.
- * Asynchronous. */
+ * Asynchronous for uniform batches; a ragged batch costs one 4-byte read-back + stream synchronisation (see uavqp_solve_corridor_batch_device). */
 int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                   const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
                                   const double* d_bc, const double* d_corr_lo, const double* d_corr_hi, int rows_per_segment,
                                   const double* d_row_tau, const int32_t* d_row_deriv, const double* d_row_lo,
                                   const double* d_row_hi, double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
                                   uint64_t* d_active_out);
-/* The same solve from HOST pointers (staged through device memory, synchronous; a trajectory that is not solved comes back as
- * zeros): what a caller of the reference's solver interface has -- it hands its rows to OSQP from host memory,
+/* The same solve from HOST pointers (staged through device memory, synchronous; a trajectory flagged UAVQP_INVALID_INPUT comes back
+ * as zeros, a UAVQP_MAX_ITER_REACHED one carries the minimiser of its last regular working set -- which need NOT satisfy the
+ * remaining rows: check the status, not the coefficients): what a caller of the reference's solver interface has -- it hands its rows to OSQP from host memory,
  * minimum_control.cpp:164-170. */
 int uavqp_solve_rows_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                 const int32_t* seg_offsets, const double* waypoints, const double* times, const double* bc,
@@ -333,6 +337,61 @@ int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_traj, int unif
                                      int n_rows, const double* d_waypoints, const double* d_times, const double* d_coeff,
                                      const double* d_obstacles, int n_obs, double robot_r, double robot_h, double h_max,
                                      double* d_corr_lo, double* d_corr_hi, double* d_clearance);
+
+/* BASELINE config 5 as ONE call (north-star extension: "SE(3) ellipsoid-collision corridor + time-reallocation outer loop"; the
+ * reference has no such loop -- constant 1.0 s per segment, test_minimum_jerk.cpp:65-71, every row an equality,
+ * minimum_control.cpp:98-125 -- so parity is per inner solve, SURVEY.md section 8-a').  Host-side C++ sequencing of the entry points
+ * above on device buffers:
+ *   uavqp_solve_batch_device (the reference's equality problem) -> uavqp_corridor_from_cloud_device (boxes, attitude of that solve)
+ *   -> at most max_rounds x (uavqp_solve_corridor_warm_device, working set carried over + uavqp_time_reallocate_device; the loop ends
+ *   as soon as a re-allocation stretches nothing; if the cap is reached with durations still changing, one more solve makes the
+ *   coefficients match d_times) -> uavqp_ellipsoid_check_grid_device on check_samples samples per trajectory (ONE time grid for the
+ *   batch: dt = longest total duration / (check_samples - 1)) -> at most repair_rounds x (the boxes of every colliding trajectory
+ *   are halved towards its waypoints -- in the last repair round collapsed onto them: the reference's equality rows --, warm re-solve,
+ *   one re-allocation, re-solve if that stretched anything, check again).  A colliding trajectory with an interior waypoint whose box
+ *   is degenerate (the cloud leaves no room around the searcher's waypoint) cannot be helped by narrower boxes: counted, not repaired.
+ * Loop control is data dependent: one 64-byte device-to-host copy and one stream synchronisation per round; the call returns with
+ * the stream idle (SYNCHRONOUS).
+ *   total_segments      sum_b M_b (the host knows it: it sized the buffers); uniform batches: n_traj * uniform_segments
+ *   d_times             [total_segments] IN / OUT: stretched in place by the re-allocation (never shrunk)
+ *   grid                uniform grid over d_obstacles with cell = check radius + 0.1 (uavqp_obstacle_grid_build_device), or NULL: built
+ *                       and destroyed inside the call (a planner builds it once per map)
+ *   d_corr_lo / d_corr_hi [total_segments + n_traj][3] OUT: the boxes of the final solve
+ *   d_first_hit         [n_traj] OUT (may be NULL): first colliding sample of the final check, check_samples = collision-free
+ *   params              uavqp_default_pipeline_params fills the launch-file values of the reference's kino-A* test
+ *                       (test_kino_astar_searching.launch:49-57: robot 0.4 x 0.1 m, 7 m/s, 10 m/s^2); check_samples = 0 skips
+ *                       the check and the repair; check_robot_r / _h > 0 check with another ellipsoid than the boxes were built with
+ *   result              (may be NULL) rounds run, repair rounds run, trajectories still stretching at the cap, colliding at the first
+ *                       check / of those with a blocked waypoint / colliding at the last check, trajectories not UAVQP_SOLVED, the dt
+ *                       of the check grid. */
+typedef struct uavqp_pipeline_params {
+    int32_t struct_size;
+    int32_t max_rounds;
+    double robot_r, robot_h, h_max;
+    double v_max, a_max;
+    int32_t samples_per_seg;
+    int32_t check_samples;
+    double max_stretch;
+    int32_t repair_rounds;
+    int32_t reserved_;
+    double check_robot_r, check_robot_h;
+} uavqp_pipeline_params;
+typedef struct uavqp_pipeline_result {
+    int32_t rounds, repairs, still_stretching, colliding_before_repair, colliding_with_blocked_waypoints, colliding_after, unsolved, reserved_;
+    double check_dt;
+} uavqp_pipeline_result;
+void uavqp_default_pipeline_params(uavqp_pipeline_params* out);
+int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments, int total_segments,
+                                   const int32_t* d_seg_offsets, const double* d_waypoints, double* d_times, const double* d_bc,
+                                   const double* d_obstacles, int n_obs, const uavqp_grid* grid, const uavqp_pipeline_params* params,
+                                   double* d_coeff_out, int32_t* d_status_out, double* d_corr_lo, double* d_corr_hi,
+                                   int32_t* d_first_hit, uavqp_pipeline_result* result);
+/* The same from HOST pointers (staged through device memory; times is updated in place; corr_lo / corr_hi / first_hit may be NULL):
+ * what a C++ planner that keeps its paths in host memory calls -- TrajOptimizer::solvePipeline. */
+int uavqp_corridor_pipeline_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments, const int32_t* seg_offsets,
+                                 const double* waypoints, double* times, const double* bc, const double* obstacles, int n_obs,
+                                 const uavqp_pipeline_params* params, double* coeff_out, int32_t* status_out, double* corr_lo,
+                                 double* corr_hi, int32_t* first_hit, uavqp_pipeline_result* result);
 
 /* quadrotor_msgs/PolynomialTrajectory packer.  HOST function, no ctx, no device: turns ONE solved
  * trajectory (the [axis][segment][2r] slice of coeff_out that belongs to it) into the arrays of the message the rest of the

@@ -52,6 +52,9 @@ SYMBOLS = (
     "uavqp_obstacle_grid_build_device",
     "uavqp_obstacle_grid_destroy",
     "uavqp_ellipsoid_check_grid_device",
+    "uavqp_default_pipeline_params",
+    "uavqp_corridor_pipeline_device",
+    "uavqp_corridor_pipeline_host",
     "uavqp_pack_polynomial_trajectory",
     "uavqp_shard_bounds",
     "uavqp_shard_bounds_ragged",
@@ -78,6 +81,21 @@ class Settings(ctypes.Structure):
                 ("generic_lanes_per_traj", ctypes.c_int32), ("generic_waves_per_cu", ctypes.c_int32),
                 ("corridor_pdas_rounds", ctypes.c_int32), ("corridor_initial_guess", ctypes.c_int32), ("realloc_dead_band", ctypes.c_double),
                 ("realloc_overshoot", ctypes.c_double)]
+
+
+class PipelineParams(ctypes.Structure):
+    """uavqp_pipeline_params of include/uavqp.h."""
+    _fields_ = [("struct_size", ctypes.c_int32), ("max_rounds", ctypes.c_int32), ("robot_r", ctypes.c_double), ("robot_h", ctypes.c_double),
+                ("h_max", ctypes.c_double), ("v_max", ctypes.c_double), ("a_max", ctypes.c_double), ("samples_per_seg", ctypes.c_int32),
+                ("check_samples", ctypes.c_int32), ("max_stretch", ctypes.c_double), ("repair_rounds", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+                ("check_robot_r", ctypes.c_double), ("check_robot_h", ctypes.c_double)]
+
+
+class PipelineResult(ctypes.Structure):
+    """uavqp_pipeline_result of include/uavqp.h."""
+    _fields_ = [("rounds", ctypes.c_int32), ("repairs", ctypes.c_int32), ("still_stretching", ctypes.c_int32),
+                ("colliding_before_repair", ctypes.c_int32), ("colliding_with_blocked_waypoints", ctypes.c_int32),
+                ("colliding_after", ctypes.c_int32), ("unsolved", ctypes.c_int32), ("reserved_", ctypes.c_int32), ("check_dt", ctypes.c_double)]
 
 
 def build(force=False):
@@ -141,6 +159,12 @@ def lib():
     L.uavqp_obstacle_grid_destroy.argtypes = [vp, vp]
     L.uavqp_ellipsoid_check_grid_device.argtypes = [vp, i32, i32, i32, ip, dp, dp, i32, ctypes.c_double, ctypes.c_double, vp,
                                                     ctypes.c_double, ctypes.c_double, ip, vp]
+    L.uavqp_default_pipeline_params.argtypes = [ctypes.POINTER(PipelineParams)]
+    L.uavqp_default_pipeline_params.restype = None
+    L.uavqp_corridor_pipeline_device.argtypes = [vp, i32, i32, i32, i32, i32, ip, dp, dp, dp, dp, i32, vp, ctypes.POINTER(PipelineParams),
+                                                 dp, ip, dp, dp, ip, ctypes.POINTER(PipelineResult)]
+    L.uavqp_corridor_pipeline_host.argtypes = [vp, i32, i32, i32, i32, ip, dp, dp, dp, dp, i32, ctypes.POINTER(PipelineParams), dp, ip, dp, dp,
+                                               ip, ctypes.POINTER(PipelineResult)]
     L.uavqp_pack_polynomial_trajectory.argtypes = [i32, i32, dp, dp, dp, dp, dp, dp, vp, vp, vp]
     L.uavqp_shard_bounds.argtypes = [i32, i32, ip]
     L.uavqp_shard_bounds_ragged.argtypes = [ip, i32, i32, ip]

@@ -64,7 +64,7 @@ class TrajOptimizer {
     // slot.  Needs setTimeAllocation first (sizes).  rows_per_segment = 0 removes them.
     void setRows(int rows_per_segment, const double* tau, const int32_t* deriv, const double* lo, const double* hi) {
         rows_k_ = rows_per_segment;
-        if (rows_k_ <= 0) { rows_k_ = 0; return; }
+        if (rows_k_ <= 0 || !tau || !deriv || !lo || !hi) { rows_k_ = 0; return; }   // (null arrays: no rows, never a wild read)
         const size_t n = T_.size() * static_cast<size_t>(rows_k_);
         row_tau_.assign(tau, tau + n);
         row_deriv_.assign(deriv, deriv + n);
@@ -82,6 +82,10 @@ class TrajOptimizer {
 
     bool solve() {
         if (n_traj_ <= 0 || T_.size() != static_cast<size_t>(seg_offsets_[n_traj_])) return false;
+        if (!rowsMatchBatch() || !corridorMatchesBatch()) {   // rows / boxes installed for another batch size: refuse, never read past them
+            std::cout << "solver solve failed! (rows or corridor arrays do not match the current batch)" << std::endl;
+            return false;
+        }
         if (!ensureContext()) return false;
         if (bc_.empty()) bc_.assign(static_cast<size_t>(n_traj_) * 2 * (order_ - 1) * 3, 0.0);
         coef_.assign(static_cast<size_t>(3) * 2 * order_ * seg_offsets_[n_traj_], 0.0);
@@ -112,6 +116,38 @@ class TrajOptimizer {
     int segOffset(int traj) const { return seg_offsets_[traj]; }
     const std::vector<int32_t>& status() const { return status_; }
 
+    // BASELINE config 5 as one call (include/uavqp.h uavqp_corridor_pipeline_host): plain solve -> corridor boxes from the obstacle cloud
+    // (SE(3) robot ellipsoid of KinoAstar::isCollisionFree) -> <= max_rounds x (corridor solve + time re-allocation) -> collision check
+    // -> repair.  obstacles [n_obs][3].  On return: getPolyCoeff() = the final polynomials, timeAllocation() = the stretched durations,
+    // corridorLo() / corridorHi() = the boxes of the final solve, firstHit() = first colliding sample per trajectory (check_samples =
+    // free), pipelineResult() = the summary.  true iff the call succeeded and every trajectory is SOLVED (collisions are reported, not
+    // turned into failure: a planner decides what to do with a colliding candidate).
+    bool solvePipeline(const double* obstacles, int n_obs, const uavqp_pipeline_params* params = nullptr) {
+        if (n_traj_ <= 0 || T_.size() != static_cast<size_t>(seg_offsets_[n_traj_])) return false;
+        if (!ensureContext()) return false;
+        if (bc_.empty()) bc_.assign(static_cast<size_t>(n_traj_) * 2 * (order_ - 1) * 3, 0.0);
+        uavqp_pipeline_params pp;
+        if (params) pp = *params; else uavqp_default_pipeline_params(&pp);
+        coef_.assign(static_cast<size_t>(3) * 2 * order_ * seg_offsets_[n_traj_], 0.0);
+        status_.assign(n_traj_, 0);
+        lo_.assign(wp_.size(), 0.0);
+        hi_.assign(wp_.size(), 0.0);
+        first_hit_.assign(n_traj_, pp.check_samples);
+        pipe_result_ = uavqp_pipeline_result{};
+        const int rc = uavqp_corridor_pipeline_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(), obstacles, n_obs,
+                                                    &pp, coef_.data(), status_.data(), lo_.data(), hi_.data(), first_hit_.data(), &pipe_result_);
+        if (rc != UAVQP_OK) {
+            std::cout << "solver solve failed! (" << uavqp_last_error() << ")" << std::endl;
+            return false;
+        }
+        return pipe_result_.unsolved == 0;
+    }
+    const std::vector<double>& timeAllocation() const { return T_; }
+    const std::vector<double>& corridorLo() const { return lo_; }
+    const std::vector<double>& corridorHi() const { return hi_; }
+    const std::vector<int32_t>& firstHit() const { return first_hit_; }
+    const uavqp_pipeline_result& pipelineResult() const { return pipe_result_; }
+
     // ---- multi-GPU: one process (or thread) per GPU, every rank holds the whole batch description, solves its contiguous shard
     // (balanced by segment count) on its device and ends with ALL coefficients: uavqp_shard_bounds_ragged, uavqp_comm_create,
     // uavqp_solve_*_batch_device on views, uavqp_allgather_coeffs / _status (RCCL over xGMI).  Rank 0 draws the id and ships it to
@@ -130,6 +166,10 @@ class TrajOptimizer {
 #ifdef UAVQP_TRAJ_OPTIMIZER_HAS_HIP
     bool solveSharded() {
         if (n_traj_ <= 0 || world_ < 1 || !ctx_ || T_.size() != static_cast<size_t>(seg_offsets_[n_traj_])) return false;
+        if (!rowsMatchBatch() || !corridorMatchesBatch()) {
+            std::cout << "solver solve failed! (rows or corridor arrays do not match the current batch)" << std::endl;
+            return false;
+        }
         if (bc_.empty()) bc_.assign(static_cast<size_t>(n_traj_) * 2 * (order_ - 1) * 3, 0.0);
         std::vector<int32_t> bounds(world_ + 1);
         if (uavqp_shard_bounds_ragged(seg_offsets_.data(), n_traj_, world_, bounds.data()) != UAVQP_OK) return false;
@@ -148,8 +188,8 @@ class TrajOptimizer {
             if (g < rank_) c_off += static_cast<size_t>(c_counts[g]);
         }
         const size_t n_wp = static_cast<size_t>(3) * ((s1 - s0) + nl), n_t = static_cast<size_t>(s1 - s0), n_bc = static_cast<size_t>(nl) * 2 * (order_ - 1) * 3;
-        int32_t *d_so = nullptr, *d_st = nullptr;
-        double *d_wp = nullptr, *d_T = nullptr, *d_bc = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_coef = nullptr;
+        int32_t *d_so = nullptr, *d_st = nullptr, *d_rd = nullptr;
+        double *d_wp = nullptr, *d_T = nullptr, *d_bc = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_coef = nullptr, *d_rt = nullptr, *d_rl = nullptr, *d_rh = nullptr;
         bool ok = hipSetDevice(device_) == hipSuccess;
         auto up = [&](void** d, const void* h, size_t bytes) {
             ok = ok && hipMalloc(d, bytes ? bytes : 8) == hipSuccess && (bytes == 0 || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess);
@@ -162,13 +202,26 @@ class TrajOptimizer {
             up(reinterpret_cast<void**>(&d_lo), lo_.data() + static_cast<size_t>(3) * (s0 + b0), sizeof(double) * n_wp);
             up(reinterpret_cast<void**>(&d_hi), hi_.data() + static_cast<size_t>(3) * (s0 + b0), sizeof(double) * n_wp);
         }
+        if (rows_k_ > 0) {   // the shard's general inequality rows (per segment, rows_k_ slots)
+            const size_t k = static_cast<size_t>(rows_k_);
+            up(reinterpret_cast<void**>(&d_rt), row_tau_.data() + k * s0, sizeof(double) * k * n_t);
+            up(reinterpret_cast<void**>(&d_rd), row_deriv_.data() + k * s0, sizeof(int32_t) * k * n_t);
+            up(reinterpret_cast<void**>(&d_rl), row_lo_.data() + 3 * k * s0, sizeof(double) * 3 * k * n_t);
+            up(reinterpret_cast<void**>(&d_rh), row_hi_.data() + 3 * k * s0, sizeof(double) * 3 * k * n_t);
+        }
         ok = ok && hipMalloc(reinterpret_cast<void**>(&d_coef), sizeof(double) * nc * tot) == hipSuccess &&
              hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(int32_t) * n_traj_) == hipSuccess;
+        // the device kernels leave a trajectory they flag UAVQP_INVALID_INPUT untouched: zeros, as the host entry points give
+        ok = ok && hipMemset(d_coef, 0, sizeof(double) * nc * tot) == hipSuccess && hipMemset(d_st, 0, sizeof(int32_t) * n_traj_) == hipSuccess;
         int rc = ok ? UAVQP_OK : UAVQP_ERR_ALLOC;
         if (ok && nl > 0) {   // this rank's shard, written straight into its slice of the full buffers
-            rc = lo_.empty()
-                ? uavqp_solve_batch_device(ctx_, order_, nl, 0, mmax, d_so, d_wp, d_T, d_bc, d_coef + c_off, d_st + b0)
-                : uavqp_solve_corridor_batch_device(ctx_, order_, nl, 0, mmax, d_so, d_wp, d_T, d_bc, d_lo, d_hi, d_coef + c_off, d_st + b0, nullptr);
+            if (rows_k_ > 0)
+                rc = uavqp_solve_rows_batch_device(ctx_, order_, nl, 0, mmax, d_so, d_wp, d_T, d_bc, d_lo, d_hi, rows_k_, d_rt, d_rd, d_rl, d_rh,
+                                                   d_coef + c_off, d_st + b0, nullptr, nullptr);
+            else if (lo_.empty())
+                rc = uavqp_solve_batch_device(ctx_, order_, nl, 0, mmax, d_so, d_wp, d_T, d_bc, d_coef + c_off, d_st + b0);
+            else
+                rc = uavqp_solve_corridor_batch_device(ctx_, order_, nl, 0, mmax, d_so, d_wp, d_T, d_bc, d_lo, d_hi, d_coef + c_off, d_st + b0, nullptr);
         }
         if (rc == UAVQP_OK) rc = uavqp_allgather_coeffs(ctx_, d_coef + c_off, c_counts.data(), d_coef);
         if (rc == UAVQP_OK) rc = uavqp_allgather_status(ctx_, d_st + b0, t_counts.data(), d_st);
@@ -180,7 +233,8 @@ class TrajOptimizer {
                  hipMemcpy(status_.data(), d_st, sizeof(int32_t) * n_traj_, hipMemcpyDeviceToHost) == hipSuccess;
         }
         for (void* p : {static_cast<void*>(d_so), static_cast<void*>(d_st), static_cast<void*>(d_wp), static_cast<void*>(d_T), static_cast<void*>(d_bc),
-                        static_cast<void*>(d_lo), static_cast<void*>(d_hi), static_cast<void*>(d_coef)})
+                        static_cast<void*>(d_lo), static_cast<void*>(d_hi), static_cast<void*>(d_coef), static_cast<void*>(d_rt), static_cast<void*>(d_rd),
+                        static_cast<void*>(d_rl), static_cast<void*>(d_rh)})
             if (p) (void)hipFree(p);
         if (rc != UAVQP_OK || !ok) {
             std::cout << "solver solve failed! (" << uavqp_last_error() << ")" << std::endl;
@@ -192,6 +246,12 @@ class TrajOptimizer {
 #endif
 
   private:
+    bool rowsMatchBatch() const {
+        if (rows_k_ <= 0) return true;
+        const size_t n = T_.size() * static_cast<size_t>(rows_k_);
+        return row_tau_.size() == n && row_deriv_.size() == n && row_lo_.size() == 3 * n && row_hi_.size() == 3 * n;
+    }
+    bool corridorMatchesBatch() const { return lo_.empty() || (lo_.size() == wp_.size() && hi_.size() == wp_.size()); }
     bool ensureContext() {
         if (ctx_) return true;
         if (uavqp_create(&ctx_, device_) != UAVQP_OK) {
@@ -213,8 +273,9 @@ class TrajOptimizer {
     uavqp_ctx* ctx_ = nullptr;
     std::vector<int32_t> seg_offsets_, status_;
     std::vector<double> wp_, T_, bc_, coef_, lo_, hi_, row_tau_, row_lo_, row_hi_;
-    std::vector<int32_t> row_deriv_;
+    std::vector<int32_t> row_deriv_, first_hit_;
     int rows_k_ = 0;
+    uavqp_pipeline_result pipe_result_{};
 };
 
 }  // namespace traj_optimization

@@ -738,6 +738,10 @@ struct uavqp_ctx {
     void* h_axis = nullptr;
     void* d_axis = nullptr;
     size_t axis_bytes = 0;
+    // corridor pipeline (uavqp_pipeline.h): device scratch (counters, flags, working sets) and the pinned page its counters are read through
+    void* d_pipe = nullptr;
+    size_t pipe_bytes = 0;
+    void* h_pipe = nullptr;
 };
 
 #define UAVQP_HIP(expr)                                                                          \
@@ -749,7 +753,7 @@ struct uavqp_ctx {
         }                                                                                        \
     } while (0)
 
-extern "C" const char* uavqp_version(void) { return "uavqp 0.2.0 (gfx950, float64)"; }
+extern "C" const char* uavqp_version(void) { return "uavqp 0.3.0 (gfx950, float64)"; }
 
 extern "C" void uavqp_default_settings(uavqp_settings* out) {
     if (!out) return;
@@ -860,6 +864,8 @@ extern "C" int uavqp_destroy(uavqp_ctx* ctx) {
     if (ctx->h_axis) (void)hipHostFree(ctx->h_axis);
     if (ctx->rows_warm) (void)hipFree(ctx->rows_warm);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_pipe) (void)hipFree(ctx->d_pipe);
+    if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return UAVQP_OK;
@@ -935,15 +941,14 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     // kernel, which touches memory 8 bytes at a time, takes the batch
     const bool aligned16 = ((((uintptr_t)d_waypoints) | ((uintptr_t)d_times) | ((uintptr_t)d_bc) | ((uintptr_t)d_coeff_out)) & 15u) == 0;
     if (uniform_segments > 0 && ctx->variant != 1 && aligned16) {
-        // Tile shape by batch size (measured on MI355X, 8-segment snap, us per launch for tiles 8 / 16 / 32:
-        // 4096: 6.0 / 7.5 / 8.2   8192: 8.7 / 8.5 / 9.4   16384: 14.1 / 9.7 / 10.0   32768: 23.8 / 17.5 / 12.6).
-        // One CU moves only ~10 B/clk, so a small batch is spread over all 256 CUs with fewer trajectories per
-        // wave; a large one wants the full-wave shape that does the least redundant work.
-        // Tile 4 (16 lanes per trajectory: emission split over two lane pairs per axis) was built for the 4096 headline batch --
-        // 1024 waves, every SIMD busy, 15 % fewer instructions per wave -- and measures 6.51 vs 6.47 us there (four waves per CU
-        // slow each other down by what the shorter wave gains); it wins only while the grid is small: 1024 trajectories 4.21 vs
-        // 4.59 us, 2048: 5.16 vs 5.03 us.
-        int tile = (n_traj <= 5 * ctx->num_cus) ? 4 : ((n_traj <= 28 * ctx->num_cus) ? 8 : (n_traj <= 72 * ctx->num_cus ? 16 : 32));
+        // Tile shape by batch size (measured on MI355X, 8-segment snap, us per launch over rotating buffers, tools/ubench/tw, round 3 --
+        // after the pipelined copy-out of the latency shapes; tiles 4 / 8 / 16 / 32):
+        //    1024: 4.00 / 4.44 / 7.4 / -      4096: 5.08 / 5.13 / 8.0 / -     5120: 6.62 / 5.14 / 8.4 / -     8192: 7.38 / 6.02 / 8.8 / -
+        //   16384: 11.9 / 9.1 / 10.4 / 10.5   24576: 16.4 / 12.3 / 15.9 / 12.2   32768: - / 16.2 / 16.9 / 15.4   65536: - / 34.4 / 31.6 / 25.4
+        // One CU moves only ~10 B/clk, so a small batch is spread over all CUs with fewer trajectories per wave (tile 4: 16 lanes per
+        // trajectory, every SIMD busy up to 16 trajectories per CU; tile 8: 8 lanes); a large one wants the full-wave shape that does
+        // the least redundant work.  Tile 16 no longer wins anywhere (it stays selectable through uavqp_set_variant).
+        int tile = (n_traj <= 16 * ctx->num_cus) ? 4 : ((n_traj <= 96 * ctx->num_cus) ? 8 : 32);
         if (ctx->tile_override) tile = ctx->tile_override;
         uavqp::twisted_fn fn = uavqp::find_twisted(r, uniform_segments, tile);
         if (fn) {
@@ -1268,11 +1273,14 @@ extern "C" int uavqp_traj_length_device(uavqp_ctx* ctx, int r, int n_traj, int u
     return UAVQP_OK;
 }
 
-extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
-                                                const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
-                                                const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
-                                                double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
-                                                uint64_t* d_active_set, int warm_start) {
+// total_segments < 0: unknown -- for a ragged batch the last CSR offset is then read back from the device (4 bytes, one stream
+// synchronisation); callers that know it (the host-pointer entries, the rows solver's second phase, the corridor pipeline) pass it
+// and the call stays asynchronous.
+static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                              const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                              const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
+                              double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
+                              uint64_t* d_active_set, int warm_start, long long total_segments) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
     if (n_traj == 0) return UAVQP_OK;
     if (!d_waypoints || !d_times || !d_bc || !d_corr_lo || !d_corr_hi || !d_coeff_out || !d_status_out) return UAVQP_ERR_INVALID_ARG;
@@ -1298,9 +1306,9 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     const int ws_knots = own_max > NT ? own_max - NT : 0;
     long long rows = 0;                        // waypoint rows of the batch
     if (uniform_segments > 0) rows = (long long)n_traj * (uniform_segments + 1);
+    else if (total_segments >= 0) rows = total_segments + n_traj;
     else {
-        // sum(M_b) + n_traj: the last CSR offset is only known on the device; the caller's coefficient buffer bounds it, but the
-        // cheap exact way is a 4-byte read-back once per call (synchronous on the ctx stream, like the obstacle grid build)
+        // sum(M_b) + n_traj: the last CSR offset is only known on the device; a 4-byte read-back (synchronous on the ctx stream)
         int32_t last = 0;
         UAVQP_HIP(hipMemcpyAsync(&last, d_seg_offsets + n_traj, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         UAVQP_HIP(hipStreamSynchronize(ctx->stream));
@@ -1367,6 +1375,15 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     return UAVQP_OK;
 }
 
+extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                                const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                                const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
+                                                double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
+                                                uint64_t* d_active_set, int warm_start) {
+    return corridor_warm_impl(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times, d_bc, d_corr_lo, d_corr_hi,
+                              d_coeff_out, d_status_out, d_iters_out, d_active_set, warm_start, -1);
+}
+
 #ifdef UAVQP_CORRIDOR_TIMING
 // debug build only (tools/corridor_sections.py): cycles wave 0 of the last corridor solve spent per section
 extern "C" int uavqp_debug_corridor_stamps(uavqp_ctx* ctx, long long* out7) {
@@ -1387,12 +1404,12 @@ extern "C" int uavqp_debug_generic2_stamps(uavqp_ctx* ctx, long long* out9) {
 }
 #endif
 
-extern "C" int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
-                                             const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
-                                             const double* d_bc, const double* d_corr_lo, const double* d_corr_hi, int rows_per_segment,
-                                             const double* d_row_tau, const int32_t* d_row_deriv, const double* d_row_lo,
-                                             const double* d_row_hi, double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
-                                             uint64_t* d_active_out) {
+static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                           const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                           const double* d_bc, const double* d_corr_lo, const double* d_corr_hi, int rows_per_segment,
+                           const double* d_row_tau, const int32_t* d_row_deriv, const double* d_row_lo,
+                           const double* d_row_hi, double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
+                           uint64_t* d_active_out, long long total_segments) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0 || (rows_per_segment != 1 && rows_per_segment != 2))
         return UAVQP_ERR_INVALID_ARG;
     if (n_traj == 0) return UAVQP_OK;
@@ -1404,7 +1421,8 @@ extern "C" int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, 
     const int Mmax = uniform_segments > 0 ? uniform_segments : max_segments;
     long long rows = 0;
     if (uniform_segments > 0) rows = (long long)n_traj * (uniform_segments + 1);
-    else {
+    else if (total_segments >= 0) rows = total_segments + n_traj;
+    else {   // read once here, handed on to the box phase below
         int32_t last = 0;
         UAVQP_HIP(hipMemcpyAsync(&last, d_seg_offsets + n_traj, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         UAVQP_HIP(hipStreamSynchronize(ctx->stream));
@@ -1425,8 +1443,8 @@ extern "C" int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, 
             UAVQP_HIP(hipMalloc((void**)&ctx->rows_warm, sizeof(uint64_t) * (size_t)n_traj * 6));
             ctx->rows_warm_count = (size_t)n_traj * 6;
         }
-        const int rc1 = uavqp_solve_corridor_warm_device(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times,
-                                                         d_bc, d_corr_lo, d_corr_hi, d_coeff_out, d_status_out, nullptr, ctx->rows_warm, 0);
+        const int rc1 = corridor_warm_impl(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times,
+                                           d_bc, d_corr_lo, d_corr_hi, d_coeff_out, d_status_out, nullptr, ctx->rows_warm, 0, rows - n_traj);
         if (rc1 != UAVQP_OK) return rc1;
     }
     const int K = rows_per_segment, Bk = r + K;
@@ -1469,6 +1487,16 @@ extern "C" int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, 
     }
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
+}
+
+extern "C" int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                             const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
+                                             const double* d_bc, const double* d_corr_lo, const double* d_corr_hi, int rows_per_segment,
+                                             const double* d_row_tau, const int32_t* d_row_deriv, const double* d_row_lo,
+                                             const double* d_row_hi, double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
+                                             uint64_t* d_active_out) {
+    return rows_batch_impl(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times, d_bc, d_corr_lo, d_corr_hi,
+                           rows_per_segment, d_row_tau, d_row_deriv, d_row_lo, d_row_hi, d_coeff_out, d_status_out, d_iters_out, d_active_out, -1);
 }
 
 extern "C" int uavqp_solve_corridor_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
@@ -1529,7 +1557,7 @@ extern "C" int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj
     if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(d_t, times, sizeof(double) * (size_t)total_seg, hipMemcpyHostToDevice, s));
     UAVQP_HIP(hipMemcpyAsync(d_bc, bc, sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3, hipMemcpyHostToDevice, s));
     UAVQP_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * 3 * 2 * r * (size_t)total_seg, s));
-    rc = uavqp_solve_corridor_batch_device(ctx, r, n_traj, uniform_segments, Mmax, d_off, d_wp, d_t, d_bc, d_lo, d_hi, d_out, d_st, d_it);
+    rc = corridor_warm_impl(ctx, r, n_traj, uniform_segments, Mmax, d_off, d_wp, d_t, d_bc, d_lo, d_hi, d_out, d_st, d_it, nullptr, 0, total_seg);
     if (rc != UAVQP_OK) return rc;
     if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(coeff_out, d_out, sizeof(double) * 3 * 2 * r * (size_t)total_seg, hipMemcpyDeviceToHost, s));
     if (status_out) UAVQP_HIP(hipMemcpyAsync(status_out, d_st, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
@@ -1605,8 +1633,8 @@ extern "C" int uavqp_solve_rows_batch_host(uavqp_ctx* ctx, int r, int n_traj, in
     }
     UAVQP_HIP(hipMemcpyAsync(d_bc, bc, sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3, hipMemcpyHostToDevice, s));
     UAVQP_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * 3 * 2 * r * (size_t)total_seg, s));   // failed trajectories come back as zeros
-    rc = uavqp_solve_rows_batch_device(ctx, r, n_traj, uniform_segments, Mmax, d_off, d_wp, d_t, d_bc, corr_lo ? d_lo : nullptr,
-                                       corr_lo ? d_hi : nullptr, K, d_rt, d_rd, d_rl, d_rh, d_out, d_st, d_it, nullptr);
+    rc = rows_batch_impl(ctx, r, n_traj, uniform_segments, Mmax, d_off, d_wp, d_t, d_bc, corr_lo ? d_lo : nullptr,
+                         corr_lo ? d_hi : nullptr, K, d_rt, d_rd, d_rl, d_rh, d_out, d_st, d_it, nullptr, total_seg);
     if (rc != UAVQP_OK) return rc;
     if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(coeff_out, d_out, sizeof(double) * 3 * 2 * r * (size_t)total_seg, hipMemcpyDeviceToHost, s));
     if (status_out) UAVQP_HIP(hipMemcpyAsync(status_out, d_st, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
@@ -1837,6 +1865,11 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }
+
+// ===================================================================================================
+// BASELINE config 5 as one call
+// ===================================================================================================
+#include "uavqp_pipeline.h"
 
 // ===================================================================================================
 // N3: quadrotor_msgs/PolynomialTrajectory packer (host only)

@@ -1,0 +1,382 @@
+// uavqp_pipeline.h -- BASELINE config 5 as ONE C-ABI call (included at the end of uavqp.hip): host-side sequencing of the entry
+// points of include/uavqp.h plus the few small kernels the sequencing needs (counters for the loop control, box repair).
+//
+//   plain solve -> corridor boxes from the obstacle cloud (robot ellipsoid of KinoAstar::isCollisionFree, kino_astar.cpp:721-758,
+//   attitude of that solve) -> at most max_rounds x (corridor-constrained solve, working set carried from round to round + time
+//   re-allocation) -> SE(3) collision check of the result against a uniform grid over the cloud -> REPAIR: the boxes only bound the
+//   knots and carry the attitude of the first solve, so the check of the final polynomials is the arbiter: the boxes of every
+//   trajectory it flags are halved towards the searcher's waypoints (last round: collapsed onto them = the reference's equality
+//   problem) and the batch is re-solved, at most repair_rounds times.
+//
+// The reference has no such loop (constant 1.0 s per segment, test_minimum_jerk.cpp:65-71; every row an equality,
+// minimum_control.cpp:98-125): nothing to mirror, parity is per inner solve (SURVEY.md section 8-a').
+// Loop control is data dependent (did any duration change? does anything still collide?): per round the device sums what the
+// host needs into a 64-byte counter block that is copied to a pinned page -- one small D2H copy and one stream synchronisation per
+// round; everything else stays in device buffers.
+#pragma once
+
+namespace uavqp {
+
+struct PipeCounters {
+    unsigned int changed;        // trajectories whose durations the last re-allocation stretched
+    unsigned int hit;            // trajectories the check flags
+    unsigned int hit_blocked;    // ... of those: with an interior waypoint the cloud leaves no room around (degenerate box)
+    unsigned int hit_repairable; // ... the rest (what a repair round works on)
+    unsigned int unsolved;       // trajectories whose status is not UAVQP_SOLVED
+    unsigned int pad_[3];
+    unsigned long long tmax_bits;  // max over trajectories of the total duration (bits of a non-negative double: ordered like integers)
+    unsigned long long pad2_[3];
+};
+static_assert(sizeof(PipeCounters) == 64, "counter block is one 64-byte record");
+
+__global__ void pipe_zero_kernel(PipeCounters* c) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *c = PipeCounters{};
+}
+
+// changed[b] > 0 / status[b] != SOLVED counts (either pointer may be null)
+__global__ __launch_bounds__(256) void pipe_count_kernel(const int32_t* __restrict__ changed, const int32_t* __restrict__ status, int n, PipeCounters* c) {
+    int nc = 0, nu = 0;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) {
+        if (changed && changed[b] > 0) ++nc;
+        if (status && status[b] != UAVQP_SOLVED) ++nu;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nc += __shfl_xor(nc, d, 64);
+        nu += __shfl_xor(nu, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nc) atomicAdd(&c->changed, (unsigned)nc);
+        if (nu) atomicAdd(&c->unsolved, (unsigned)nu);
+    }
+}
+
+// total duration per trajectory -> max over the batch (the check samples every trajectory on ONE grid: dt = max total / (samples - 1))
+__global__ __launch_bounds__(256) void pipe_total_time_kernel(int n, int uniform, const int32_t* __restrict__ seg_offsets, const double* __restrict__ times, PipeCounters* c) {
+    double mx = 0.0;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) {
+        int s0, M;
+        if (uniform > 0) { M = uniform; s0 = b * M; } else { s0 = seg_offsets[b]; M = seg_offsets[b + 1] - s0; }
+        double t = 0.0;
+        for (int i = 0; i < M; ++i) t += times[s0 + i];
+        if (t > mx && t < INFINITY) mx = t;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&c->tmax_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+// roomy[b] = 0 when an INTERIOR waypoint row of trajectory b has a degenerate box (min over axes of hi - lo <= 0): the searcher's
+// waypoint itself is within the robot's reach of an obstacle, narrower boxes cannot help
+__global__ __launch_bounds__(256) void pipe_roomy_kernel(int n, int uniform, const int32_t* __restrict__ seg_offsets, const double* __restrict__ lo,
+                                                         const double* __restrict__ hi, uint8_t* __restrict__ roomy) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) {
+        int s0, M;
+        if (uniform > 0) { M = uniform; s0 = b * M; } else { s0 = seg_offsets[b]; M = seg_offsets[b + 1] - s0; }
+        const size_t row0 = (size_t)s0 + b;
+        bool ok = true;
+        for (int i = 1; i < M; ++i) {
+            const double* l = lo + 3 * (row0 + i);
+            const double* h = hi + 3 * (row0 + i);
+            const double w = fmin(fmin(h[0] - l[0], h[1] - l[1]), h[2] - l[2]);
+            ok = ok && (w > 0.0);
+        }
+        roomy[b] = ok ? 1 : 0;
+    }
+}
+
+// flag[b] = trajectory b collides (first_hit < n_samples) AND is roomy; counts for the host
+__global__ __launch_bounds__(256) void pipe_hits_kernel(int n, const int32_t* __restrict__ first_hit, int n_samples, const uint8_t* __restrict__ roomy,
+                                                        uint8_t* __restrict__ flag, PipeCounters* c) {
+    int nh = 0, nb = 0, nr = 0;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) {
+        const bool hit = first_hit[b] < n_samples;
+        const bool rm = roomy[b] != 0;
+        flag[b] = (hit && rm) ? 1 : 0;
+        nh += hit;
+        nb += hit && !rm;
+        nr += hit && rm;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nh += __shfl_xor(nh, d, 64);
+        nb += __shfl_xor(nb, d, 64);
+        nr += __shfl_xor(nr, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nh) atomicAdd(&c->hit, (unsigned)nh);
+        if (nb) atomicAdd(&c->hit_blocked, (unsigned)nb);
+        if (nr) atomicAdd(&c->hit_repairable, (unsigned)nr);
+    }
+}
+
+// boxes of the flagged trajectories move towards their waypoints: lo <- w - shrink (w - lo), hi <- w + shrink (hi - w)
+// (shrink = 0.5 halves them, 0 collapses them onto the waypoint: the reference's equality row).  One wave per trajectory.
+__global__ __launch_bounds__(64) void pipe_shrink_kernel(int n, int uniform, const int32_t* __restrict__ seg_offsets, const double* __restrict__ wp,
+                                                         double* __restrict__ lo, double* __restrict__ hi, const uint8_t* __restrict__ flag, double shrink) {
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        if (!flag[b]) continue;
+        int s0, M;
+        if (uniform > 0) { M = uniform; s0 = b * M; } else { s0 = seg_offsets[b]; M = seg_offsets[b + 1] - s0; }
+        const size_t e0 = 3 * ((size_t)s0 + b);
+        for (int i = threadIdx.x; i < 3 * (M + 1); i += 64) {
+            const double w = wp[e0 + i];
+            lo[e0 + i] = w - shrink * (w - lo[e0 + i]);
+            hi[e0 + i] = w + shrink * (hi[e0 + i] - w);
+        }
+    }
+}
+
+}  // namespace uavqp
+
+static int ensure_pipe_ws(uavqp_ctx* ctx, size_t bytes) {
+    if (!ctx->h_pipe) UAVQP_HIP(hipHostMalloc(&ctx->h_pipe, 256, hipHostMallocDefault));
+    if (bytes <= ctx->pipe_bytes) return UAVQP_OK;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_pipe) UAVQP_HIP(hipFree(ctx->d_pipe));
+    ctx->d_pipe = nullptr;
+    ctx->pipe_bytes = 0;
+    UAVQP_HIP(hipMalloc(&ctx->d_pipe, bytes));
+    ctx->pipe_bytes = bytes;
+    return UAVQP_OK;
+}
+
+extern "C" void uavqp_default_pipeline_params(uavqp_pipeline_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->struct_size = (int32_t)sizeof(uavqp_pipeline_params);
+    p->robot_r = 0.4;        // test_kino_astar_searching.launch:56
+    p->robot_h = 0.1;        // :57
+    p->h_max = 0.8;          // corridor half-widths h ~ U(0.3, 0.8) m
+    p->v_max = 7.0;          // max_velocity, test_kino_astar_searching.launch:49
+    p->a_max = 10.0;         // max_accelration, :50
+    p->max_rounds = 5;       // BASELINE config 5: "an outer loop of <= 5 time re-allocations"
+    p->samples_per_seg = 16;
+    p->max_stretch = 2.0;
+    p->check_samples = 100;
+    p->repair_rounds = 2;
+    p->check_robot_r = 0.0;  // <= 0: the ellipsoid the boxes were built with
+    p->check_robot_h = 0.0;
+}
+
+extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments, int total_segments,
+                                              const int32_t* d_seg_offsets, const double* d_waypoints, double* d_times, const double* d_bc,
+                                              const double* d_obstacles, int n_obs, const uavqp_grid* grid,
+                                              const uavqp_pipeline_params* params, double* d_coeff_out, int32_t* d_status_out,
+                                              double* d_corr_lo, double* d_corr_hi, int32_t* d_first_hit, uavqp_pipeline_result* result) {
+    if (!ctx || !params || params->struct_size != (int32_t)sizeof(uavqp_pipeline_params) || (r != 3 && r != 4) || n_traj < 0 ||
+        uniform_segments < 0 || n_obs < 0 || total_segments < 0)
+        return UAVQP_ERR_INVALID_ARG;
+    const uavqp_pipeline_params P = *params;
+    if (!(P.robot_r > 0.0) || !(P.robot_h > 0.0) || !(P.h_max >= 0.0) || !(P.v_max > 0.0) || !(P.a_max > 0.0) || P.max_rounds < 1 ||
+        P.samples_per_seg < 1 || !(P.max_stretch > 1.0) || P.check_samples < 0 || P.check_samples == 1 || P.repair_rounds < 0)
+        return UAVQP_ERR_INVALID_ARG;
+    if (result) *result = uavqp_pipeline_result{};
+    if (n_traj == 0) return UAVQP_OK;
+    if (!d_waypoints || !d_times || !d_bc || !d_coeff_out || !d_status_out || !d_corr_lo || !d_corr_hi || (n_obs > 0 && !d_obstacles) ||
+        (uniform_segments == 0 && (!d_seg_offsets || max_segments < 1)) ||
+        (uniform_segments > 0 && (long long)uniform_segments * n_traj != total_segments))
+        return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int n = n_traj, uni = uniform_segments, mx = uni > 0 ? uni : max_segments;
+    const int n_rows = total_segments + n_traj;
+    const bool checking = P.check_samples > 0;
+
+    // scratch: [counters 64 B][iters n][changed n][first_hit n][active n x 6 x 8][roomy n][flag n]
+    const size_t o_it = 256, o_ch = o_it + align256(sizeof(int32_t) * (size_t)n), o_fh = o_ch + align256(sizeof(int32_t) * (size_t)n);
+    const size_t o_as = o_fh + align256(sizeof(int32_t) * (size_t)n), o_rm = o_as + align256(sizeof(uint64_t) * 6 * (size_t)n);
+    const size_t o_fl = o_rm + align256((size_t)n), need = o_fl + align256((size_t)n);
+    int rc = ensure_pipe_ws(ctx, need);
+    if (rc != UAVQP_OK) return rc;
+    char* base = (char*)ctx->d_pipe;
+    uavqp::PipeCounters* d_cnt = (uavqp::PipeCounters*)base;
+    int32_t* d_iters = (int32_t*)(base + o_it);
+    int32_t* d_changed = (int32_t*)(base + o_ch);
+    int32_t* d_fh = d_first_hit ? d_first_hit : (int32_t*)(base + o_fh);
+    uint64_t* d_active = (uint64_t*)(base + o_as);
+    uint8_t* d_roomy = (uint8_t*)(base + o_rm);
+    uint8_t* d_flag = (uint8_t*)(base + o_fl);
+    uavqp::PipeCounters* h_cnt = (uavqp::PipeCounters*)ctx->h_pipe;
+    int cgrid = (n + 255) / 256;
+    if (cgrid > ctx->num_cus * 8) cgrid = ctx->num_cus * 8;
+
+    auto read_counters = [&]() -> int {   // device counter block -> pinned page, then the one synchronisation of this round
+        UAVQP_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(uavqp::PipeCounters), hipMemcpyDeviceToHost, s));
+        UAVQP_HIP(hipStreamSynchronize(s));
+        return UAVQP_OK;
+    };
+    auto corridor_solve = [&](int warm) {
+        return corridor_warm_impl(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_corr_lo, d_corr_hi, d_coeff_out,
+                                  d_status_out, d_iters, d_active, warm, total_segments);
+    };
+    auto reallocate = [&]() -> int {      // + count of the trajectories it stretched
+        int rc_ = uavqp_time_reallocate_device(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
+                                               P.max_stretch, d_changed);
+        if (rc_ != UAVQP_OK) return rc_;
+        hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
+        hipLaunchKernelGGL(uavqp::pipe_count_kernel, dim3(cgrid), dim3(256), 0, s, (const int32_t*)d_changed, (const int32_t*)nullptr, n, d_cnt);
+        return read_counters();
+    };
+
+    // 1. the reference's equality problem, 2. boxes from the cloud with the attitude of that solve
+    rc = uavqp_solve_batch_device(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_coeff_out, d_status_out);
+    if (rc != UAVQP_OK) return rc;
+    rc = uavqp_corridor_from_cloud_device(ctx, r, n, uni, d_seg_offsets, n_rows, d_waypoints, d_times, d_coeff_out, d_obstacles, n_obs,
+                                          P.robot_r, P.robot_h, P.h_max, d_corr_lo, d_corr_hi, nullptr);
+    if (rc != UAVQP_OK) return rc;
+    // 3. outer loop
+    int rounds = 0, still = 0;
+    for (int rnd = 0; rnd < P.max_rounds; ++rnd) {
+        rc = corridor_solve(rnd > 0);
+        if (rc != UAVQP_OK) return rc;
+        ++rounds;
+        rc = reallocate();
+        if (rc != UAVQP_OK) return rc;
+        still = (int)h_cnt->changed;
+        if (still == 0) break;   // the last solve already belongs to the final durations
+    }
+    if (still != 0) {
+        // cap reached with durations changed by the last re-allocation: one more solve so that the coefficients match d_times
+        rc = corridor_solve(1);
+        if (rc != UAVQP_OK) return rc;
+    }
+    // 4. check + repair
+    int repairs = 0, before = -1, blocked = 0, after = 0;
+    double check_dt = 0.0;
+    uavqp_grid* own_grid = nullptr;
+    if (checking) {
+        const double chk_r = P.check_robot_r > 0.0 ? P.check_robot_r : P.robot_r, chk_h = P.check_robot_h > 0.0 ? P.check_robot_h : P.robot_h;
+        if (!grid) {
+            rc = uavqp_obstacle_grid_build_device(ctx, d_obstacles, n_obs, chk_r + 0.1, &own_grid);
+            if (rc != UAVQP_OK) return rc;
+            grid = own_grid;
+        }
+        hipLaunchKernelGGL(uavqp::pipe_roomy_kernel, dim3(cgrid), dim3(256), 0, s, n, uni, d_seg_offsets, (const double*)d_corr_lo,
+                           (const double*)d_corr_hi, d_roomy);
+        for (;;) {
+            hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
+            hipLaunchKernelGGL(uavqp::pipe_total_time_kernel, dim3(cgrid), dim3(256), 0, s, n, uni, d_seg_offsets, (const double*)d_times, d_cnt);
+            rc = read_counters();
+            if (rc != UAVQP_OK) break;
+            double tmax;
+            std::memcpy(&tmax, &h_cnt->tmax_bits, sizeof(double));
+            check_dt = tmax / (double)(P.check_samples - 1);
+            rc = uavqp_ellipsoid_check_grid_device(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.check_samples, 0.0, check_dt, grid,
+                                                   chk_r, chk_h, d_fh, nullptr);
+            if (rc != UAVQP_OK) break;
+            hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
+            hipLaunchKernelGGL(uavqp::pipe_hits_kernel, dim3(cgrid), dim3(256), 0, s, n, (const int32_t*)d_fh, P.check_samples, (const uint8_t*)d_roomy, d_flag, d_cnt);
+            rc = read_counters();
+            if (rc != UAVQP_OK) break;
+            after = (int)h_cnt->hit;
+            if (before < 0) {
+                before = (int)h_cnt->hit;
+                blocked = (int)h_cnt->hit_blocked;
+            }
+            if (h_cnt->hit_repairable == 0 || repairs >= P.repair_rounds) break;
+            // halve the boxes of the flagged trajectories towards their waypoints (last round: the waypoint equalities), re-solve
+            // warm-started, re-allocate once (the durations only ever stretch) and solve again if that changed anything
+            const double shrink = (repairs + 1 == P.repair_rounds) ? 0.0 : 0.5;
+            hipLaunchKernelGGL(uavqp::pipe_shrink_kernel, dim3(n < ctx->num_cus * 32 ? n : ctx->num_cus * 32), dim3(64), 0, s, n, uni, d_seg_offsets,
+                               d_waypoints, d_corr_lo, d_corr_hi, (const uint8_t*)d_flag, shrink);
+            rc = corridor_solve(1);
+            if (rc != UAVQP_OK) break;
+            rc = reallocate();
+            if (rc != UAVQP_OK) break;
+            still = (int)h_cnt->changed;
+            if (still > 0) {
+                rc = corridor_solve(1);
+                if (rc != UAVQP_OK) break;
+            }
+            ++repairs;
+        }
+        if (own_grid) (void)uavqp_obstacle_grid_destroy(ctx, own_grid);
+        if (rc != UAVQP_OK) return rc;
+    }
+    // 5. summary
+    hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
+    hipLaunchKernelGGL(uavqp::pipe_count_kernel, dim3(cgrid), dim3(256), 0, s, (const int32_t*)nullptr, (const int32_t*)d_status_out, n, d_cnt);
+    rc = read_counters();
+    if (rc != UAVQP_OK) return rc;
+    UAVQP_HIP(hipGetLastError());
+    if (result) {
+        result->rounds = rounds;
+        result->repairs = repairs;
+        result->still_stretching = still;
+        result->colliding_before_repair = before < 0 ? 0 : before;
+        result->colliding_with_blocked_waypoints = blocked;
+        result->colliding_after = after;
+        result->unsolved = (int32_t)h_cnt->unsolved;
+        result->check_dt = check_dt;
+    }
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_corridor_pipeline_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
+                                            const int32_t* seg_offsets, const double* waypoints, double* times, const double* bc,
+                                            const double* obstacles, int n_obs, const uavqp_pipeline_params* params, double* coeff_out,
+                                            int32_t* status_out, double* corr_lo, double* corr_hi, int32_t* first_hit,
+                                            uavqp_pipeline_result* result) {
+    if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0 || n_obs < 0) return UAVQP_ERR_INVALID_ARG;
+    if (result) *result = uavqp_pipeline_result{};
+    if (n_traj == 0) return UAVQP_OK;
+    if (!waypoints || !times || !bc || !coeff_out || (n_obs > 0 && !obstacles) || (uniform_segments == 0 && !seg_offsets)) return UAVQP_ERR_INVALID_ARG;
+    long long total_seg = 0;
+    int Mmax = uniform_segments;
+    if (uniform_segments > 0) total_seg = (long long)uniform_segments * n_traj;
+    else {
+        if (seg_offsets[0] != 0) return UAVQP_ERR_INVALID_ARG;
+        for (int b = 0; b < n_traj; ++b) {
+            const int M = seg_offsets[b + 1] - seg_offsets[b];
+            if (M < 0) return UAVQP_ERR_INVALID_ARG;
+            if (M > Mmax) Mmax = M;
+        }
+        total_seg = seg_offsets[n_traj];
+        if (max_segments > 0 && max_segments < Mmax) Mmax = max_segments;
+        if (Mmax < 1) Mmax = 1;
+    }
+    if (total_seg > 0x7fffffffLL - n_traj) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipSetDevice(ctx->device));
+    const size_t n_wp = 3 * (size_t)(total_seg + n_traj);
+    const size_t b_off = uniform_segments > 0 ? 0 : align256(sizeof(int32_t) * (size_t)(n_traj + 1));
+    const size_t b_wp = align256(sizeof(double) * n_wp);
+    const size_t b_t = align256(sizeof(double) * (size_t)total_seg);
+    const size_t b_bc = align256(sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3);
+    const size_t b_obs = align256(sizeof(double) * 3 * (size_t)(n_obs > 0 ? n_obs : 1));
+    const size_t b_out = align256(sizeof(double) * 3 * 2 * r * (size_t)total_seg);
+    const size_t b_st = align256(sizeof(int32_t) * (size_t)n_traj);
+    int rc = ensure_stage(ctx, b_off + 3 * b_wp + b_t + b_bc + b_obs + b_out + 2 * b_st);
+    if (rc != UAVQP_OK) return rc;
+    char* p = (char*)ctx->d_stage;
+    int32_t* d_off = uniform_segments > 0 ? nullptr : (int32_t*)p; p += b_off;
+    double* d_wp = (double*)p; p += b_wp;
+    double* d_lo = (double*)p; p += b_wp;
+    double* d_hi = (double*)p; p += b_wp;
+    double* d_t = (double*)p; p += b_t;
+    double* d_bc = (double*)p; p += b_bc;
+    double* d_obs = (double*)p; p += b_obs;
+    double* d_out = (double*)p; p += b_out;
+    int32_t* d_st = (int32_t*)p; p += b_st;
+    int32_t* d_fh = (int32_t*)p;
+    hipStream_t s = ctx->stream;
+    if (d_off) UAVQP_HIP(hipMemcpyAsync(d_off, seg_offsets, sizeof(int32_t) * (size_t)(n_traj + 1), hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_wp, waypoints, sizeof(double) * n_wp, hipMemcpyHostToDevice, s));
+    if (total_seg > 0) UAVQP_HIP(hipMemcpyAsync(d_t, times, sizeof(double) * (size_t)total_seg, hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemcpyAsync(d_bc, bc, sizeof(double) * (size_t)n_traj * 2 * (r - 1) * 3, hipMemcpyHostToDevice, s));
+    if (n_obs > 0) UAVQP_HIP(hipMemcpyAsync(d_obs, obstacles, sizeof(double) * 3 * (size_t)n_obs, hipMemcpyHostToDevice, s));
+    UAVQP_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * 3 * 2 * r * (size_t)total_seg, s));   // an invalid trajectory comes back as zeros
+    rc = uavqp_corridor_pipeline_device(ctx, r, n_traj, uniform_segments, Mmax, (int)total_seg, d_off, d_wp, d_t, d_bc, d_obs, n_obs, nullptr, params,
+                                        d_out, d_st, d_lo, d_hi, d_fh, result);
+    if (rc != UAVQP_OK) return rc;
+    if (total_seg > 0) {
+        UAVQP_HIP(hipMemcpyAsync(coeff_out, d_out, sizeof(double) * 3 * 2 * r * (size_t)total_seg, hipMemcpyDeviceToHost, s));
+        UAVQP_HIP(hipMemcpyAsync(times, d_t, sizeof(double) * (size_t)total_seg, hipMemcpyDeviceToHost, s));   // stretched by the re-allocation
+    }
+    if (status_out) UAVQP_HIP(hipMemcpyAsync(status_out, d_st, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
+    if (corr_lo) UAVQP_HIP(hipMemcpyAsync(corr_lo, d_lo, sizeof(double) * n_wp, hipMemcpyDeviceToHost, s));
+    if (corr_hi) UAVQP_HIP(hipMemcpyAsync(corr_hi, d_hi, sizeof(double) * n_wp, hipMemcpyDeviceToHost, s));
+    if (first_hit && params && params->check_samples > 0) UAVQP_HIP(hipMemcpyAsync(first_hit, d_fh, sizeof(int32_t) * (size_t)n_traj, hipMemcpyDeviceToHost, s));
+    UAVQP_HIP(hipStreamSynchronize(s));
+    return UAVQP_OK;
+}

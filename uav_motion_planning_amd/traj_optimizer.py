@@ -168,6 +168,26 @@ class Context:
                                                           p(first_hit), p(flags))
         _lib.check(rc, "uavqp_ellipsoid_check_grid_device")
 
+    def corridor_pipeline_device(self, r, n_traj, uniform_segments, max_segments, total_segments, seg_offsets, waypoints, times, bc,
+                                 obstacles, n_obs, coeff_out, status_out, corr_lo, corr_hi, first_hit=None, grid=None, **params):
+        """uavqp_corridor_pipeline_device: BASELINE config 5 as one C-ABI call on device buffers (times is stretched in place).
+        params: fields of uavqp_pipeline_params that differ from uavqp_default_pipeline_params.  Returns the uavqp_pipeline_result
+        fields as a dict.  Synchronous."""
+        def p(x):
+            return x if isinstance(x, int) or x is None else _ptr(x)
+        pp = _lib.PipelineParams()
+        _lib.lib().uavqp_default_pipeline_params(ctypes.byref(pp))
+        for k, v in params.items():
+            if not hasattr(pp, k) or k in ("struct_size", "reserved_"):
+                raise ValueError(f"unknown uavqp_pipeline_params field {k!r}")
+            setattr(pp, k, v)
+        res = _lib.PipelineResult()
+        rc = _lib.lib().uavqp_corridor_pipeline_device(self._h, r, n_traj, uniform_segments, max_segments, int(total_segments), p(seg_offsets),
+                                                       p(waypoints), p(times), p(bc), p(obstacles), int(n_obs), grid, ctypes.byref(pp),
+                                                       p(coeff_out), p(status_out), p(corr_lo), p(corr_hi), p(first_hit), ctypes.byref(res))
+        _lib.check(rc, "uavqp_corridor_pipeline_device")
+        return {k: getattr(res, k) for k, _ in _lib.PipelineResult._fields_ if k != "reserved_"}
+
     # ---- multi-GPU: the ctx owns an RCCL communicator (include/uavqp.h, "Multi-GPU") ----
     @staticmethod
     def comm_unique_id():
