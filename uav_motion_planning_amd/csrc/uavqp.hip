@@ -2000,12 +2000,29 @@ static int allgather_shards(uavqp_ctx* ctx, const T* d_local, const int64_t* cou
     std::vector<int64_t> off(world + 1, 0);
     for (int g = 0; g < world; ++g) off[g + 1] = off[g] + counts[g];
     UAVQP_RCCL(R.GroupStart());
-    for (int g = 0; g < world; ++g) {
+    ncclResult_t first_err = ncclSuccess;
+    const char* what = "";
+    for (int g = 0; g < world && first_err == ncclSuccess; ++g) {
         if (g == rank) continue;
-        if (counts[rank] > 0) UAVQP_RCCL(R.Send(d_local, (size_t)counts[rank], dt, g, ctx->comm.comm, ctx->stream));
-        if (counts[g] > 0) UAVQP_RCCL(R.Recv(d_full + off[g], (size_t)counts[g], dt, g, ctx->comm.comm, ctx->stream));
+        if (counts[rank] > 0) {
+            first_err = R.Send(d_local, (size_t)counts[rank], dt, g, ctx->comm.comm, ctx->stream);
+            what = "ncclSend";
+        }
+        if (first_err == ncclSuccess && counts[g] > 0) {
+            first_err = R.Recv(d_full + off[g], (size_t)counts[g], dt, g, ctx->comm.comm, ctx->stream);
+            what = "ncclRecv";
+        }
     }
-    UAVQP_RCCL(R.GroupEnd());
+    // the group is closed on EVERY path: an open group would swallow the next collective of this thread
+    const ncclResult_t end_err = R.GroupEnd();
+    if (first_err != ncclSuccess) {
+        g_last_error = std::string(what) + ": " + R.GetErrorString(first_err);
+        return UAVQP_ERR_RCCL;
+    }
+    if (end_err != ncclSuccess) {
+        g_last_error = std::string("ncclGroupEnd: ") + R.GetErrorString(end_err);
+        return UAVQP_ERR_RCCL;
+    }
     if (counts[rank] > 0 && d_local != d_full + off[rank])
         UAVQP_HIP(hipMemcpyAsync(d_full + off[rank], d_local, sizeof(T) * (size_t)counts[rank], hipMemcpyDeviceToDevice, ctx->stream));
     return UAVQP_OK;

@@ -10,6 +10,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <mutex>
+
 namespace uavqp {
 
 struct RcclApi {
@@ -25,8 +27,14 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 
+    // one thread per GPU is the documented use: the first callers may race here, so the binding happens exactly once
+    std::once_flag once;
+    bool loaded = false;
     bool load() {
-        if (handle) return true;
+        std::call_once(once, [this] { loaded = load_once(); });
+        return loaded;
+    }
+    bool load_once() {
         const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
         for (const char* n : names) {
             handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
