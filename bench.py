@@ -31,6 +31,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -61,6 +62,7 @@ def parse():
     ap.add_argument("--pipelined-streams", type=int, default=4, help="streams of the `pipelined` sub-record (0 = skip it)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--no-fp64", action="store_true", help="skip the rocprofv3 passes that fill roofline.fp64 and the per-kernel table")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the barrier / communicator / all-gather code even at world size 1 (self-test)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child run under rocprofv3: kernels only
@@ -162,6 +164,87 @@ def measure_traffic(args):
                 "write_bytes": out["WRITE_SIZE"]}
     except Exception:
         return None
+
+
+def _child_cmd(args, extra):
+    return [sys.executable, os.path.abspath(__file__), "--inner", "--repeats", "1", "--graph", "0", "--config", str(args.config),
+            "--batch", str(args.batch), "--segments", str(args.segments), "--order", str(args.order), "--time-mode", args.time_mode,
+            "--variant", str(args.variant), "--pipelined-streams", "0", "--no-allgather"] + extra
+
+
+def _short(name):
+    m = re.search(r"uavqp::([A-Za-z0-9_]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector (= FP64 matrix on this part)
+
+
+def measure_fp64(args, steps):
+    """FP64 VALU work per launch of every uavqp kernel from the SQ instruction counters (one rocprofv3 --pmc pass, kernel-trace only):
+    SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 count wave-instructions; FLOPs = 64 lanes x (ADD + MUL + 2 FMA + TRANS) -- issued lane-slots,
+    whatever the exec mask.  SURVEY.md section 8-d / H3: the solvers are bound by dependent FP64 issue, not by HBM; this is the figure
+    that says how far from THAT roof they are (78.6 TFLOP/s vector FP64).  Returns {kernel: {launches, wave_insts, flops}} or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    ctrs = ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]
+    d = tempfile.mkdtemp(prefix="uavqp_f64_", dir="/tmp")
+    try:
+        cmd = [prof, "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "f64", "--"] + _child_cmd(args, ["--steps", str(steps), "--warmup", "1"])
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+        acc = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = row["Kernel_Name"]
+                if "uavqp::" not in k or row["Counter_Name"] not in ctrs:
+                    continue
+                e = acc.setdefault(_short(k), {"ids": set(), "insts": {c: 0.0 for c in ctrs}})
+                e["ids"].add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+                e["insts"][row["Counter_Name"]] += float(row["Counter_Value"])
+        out = {}
+        for k, e in acc.items():
+            n = max(1, len(e["ids"]))
+            wi = {c.replace("SQ_INSTS_VALU_", ""): v / n for c, v in e["insts"].items()}
+            out[k] = {"launches": n, "wave_insts_per_launch": wi,
+                      "flops_per_launch": 64.0 * (wi["ADD_F64"] + wi["MUL_F64"] + 2.0 * wi["FMA_F64"] + wi["TRANS_F64"])}
+        return out or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def measure_kernel_times(args, steps):
+    """Per-kernel launch counts and average durations of one bench pass: rocprofv3 --kernel-trace --stats around a child run
+    (the summary the judge reads; committed under profiles/ by tools/collect_profiles.sh).  Returns {kernel: {calls, avg_us, total_us}}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    d = tempfile.mkdtemp(prefix="uavqp_kt_", dir="/tmp")
+    try:
+        cmd = [prof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "kt", "--"] + _child_cmd(args, ["--steps", str(steps), "--warmup", "1"])
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+        out = {}
+        for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "uavqp::" in row["Name"]:
+                    out[_short(row["Name"])] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "total_us": float(row["TotalDurationNs"]) / 1e3}
+        return out or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -354,8 +437,9 @@ def main():
 
     # ------------------------------------------------------------------ pipelined sub-record: the same K steps dealt to P streams
     pipelined = None
-    if args.pipelined_streams > 1 and K >= args.pipelined_streams:
+    if args.pipelined_streams > 1 and K > 0:
         P = args.pipelined_streams
+        KP = max(K, 200)   # its own step count: at the driver's 20 steps the overlap of four streams does not reach steady state
         slots = [(stream, ctx)] + [make_slot() for _ in range(P - 1)]
         for k, (_, c) in enumerate(slots):
             launch(c, k)
@@ -363,7 +447,7 @@ def main():
         graphs = []
         for k, (_, c) in enumerate(slots):
             c.capture_begin()
-            for i in range(k, K, P):
+            for i in range(k, KP, P):
                 launch(c, i)
             graphs.append(c.capture_end())
             c.graph_launch(graphs[-1])
@@ -382,8 +466,8 @@ def main():
             t = torch.tensor([pdt], dtype=torch.float64, device=dev if rccl_ok else torch.device("cpu"))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pdt = float(t.item())
-        pipelined = {"streams": P, "value": n_total * K / pdt if args.config == 4 else world * n_local * K / pdt, "ms_per_step": pdt / K * 1e3,
-                     "note": f"the same {K} steps dealt round-robin to {P} streams, one hipGraph each: consecutive steps overlap on the GPU "
+        pipelined = {"streams": P, "steps": KP, "value": n_total * KP / pdt if args.config == 4 else world * n_local * KP / pdt, "ms_per_step": pdt / KP * 1e3,
+                     "note": f"{KP} steps (max(--steps, 200): independent of the timed block) dealt round-robin to {P} streams, one hipGraph each: consecutive steps overlap on the GPU "
                              "(each kernel then shares the machine; per-kernel duration is not comparable with the single-stream figure)"}
         for (_, c), g_ in zip(slots, graphs):
             c.graph_destroy(g_)
@@ -455,6 +539,27 @@ def main():
         n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 4096
         cpu = cpu_baseline(batch, r, n_cpu) if (n_cpu > 0 and world == 1 and args.config == 2) else None
         traffic = measure_traffic(args) if (world == 1 and not args.no_traffic) else None
+        # FP64 roof ("report FP64 FLOP/s next to GB/s") and per-kernel view, from counters / traces of child runs
+        fp64 = kernels = None
+        if world == 1 and not args.no_fp64:
+            prof_steps = 2 if args.config == 5 else 40
+            f64 = measure_fp64(args, prof_steps)
+            kt = measure_kernel_times(args, prof_steps)
+            if f64 and kt:
+                kernels = []
+                tot_us = sum(v["total_us"] for v in kt.values())
+                for name, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_us"]):
+                    fl = f64.get(name, {}).get("flops_per_launch", 0.0)
+                    kernels.append({"kernel": name, "launches_per_step": v["calls"] / (prof_steps + 1), "avg_us": v["avg_us"],
+                                    "share_of_gpu_time": v["total_us"] / tot_us if tot_us else None, "fp64_flops_per_launch": fl,
+                                    "fp64_tflops": fl / (v["avg_us"] * 1e-6) / 1e12 if v["avg_us"] > 0 else None,
+                                    "fp64_frac_of_vector_peak": fl / (v["avg_us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if v["avg_us"] > 0 else None})
+                dom = kernels[0]
+                fp64 = {"kernel": dom["kernel"], "flops_per_launch": dom["fp64_flops_per_launch"], "achieved": dom["fp64_tflops"],
+                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["fp64_frac_of_vector_peak"],
+                        "wave_insts_per_launch": f64.get(dom["kernel"], {}).get("wave_insts_per_launch"),
+                        "note": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 wave-instructions x 64 lanes (FMA = 2 FLOP), per launch of the dominant kernel, "
+                                "over its rocprofv3 average duration; issued lane-slots, idle lanes included"}
         host_e2e = None
         if world == 1 and args.config == 2 and n_cpu > 0:
             # the same batch from HOST pointers (uavqp_solve_batch_host: staging copies over PCIe, solve, copy back, synchronise):
@@ -497,9 +602,12 @@ def main():
                          "kernel_ms_is": ("HIP events on the launch stream around the timed K-step block / K (same clock as value; includes the inter-kernel gap)"
                                           if args.config != 5 else "one pass of the WHOLE pipeline (about 20 launches, host-synchronised between outer rounds), not one kernel"),
                          "working_set_bytes": int(S * set_bytes),
-                         "algorithmic_bytes_per_trajectory": bytes_local / max(n_local, 1)},
+                         "algorithmic_bytes_per_trajectory": bytes_local / max(n_local, 1),
+                         "fp64": fp64},
             "cpu_baseline": cpu,
         }
+        if kernels:
+            out["kernels"] = kernels   # per-kernel launches, durations and FP64 rates of one step (config 5: the pipeline's own kernels)
         if host_e2e:
             out["host_pointers"] = host_e2e
         if pipelined:

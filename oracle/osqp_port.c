@@ -29,8 +29,12 @@
  *   - no polishing (default off), no printing (the reference dumps P, q, A, l, u to stdout on every
  *     solve, minimum_control.cpp:154-158, and OSQP runs verbose: both excluded from timing).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* pthread_setaffinity_np, sched_getaffinity: the all-cores baseline pins one thread per core */
+#endif
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -589,7 +593,22 @@ int osqp_port_solve_batch_rows(int r, int n_traj, const int* seg_offsets, const 
     }
     if (n_threads == 1) job_run(&jobs[0]);
     else {
-        for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, job_run, &jobs[t]);
+        /* one thread per allowed CPU, pinned (un-pinned passes of the all-cores baseline spread 4x on the 128-core host):
+         * thread t runs on the t-th CPU of the process's affinity mask, wrapping around if there are more threads than CPUs */
+        cpu_set_t allowed;
+        int cpus[1024], n_cpu = 0;
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+            for (int c = 0; c < CPU_SETSIZE && n_cpu < 1024; ++c)
+                if (CPU_ISSET(c, &allowed)) cpus[n_cpu++] = c;
+        for (int t = 0; t < n_threads; ++t) {
+            pthread_create(&th[t], NULL, job_run, &jobs[t]);
+            if (n_cpu > 0) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                CPU_SET(cpus[t % n_cpu], &one);
+                (void)pthread_setaffinity_np(th[t], sizeof(one), &one);
+            }
+        }
         for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
     }
     free(jobs); free(th);

@@ -8,13 +8,13 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python $R/bench.py > $O/bench4096.json 2> $O/bench4096.err
-python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-traffic > $O/bench4096_steps20.json 2>> $O/bench4096.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof4096 -o b -- python $R/bench.py --cpu-sample 0 --no-traffic --pipelined-streams 0 > $O/bench4096_under_prof.json 2>> $O/bench4096.err
+python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --no-fp64 > $O/bench4096_steps20.json 2>> $O/bench4096.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof4096 -o b -- python $R/bench.py --cpu-sample 0 --no-traffic --no-fp64 --pipelined-streams 0 > $O/bench4096_under_prof.json 2>> $O/bench4096.err
 cp $(find $O/prof4096 -name "*kernel_stats.csv" | head -1) $O/bench4096_kernel_stats.csv
 for B in 65536 1048576; do
   python $R/bench.py --batch $B --steps 50 --cpu-sample 0 --pipelined-streams 0 > $O/bench_$B.json 2>> $O/bench4096.err
 done
-python $R/bench.py --config 4 --steps 50 --cpu-sample 0 --no-traffic > $O/bench_config4.json 2>> $O/bench4096.err
+python $R/bench.py --config 4 --steps 50 --cpu-sample 0 --no-traffic --no-fp64 > $O/bench_config4.json 2>> $O/bench4096.err
 python $R/tools/bench_configs.py > $O/other_configs.jsonl 2> $O/other_configs.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_configs -o c -- python $R/tools/bench_configs.py > /dev/null 2>> $O/other_configs.err
 cp $(find $O/prof_configs -name "*kernel_stats.csv" | head -1) $O/other_configs_kernel_stats.csv

@@ -3,7 +3,7 @@
 # Collects PMC counters for the solve kernels in their own rocprofv3 pass (kernel-trace only).
 name=$1; ctrs=$2; shift 3
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$name -o $name -- python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$name -o $name -- python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --no-fp64 "$@" > /dev/null 2>&1
 python - <<PY
 import csv,collections,glob
 f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_$name/*counter_collection.csv")[0]
