@@ -129,12 +129,23 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
             // against 53.7 us for the plain order)
             const int win = blockIdx.x >> 4, q = ((blockIdx.x & 15) + win) & 15;
             b = round * n_items + (win * 16 + q) * IPW + item;
-            if (b < a.n_traj) b = a.perm[b];
         }
         G2_STAMP(0);
-        const bool live = b < a.n_traj;   // (both lanes of a pair agree)
         int s0 = 0, M = 0;
-        if (live) {
+        bool packed = false;
+        if constexpr (LSORT) {
+            if (b < a.n_traj) {
+                if (a.perm4) {   // {trajectory, first segment, segment count}: one load (the sort kernel had all three in hand)
+                    const int4 rec = a.perm4[b];
+                    b = rec.x; s0 = rec.y; M = rec.z;
+                    packed = true;
+                } else {
+                    b = a.perm[b];
+                }
+            }
+        }
+        const bool live = b < a.n_traj;   // (both lanes of a pair agree)
+        if (live && !packed) {
             if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
         }
         const bool shape_ok = live && (M >= 1) && (M <= Mx);
@@ -252,79 +263,93 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
             Tn = Tof(1);
             wrow(2, pn);
         }
+        // One elimination step (own knot j): updates the carried state and leaves the knot's record (E_j, h_j) in rec.
+        auto elim_step = [&](const int j, double (&rec)[F]) {
+            const double Tj = Tn;
+            double pc[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) pc[ax] = pn[ax];
+            Tn = Tof(j + 1);
+            wrow(j + 2, pn);
+            okT = (int)okT & (int)(Tj > 0.0) & (int)(Tj < INFINITY);
+            SegBlocks<R> sb;
+            sb.build(Tj);
+            double dpb[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                dpb[ax] = pc[ax] - pb[ax];
+                pb[ax] = pc[ax];
+            }
+            double S[ND][ND], z[ND][3];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+#pragma unroll
+                for (int c = 0; c < ND; ++c) S[i][c] = sa.A11[i][c] + sb.A00(i, c);
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) z[i][ax] = sb.gv(i) * dpb[ax] - sa.gw[i] * dpa[ax];
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+#pragma unroll
+                for (int q = 0; q < ND; ++q) {
+#pragma unroll
+                    for (int c = 0; c <= i; ++c) S[i][c] -= sa.A01[q][i] * E_prev[q][c];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) z[i][ax] -= sa.A01[q][i] * h_prev[q][ax];
+                }
+            G2_INV<ND> inv;
+            inv.factor(S);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                double col[ND];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) col[i] = z[i][ax];
+                inv.solve(col);
+#pragma unroll
+                for (int i = 0; i < ND; ++i) h_prev[i][ax] = col[i];
+            }
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                double col[ND];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) col[i] = sb.A01[i][c];
+                inv.solve(col);
+#pragma unroll
+                for (int i = 0; i < ND; ++i) E_prev[i][c] = col[i];
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+#pragma unroll
+                for (int c = 0; c < ND; ++c) rec[i * ND + c] = E_prev[i][c];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) rec[ND * ND + i * 3 + ax] = h_prev[i][ax];
+            }
+            sa = sb;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) dpa[ax] = dpb[ax];
+        };
+        // The records of the LAST NKR own knots (the ones next to the meeting knot: the first the backward sweep needs) stay in
+        // registers -- three peeled steps behind the loop, three peeled trips in front of the backward loop; only the knots before
+        // them go through the HBM workspace.  Config 4 (own eliminated knots per lane: 1..11, mean ~6): the workspace round trip
+        // drops from 86 MB to ~40 MB per dispatch, and every wave issues 27 fewer vector-memory stores and 27 fewer loads (a
+        // vector-memory instruction costs the wave ~100 cycles of issue).  One wave per SIMD: the 108 registers are there.
+        constexpr int NKR = 3;
+        const int ne = m > 0 ? m - 1 : 0;                  // own eliminated knots 1..ne
+        const int n_ws = ne > NKR ? ne - NKR : 0;          // ... of which 1..n_ws go through the workspace
         // (a plain per-lane loop: lanes that are done are masked off and keep their state in place -- a wave-uniform loop with
         // the body under `if (j < m)` makes the compiler copy all ~50 loop-carried doubles twice per trip)
-        for (int j = 1; j < m; ++j) {
-            {
-                const double Tj = Tn;
-                double pc[3];
+        for (int j = 1; j <= n_ws; ++j) {
+            double rec[F];
+            elim_step(j, rec);
 #pragma unroll
-                for (int ax = 0; ax < 3; ++ax) pc[ax] = pn[ax];
-                Tn = Tof(j + 1);
-                wrow(j + 2, pn);
-                okT = (int)okT & (int)(Tj > 0.0) & (int)(Tj < INFINITY);
-                SegBlocks<R> sb;
-                sb.build(Tj);
-                double dpb[3];
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    dpb[ax] = pc[ax] - pb[ax];
-                    pb[ax] = pc[ax];
-                }
-                double S[ND][ND], z[ND][3];
-#pragma unroll
-                for (int i = 0; i < ND; ++i) {
-#pragma unroll
-                    for (int c = 0; c < ND; ++c) S[i][c] = sa.A11[i][c] + sb.A00(i, c);
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) z[i][ax] = sb.gv(i) * dpb[ax] - sa.gw[i] * dpa[ax];
-                }
-#pragma unroll
-                for (int i = 0; i < ND; ++i)
-#pragma unroll
-                    for (int q = 0; q < ND; ++q) {
-#pragma unroll
-                        for (int c = 0; c <= i; ++c) S[i][c] -= sa.A01[q][i] * E_prev[q][c];
-#pragma unroll
-                        for (int ax = 0; ax < 3; ++ax) z[i][ax] -= sa.A01[q][i] * h_prev[q][ax];
-                    }
-                G2_INV<ND> inv;
-                inv.factor(S);
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    double col[ND];
-#pragma unroll
-                    for (int i = 0; i < ND; ++i) col[i] = z[i][ax];
-                    inv.solve(col);
-#pragma unroll
-                    for (int i = 0; i < ND; ++i) h_prev[i][ax] = col[i];
-                }
-#pragma unroll
-                for (int c = 0; c < ND; ++c) {
-                    double col[ND];
-#pragma unroll
-                    for (int i = 0; i < ND; ++i) col[i] = sb.A01[i][c];
-                    inv.solve(col);
-#pragma unroll
-                    for (int i = 0; i < ND; ++i) E_prev[i][c] = col[i];
-                }
-                {
-                    double rec[F];
-#pragma unroll
-                    for (int i = 0; i < ND; ++i) {
-#pragma unroll
-                        for (int c = 0; c < ND; ++c) rec[i * ND + c] = E_prev[i][c];
-#pragma unroll
-                        for (int ax = 0; ax < 3; ++ax) rec[ND * ND + i * 3 + ax] = h_prev[i][ax];
-                    }
-#pragma unroll
-                    for (int f2 = 0; f2 < F / 2; ++f2) G2_WS_ST(W2(j, f2), make_double2(rec[2 * f2], rec[2 * f2 + 1]));
-                }
-                sa = sb;
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) dpa[ax] = dpb[ax];
-            }
+            for (int f2 = 0; f2 < F / 2; ++f2) G2_WS_ST(W2(j, f2), make_double2(rec[2 * f2], rec[2 * f2 + 1]));
         }
+        double R0[F], R1[F], R2[F];   // records of own knots ne, ne - 1, ne - 2
+#pragma unroll
+        for (int f = 0; f < F; ++f) { R0[f] = 0.0; R1[f] = 0.0; R2[f] = 0.0; }
+        if (ne >= 3) elim_step(ne - 2, R2);
+        if (ne >= 2) elim_step(ne - 1, R1);
+        if (ne >= 1) elim_step(ne, R0);
         G2_STAMP(4);
         // every duration of the trajectory has been seen by one of the two lanes
         bool ok;
@@ -396,7 +421,7 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
         {
             double recA[F], recB[F], Tc, pa[3], pe[3];   // records of own knots mm-1-i (trip i even: A, odd: B), data of the trip's segment
             {
-                const int j1 = mm >= 2 ? mm - 1 : 1, j2 = mm >= 3 ? mm - 2 : 1;
+                const int j1 = mm >= 5 ? mm - 4 : 1, j2 = mm >= 6 ? mm - 5 : 1;   // trips 0..2 take their records from registers
                 load_rec(j1, recA);
                 load_rec(j2, recB);
 #pragma unroll
@@ -408,8 +433,9 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
                 wrow(mm, pe);
             }
             G2_ACC_DECL
-            auto trip = [&](const int i, double (&rec)[F], double (&other)[F], auto touch) {
+            auto trip = [&](const int i, double (&rec)[F], double (&other)[F], auto touch, auto reload) {
                 constexpr bool TOUCH = decltype(touch)::value;
+                constexpr bool RELOAD = decltype(reload)::value;   // false: a register-resident record (peeled trips), nothing to fetch
                 G2_ACC_START;
                 const int j = mm - 1 - i;   // own segment / own knot of this trip
                 double Tn2, pan[3];
@@ -427,7 +453,7 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 G2_ACC(0);
-                {   // the record of the trip after the next (own knot j - 2)
+                if constexpr (RELOAD) {   // the record of the trip after the next (own knot j - 2)
                     const int j2 = j >= 3 ? j - 2 : 1;
                     load_rec(j2, rec);
                 }
@@ -490,7 +516,7 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
                 G2_ACC(3);
 #pragma unroll
                 for (int sidx = 0; sidx < NST; ++sidx) G2_OUT_ST2(mt[sidx].x + axs[sidx] * mt[sidx].y, v[sidx]);
-                if constexpr (TOUCH) {
+                if constexpr (TOUCH && RELOAD) {
                     // ... and its own reload (issued before these stores), so that no load is pending over the loop's back-edge,
                     // where the compiler would wait with vmcnt(0), stores included
 #pragma unroll
@@ -499,10 +525,13 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
                 wave_lds_sync();
                 G2_ACC(4);
             };
-            for (int i = 0; __ballot(i < mm) != 0ull; i += 2) {
-                trip(i, recA, recB, std::false_type{});
+            if (__ballot(0 < mm) != 0ull) trip(0, R0, R0, std::false_type{}, std::false_type{});
+            if (__ballot(1 < mm) != 0ull) trip(1, R1, R1, std::false_type{}, std::false_type{});
+            if (__ballot(2 < mm) != 0ull) trip(2, R2, R2, std::false_type{}, std::false_type{});
+            for (int i = NKR; __ballot(i < mm) != 0ull; i += 2) {
+                trip(i, recA, recB, std::false_type{}, std::true_type{});
                 if (__ballot(i + 1 < mm) == 0ull) break;
-                trip(i + 1, recB, recA, std::true_type{});
+                trip(i + 1, recB, recA, std::true_type{}, std::true_type{});
             }
             G2_ACC_FLUSH;
         }

@@ -31,6 +31,8 @@ struct BatchArgs {
     int32_t* status;
     double* ws;     // forward-sweep workspace (generic kernel)
     const int32_t* perm;  // ragged dealing (generic kernel, LSORT): lane slot -> trajectory
+    const int4* perm4;    // the same with the trajectory's first segment and segment count packed in: {b, s0, M, 0} (pair kernel: one
+                          // load instead of three dependent ones at the top of the wave)
     double* dummy;  // 1 KiB sink for the predicated-off stores of the specialised kernel
 #ifdef UAVQP_PHASE_TIMING
     long long* stamps;  // debug: s_memtime stamps of wave 0 (tools/ubench only)
@@ -59,20 +61,24 @@ struct BatchArgs {
 // bin is whatever the LDS atomics of that one sort give: it decides WHICH lane solves a trajectory, never the result, and
 // since every trajectory index is written to exactly one slot of perm, none can be solved twice or dropped.
 template <int WIN>
-__global__ __launch_bounds__(256) void window_sort_kernel(const int32_t* __restrict__ seg_offsets, int n_traj, int32_t* __restrict__ perm) {
+__global__ __launch_bounds__(256) void window_sort_kernel(const int32_t* __restrict__ seg_offsets, int n_traj, int32_t* __restrict__ perm,
+                                                          int4* __restrict__ perm4) {
     constexpr int KPT = (WIN + 255) / 256;  // keys per thread
     __shared__ int s_cnt[256];
     __shared__ int s_wave[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int base = blockIdx.x * WIN;
-    int key[KPT];
+    int key[KPT], off0[KPT], cnt[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const int w = j * 256 + tid, t = base + w;
         int Mt = -1;
+        off0[j] = 0;
+        cnt[j] = 0;
         if (w < WIN && t < n_traj) {
-            Mt = seg_offsets[t + 1] - seg_offsets[t];
-            Mt = Mt < 0 ? 0 : (Mt > 255 ? 255 : Mt);
+            off0[j] = seg_offsets[t];
+            cnt[j] = seg_offsets[t + 1] - off0[j];
+            Mt = cnt[j] < 0 ? 0 : (cnt[j] > 255 ? 255 : cnt[j]);
         }
         key[j] = Mt;
     }
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(256) void window_sort_kernel(const int32_t* __restr
         if (key[j] >= 0) {
             const int pos = atomicAdd(&s_cnt[255 - key[j]], 1);
             perm[base + pos] = base + j * 256 + tid;
+            if (perm4) perm4[base + pos] = make_int4(base + j * 256 + tid, off0[j], cnt[j], 0);
         }
 }
 
@@ -725,7 +732,7 @@ struct uavqp_ctx {
     size_t ws_bytes = 0;
     uavqp::Comm comm;         // RCCL communicator of the multi-GPU entry points (uavqp_comm_create)
     void* dbg_queue = nullptr;  // (debug builds) where the last corridor solve kept its work counter
-    int32_t* perm = nullptr;  // ragged dealing permutation (window_sort_kernel)
+    int32_t* perm = nullptr;  // ragged dealing permutation (window_sort_kernel); behind it the packed {b, s0, M, 0} records
     size_t perm_count = 0;
     uint64_t* rows_warm = nullptr;   // [n_traj][3][2] working set of the box-only phase of uavqp_solve_rows_batch_device
     size_t rows_warm_count = 0;
@@ -902,6 +909,8 @@ extern "C" int uavqp_set_variant(uavqp_ctx* ctx, int variant) {
     return rc;
 }
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 static int ensure_ws(uavqp_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return UAVQP_OK;
     UAVQP_HIP(hipStreamSynchronize(ctx->stream));
@@ -935,6 +944,8 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     a.coeff = d_coeff_out;
     a.status = d_status_out;
     a.dummy = ctx->dummy;
+    a.perm = nullptr;
+    a.perm4 = nullptr;
 
     // the specialised kernels move 16 bytes per lane (LDS-DMA loads, dwordx4 stores): every array must be
     // 16-byte aligned (allocations are; a view starting at an odd double is not) -- otherwise the generic
@@ -1003,6 +1014,7 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     if (rc != UAVQP_OK) return rc;
     a.ws = ctx->ws;
     a.perm = nullptr;
+    a.perm4 = nullptr;
     if (lsort) {
         // dealing permutation: one counting sort per window of 16 waves' trajectories (see window_sort_kernel)
         if ((size_t)n_traj > ctx->perm_count) {
@@ -1010,15 +1022,18 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
             if (ctx->perm) UAVQP_HIP(hipFree(ctx->perm));
             ctx->perm = nullptr;
             ctx->perm_count = 0;
-            UAVQP_HIP(hipMalloc((void**)&ctx->perm, sizeof(int32_t) * (size_t)n_traj));
+            // [n_traj] int32 + (16-byte aligned) [n_traj] int4
+            UAVQP_HIP(hipMalloc((void**)&ctx->perm, align256(sizeof(int32_t) * (size_t)n_traj) + sizeof(int4) * (size_t)n_traj));
             ctx->perm_count = (size_t)n_traj;
         }
+        int4* perm4 = pair ? (int4*)((char*)ctx->perm + align256(sizeof(int32_t) * ctx->perm_count)) : nullptr;
         const int win = 16 * ipw;
         const int n_win = (n_traj + win - 1) / win;
-        if (pair) hipLaunchKernelGGL((uavqp::window_sort_kernel<512>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
-        else if (nax == 3) hipLaunchKernelGGL((uavqp::window_sort_kernel<1024>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
-        else hipLaunchKernelGGL((uavqp::window_sort_kernel<336>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm);
+        if (pair) hipLaunchKernelGGL((uavqp::window_sort_kernel<512>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm, perm4);
+        else if (nax == 3) hipLaunchKernelGGL((uavqp::window_sort_kernel<1024>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm, perm4);
+        else hipLaunchKernelGGL((uavqp::window_sort_kernel<336>), dim3(n_win), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, ctx->perm, perm4);
         a.perm = ctx->perm;
+        a.perm4 = perm4;
     }
 #define UAVQP_GENERIC(RR)                                                                                                   \
     do {                                                                                                                    \
@@ -1051,7 +1066,6 @@ static int ensure_stage(uavqp_ctx* ctx, size_t bytes) {
     return UAVQP_OK;
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // the pinned, device-mapped staging page of the latency paths (single-axis entry point, small host batches)
 static int ensure_mapped(uavqp_ctx* ctx, size_t need) {
