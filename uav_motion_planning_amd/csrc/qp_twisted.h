@@ -59,7 +59,8 @@ struct TwistedCfg {
     // TILE * 6 * LPT / 8 = 48 rows for both shapes) in an LDS row of stride 10 doubles (20 dwords: the b128 writes of 16 rows tile
     // the 64 banks), read back linearly by the wave for the software-pipelined copy-out; rows 48.. take the writes of the idle pairs.
     static constexpr int ROWS8 = LPT >= 8 ? TILE * 6 * (LPT / 8) : 0, RS8 = 10;
-    static constexpr int OUT_D = LPT >= 8 ? (ROWS8 + 16) * RS8 : ((LPT == 2 && !ALIAS) ? STAGE_D : 2);
+    static_assert(LPT < 8 || ROWS8 == 48, "the copy-out maps 3 axes x 16 rows");
+    static constexpr int OUT_D = LPT >= 8 ? (ROWS8 + 16) * RS8 + 16 : ((LPT == 2 && !ALIAS) ? STAGE_D : 2);
     static_assert(!ALIAS || STAGE_D <= IN_D, "aliased staging rows must fit the input buffer");
     static_assert(WP_D % 2 == 0 && T_D % 2 == 0 && BC_D % 2 == 0, "tile arrays must be whole 16-B pairs");
 };
@@ -407,8 +408,8 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
             // wave ~100 cycles of issue, sixteen scattered quarter-chunk stores per lane were 1100 of the emission's 3400 cycles and left
             // 6.3 MB dirty in L2 for the kernel boundary to write back):
             //   * the NC-double chunk a lane produces in step s goes to its own LDS row at the end of the step;
-            //   * at the START of step s + 1 the wave reads the 48 rows back linearly (16 bytes per lane: whole chunks from adjacent
-            //     lanes) and its NIT write-through stores are interleaved with that step's arithmetic (sched_group_barrier): only the
+            //   * at the START of step s + 1 the wave reads the 48 rows back (16 bytes per lane: whole chunks from adjacent lanes,
+            //     one axis per instruction) and its three write-through stores are interleaved with that step's arithmetic (sched_group_barrier): only the
             //     last step's stores are exposed;
             //   * buffer stores through a per-tile descriptor: pieces of an invalid trajectory, of a lane without a segment in that
             //     step (odd M) and -- for batches smaller than a tile -- of trajectories past the end get an out-of-range offset and
@@ -416,41 +417,41 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
             // 4096 x (M = 8, r = 4), us per launch over rotating buffers: 6.45 (direct stores) -> 5.80 (two-step chunks through LDS,
             // write-through) -> 5.52 (this) for 8 lanes per trajectory, 5.30 for 16.
             constexpr int NSUB = LPT / 8, H = (mL + NSUB - 1) / NSUB;
-            constexpr int RPT = 6 * NSUB, ROWS = C::ROWS8, RS = C::RS8, PPR = NC / 2, NP = ROWS * PPR, NIT = (NP + 63) / 64;
+            // LDS rows: axis-major, 16 rows per axis (one per (trajectory, sub, side) = `rest`), so that copy instruction `it` moves
+            // axis `it` and everything else about a piece comes from lane bits: rest = lane >> 2, 16-byte column = lane & 3 (a row
+            // is padded to four pieces; r = 3 uses three).  Row stride 10 doubles + 4 doubles per axis: the 12 working lanes of any
+            // 16 consecutive lanes start their b128 writes in 12 different bank quads.
+            constexpr int RS = C::RS8, NIT = 3;
+            auto row_addr = [&](int cax, int rest) -> int { return (cax * 16 + rest) * RS + cax * 4; };
             const unsigned tile_bytes = (unsigned)nv * 3u * M * NC * 8u;
             const unsigned long long obase = (unsigned long long)out;
             const unsigned ob_lo = __builtin_amdgcn_readfirstlane((unsigned)obase), ob_hi = __builtin_amdgcn_readfirstlane((unsigned)(obase >> 32));
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)ob_hi << 32) | ob_lo), 0,
                                                                 __builtin_amdgcn_readfirstlane(tile_bytes), 0x00020000);
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            unsigned poff[NIT];   // byte offset of this lane's piece `it` without the segment term; 0xFFFFFFF0 = never stored
-            int prow[NIT], pjv[NIT], pm[NIT];
-            bool prev[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int g = it * 64 + lane;
-                const int row = g / PPR, col = g - row * PPR;
-                const int ctl = row / RPT, rem = row - ctl * RPT, csub = rem / 6, rem2 = rem - csub * 6, cax = rem2 >> 1;
-                prev[it] = rem2 & 1;
-                pjv[it] = csub * H;
-                pm[it] = prev[it] ? mR : mL;
-                prow[it] = g < NP ? row : 0;
-                const bool keep = g < NP && ((okmask >> (LPT * (ctl < TILE ? ctl : 0))) & 1ull);
-                poff[it] = keep ? (unsigned)((((ctl * 3 + cax) * M) * NC + 2 * col) * 8) : 0xFFFFFFF0u;
-            }
-            const int myrow = axl < 3 ? tlc * RPT + sub * 6 + axl * 2 + isR : ROWS + (lane & 15);
+            // the piece this lane copies (the same row slot for the three axes)
+            const int c_rest = lane >> 2, c_col = lane & 3;
+            const int c_R = c_rest & 1, c_sub = NSUB == 2 ? (c_rest >> 1) & 1 : 0, c_tl = c_rest >> NSUB;
+            const int c_m = c_R ? mR : mL;
+            const bool c_keep = (c_col < NC / 2) && ((okmask >> (LPT * c_tl)) & 1ull);
+            const unsigned c_off = (unsigned)(((c_tl * 3 * M) * NC + 2 * c_col) * 8);   // + axis * M * NC * 8 + segment * NC * 8
+            const int c_lds = c_rest * RS + 2 * c_col;
+            const int my_rest = NSUB == 2 ? tlc * 4 + sub * 2 + isR : tlc * 2 + isR;
+            const int my_lds = axl < 3 ? row_addr(axl, my_rest) : 48 * RS + 16 + (lane & 15) * RS;
             auto flush = [&](int sp) {   // copy-out of step sp: NIT LDS reads, NIT stores
                 double2 v[NIT];
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const double2*>(s_out + prow[it] * RS + 2 * ((it * 64 + lane) % PPR));
+                for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const double2*>(s_out + row_addr(it, 0) + c_lds);
+                const int jv = c_sub * H + sp;                                    // own segment of the producing lane
+                const int cseg = c_R ? (M - 1 - jv) : jv;
+                const unsigned off0 = (c_keep && jv < c_m) ? c_off + (unsigned)(cseg * NC * 8) : 0xFFFFFFF0u;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    const int jv = pjv[it] + sp;                                  // own segment of the producing lane
-                    const int cseg = prev[it] ? (M - 1 - jv) : jv;
-                    const unsigned off = (jv < pm[it] && poff[it] != 0xFFFFFFF0u) ? poff[it] + (unsigned)(cseg * NC * 8) : 0xFFFFFFF0u;
                     u32x4 w;
                     w.x = (unsigned)__double2loint(v[it].x); w.y = (unsigned)__double2hiint(v[it].x);
                     w.z = (unsigned)__double2loint(v[it].y); w.w = (unsigned)__double2hiint(v[it].y);
+                    // (an out-of-range base stays out of range: 0xFFFFFFF0 + it * M * NC * 8 wraps only for absurd M)
+                    const unsigned off = off0 == 0xFFFFFFF0u ? off0 : off0 + (unsigned)(it * M * NC * 8);
                     __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, off, 0, 17 /* sc0 sc1: write-through, nothing left dirty for the kernel boundary */);
                 }
             };
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                 }
                 {
                     // (idle pairs and lanes without a segment in this step write too -- rows / chunks that are never copied out)
-                    double* so = s_out + myrow * RS;
+                    double* so = s_out + my_lds;
 #pragma unroll
                     for (int k = 0; k < NC; k += 2) *reinterpret_cast<double2*>(so + k) = make_double2(c8[k], c8[k + 1]);
                 }
