@@ -114,6 +114,8 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *   corridor_pdas_rounds   block-pivoting rounds before the single-pivot active-set phase (default 3)
  *   corridor_initial_guess 1 (default): a cold corridor solve starts from the knots whose boxes the end-state polynomial misses
  *                          (closed form) instead of the empty working set; 0: empty set.  Same result.
+ *   rows_lanes_per_problem uavqp_solve_rows_batch_*: 0 auto / 2 = a lane pair per (trajectory, axis) problem with the sweep state in LDS
+ *                          (default), 1 = one lane per problem, state in an HBM workspace (the round-2 kernel, kept for A/B).  Same result.
  *   realloc_dead_band      uavqp_time_reallocate_device stretches only when the limit ratio exceeds this (default 1.01)
  *   realloc_overshoot      ... and then by overshoot * ratio (default 1.02) */
 typedef struct uavqp_settings {
@@ -127,6 +129,8 @@ typedef struct uavqp_settings {
     int32_t generic_waves_per_cu;
     int32_t corridor_pdas_rounds;
     int32_t corridor_initial_guess;
+    int32_t rows_lanes_per_problem;
+    int32_t reserved_;
     double realloc_dead_band;
     double realloc_overshoot;
 } uavqp_settings;

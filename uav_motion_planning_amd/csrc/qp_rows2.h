@@ -1,0 +1,759 @@
+// qp_rows2.h -- general inequality rows (qp_rows.h) on the corridor kernel's architecture: TWO lanes per (trajectory, axis) problem,
+// sweep state in LDS, persistent waves with a work counter.
+//
+// qp_rows.h ran one lane per problem with the sweep state of every knot in an HBM workspace: 56 GB of traffic per config-3 + K = 2
+// dispatch for 0.37 GB of problem (150x), HBM-bound at 2.3 TB/s, 25 ms.  Same method here (exact dual active set, every solve one
+// block-Thomas pass with blocks [x_k ; mu(rows of the segment the block closes)] of size R + K), same decisions, but:
+//   * lane L eliminates the own knots 1..m_L-1 of the trajectory forward, lane R those of the TIME-REVERSED problem (derivative d
+//     picks up (-1)^d; a row functional g_l' x_k + g_r' x_{k+1} becomes (F g_r)' x'_start + (F g_l)' x'_end) with the same code; the
+//     rows of a segment ride in the block of the knot that closes it IN THE LANE'S OWN DIRECTION, so every row has exactly one owner
+//     (L: segments 0..c-1, R: c..M-1, c = ceil(M/2) the meeting knot);
+//   * the meeting block [x_c ; mu(segment c-1) ; mu(segment c)] (size R + 2 K) is assembled from the two partial blocks exchanged
+//     through DPP, in ONE frame and ONE ordering, so both lanes solve bit-identical systems;
+//   * per own knot the LDL' factors of the block and its solution (F = B (B + 1) / 2 + B doubles) live in LDS -- 2 waves per CU,
+//     80 KiB each: 8 knots for r = 3, K = 2, i.e. the whole state of a 16-segment problem; longer halves keep their far knots in the
+//     HBM workspace (per-lane branch); only the dual state (current / new multiplier per constraint) goes through HBM;
+//   * decisions (most violated constraint, first multiplier to reach zero, singular working set) are made per half and combined
+//     across the pair with order-independent tie rules (largest violation / smallest step, then kind, then index), so which lane
+//     sees a constraint never matters;
+//   * validation and the permanent (equality) masks come from rows_prep_kernel, one lane per problem, off the solver's path.
+// Checked against qp_rows.h's kernel (uavqp_settings.rows_kernel = 1) and the exact-rational fixtures incl. working sets.
+#pragma once
+#include "qp_rows.h"
+
+namespace uavqp {
+
+constexpr int rows2_lds_knots(int R, int K) { return (80 * 1024) / (64 * 8 * ((R + K) * (R + K + 1) / 2 + (R + K))); }
+
+struct Rows2Args {
+    RowsArgs r;
+    unsigned long long* desc;   // [problem][2 + 2 K]: {valid | M >= 2 flag, eqmask, rused[K], req[K]} from rows_prep_kernel
+    const int32_t* order;       // dealing order of the trajectories (longest first), may be null
+    double* lam;                // dual state [wave][own knot 0..kown][2 (1 + K)][lane]: current / new multiplier of the knot box and the rows
+    int ws_knots;               // own knots per lane kept in the HBM workspace (beyond the LDS slots)
+    int lam_knots;              // own knots per lane in `lam`
+};
+
+// validation + permanent masks, one lane per (trajectory, axis) problem.  desc[0]: bit 0 = valid, bit 1 = has a free knot (M >= 2),
+// bits 8.. = M; desc[1] = knot boxes with lo == hi; then per row slot: used mask, equality mask (bit = ORIGINAL segment).
+template <int R, int K>
+__global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
+    const RowsArgs& a = aa.r;
+    const long long total = (long long)a.n_traj * 3;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(q / 3), ax = (int)(q - 3LL * b);
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        const long long base3 = 3LL * ((long long)s0 + b) + ax;
+        bool ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;
+        unsigned long long eq = 0ull, used[K], req[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { used[j] = 0ull; req[j] = 0ull; }
+        if (ok)
+            for (int i = 0; i < M; ++i) { const double t = a.times[s0 + i]; ok = ok && (t > 0.0) && (t < INFINITY); }
+        if (ok) {
+            for (int k = 1; k < M; ++k) {
+                const double l = a.corr_lo ? a.corr_lo[base3 + 3 * k] : a.waypoints[base3 + 3 * k];
+                const double h = a.corr_hi ? a.corr_hi[base3 + 3 * k] : a.waypoints[base3 + 3 * k];
+                ok = ok && (l <= h);
+                if (l == h) eq |= 1ull << k;
+            }
+            for (int s = 0; s < M; ++s)
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int d = a.row_deriv[(size_t)(s0 + s) * K + j];
+                    if (d < 0) continue;
+                    const double tau = a.row_tau[(size_t)(s0 + s) * K + j];
+                    const double l = a.row_lo[((size_t)(s0 + s) * K + j) * 3 + ax], h = a.row_hi[((size_t)(s0 + s) * K + j) * 3 + ax];
+                    ok = ok && (d < R) && (tau >= 0.0) && (tau < 1.0) && (l <= h) && !(tau == 0.0 && d == 0);
+                    used[j] |= 1ull << s;
+                    if (l == h) req[j] |= 1ull << s;
+                }
+        }
+        if (!ok) atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
+        unsigned long long* o = aa.desc + (size_t)q * (2 + 2 * K);
+        o[0] = ok ? (1ull | (M >= 2 ? 2ull : 0ull) | ((unsigned long long)M << 8)) : 0ull;
+        o[1] = eq;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { o[2 + 2 * j] = used[j]; o[3 + 2 * j] = req[j]; }
+    }
+}
+
+template <int R, int K, bool WS>
+__global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
+    const RowsArgs& a = aa.r;
+    constexpr int ND = R - 1, B = R + K, NL = B * (B + 1) / 2, NCN = 1 + K, F = NL + B, BM = R + 2 * K;
+    constexpr int NT = rows2_lds_knots(R, K);
+    constexpr int NONE = 1 << 30;
+    __shared__ double s_rec[NT * F * 64];
+    const int lane = threadIdx.x;
+    const int isR = lane & 1;
+    // state slot s = own knot m - s (slot 0: the meeting knot).  LDS for s < NT, else the HBM workspace (per-lane branch: the lanes
+    // of a wave may sit at different slots)
+    double* const ws = a.ws + (size_t)blockIdx.x * (size_t)(aa.ws_knots > 0 ? aa.ws_knots : 1) * F * 64 + lane;
+    auto RL = [&](int s, int f) -> double& { return s_rec[(s * F + f) * 64 + lane]; };
+    auto RG = [&](int s, int f) -> double& { return ws[((size_t)(s - NT) * F + f) * 64]; };
+    auto rec_ld = [&](int s, int f) -> double { return (!WS || s < NT) ? RL(s, f) : RG(s, f); };
+    auto rec_st = [&](int s, int f, double v) { if (!WS || s < NT) RL(s, f) = v; else RG(s, f) = v; };
+    // dual state: slot s, constraint c (0: the knot box, 1 + j: row slot j of the segment the block closes), cur / new
+    double* const lamb = aa.lam + (size_t)blockIdx.x * (size_t)aa.lam_knots * 2 * NCN * 64 + lane;
+    auto LC = [&](int s, int c) -> double& { return lamb[((size_t)s * 2 * NCN + c) * 64]; };
+    auto LN = [&](int s, int c) -> double& { return lamb[((size_t)s * 2 * NCN + NCN + c) * 64]; };
+
+    const long long total = (long long)a.n_traj * 3;
+    bool queue_empty = false;
+
+    // ---- problem state (identical in both lanes of a pair unless noted)
+    long long g = -1;
+    int b = 0, ax = 0, s0 = 0, M = 0, m = 0;   // m: own knots up to and including the meeting knot (lane-specific for odd M)
+    long long base3 = 0;
+    unsigned long long eqmask = 0ull, pin = 0ull, upper = 0ull;
+    unsigned long long rused[K], req[K], ract[K], rup[K], pract[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { rused[j] = 0ull; req[j] = 0ull; ract[j] = 0ull; rup[j] = 0ull; pract[j] = 0ull; }
+    unsigned long long ppin = 0ull;
+    double x0[R];   // own boundary knot, own frame (lane-specific)
+#pragma unroll
+    for (int c = 0; c < R; ++c) x0[c] = 0.0;
+    int it = 0;
+    bool capped = false;
+    double tpend = 1.0;
+    int new_kind = -1, new_idx = -1;
+
+    // own frame -> original data
+    auto korig = [&](int j) -> int { return isR ? M - j : j; };                   // original knot of own knot j
+    auto sorig = [&](int s) -> int { return isR ? M - 1 - s : s; };               // original segment of own segment s (joins own knots s, s + 1)
+    auto Tseg = [&](int s) -> double { return a.times[s0 + sorig(s)]; };
+    auto klo = [&](int j) -> double { const long long i = base3 + 3LL * korig(j); return a.corr_lo ? a.corr_lo[i] : a.waypoints[i]; };
+    auto khi = [&](int j) -> double { const long long i = base3 + 3LL * korig(j); return a.corr_hi ? a.corr_hi[i] : a.waypoints[i]; };
+    auto kbit = [&](unsigned long long msk, int j) -> bool { return (msk >> (korig(j) & 63)) & 1ull; };
+    auto sbit = [&](unsigned long long msk, int s) -> bool { return (msk >> (sorig(s) & 63)) & 1ull; };
+    auto rlo = [&](int s, int j) -> double { return a.row_lo[((size_t)(s0 + sorig(s)) * K + j) * 3 + ax]; };
+    auto rhi = [&](int s, int j) -> double { return a.row_hi[((size_t)(s0 + sorig(s)) * K + j) * 3 + ax]; };
+    // functional of row slot j of own segment s in the OWN frame: value = gl' x'_s + gr' x'_{s+1}
+    auto rowf = [&](int s, int j, double (&gl)[R], double (&gr)[R]) {
+        const size_t e = (size_t)(s0 + sorig(s)) * K + j;
+        double ol[R], orr[R];
+        row_functional<R>(Tseg(s), a.row_tau[e], a.row_deriv[e], ol, orr);
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const double fl = (isR && (c & 1)) ? -orr[c] : orr[c], fr = (isR && (c & 1)) ? -ol[c] : ol[c];
+            gl[c] = isR ? fl : ol[c];
+            gr[c] = isR ? fr : orr[c];
+        }
+    };
+
+    for (;;) {
+        // ================= hand out problems to the free lane pairs =================
+        {
+            const bool need = g < 0;
+            const unsigned long long needm = __ballot(need);
+            if (needm != 0ull && !queue_empty) {
+                const int npairs = __popcll(needm) >> 1;
+                const int leader = (int)__builtin_ctzll(needm);
+                unsigned int qb = 0;
+                if (lane == leader) qb = atomicAdd(a.queue, (unsigned int)npairs);
+                qb = __shfl(qb, leader, 64);
+                if ((long long)qb + npairs >= total) queue_empty = true;
+                if (need) {
+                    const int rank = __popcll(needm & ((1ull << lane) - 1ull)) >> 1;
+                    const long long q = (long long)qb + rank;
+                    if (q < total) {
+                        const int bq = (int)(q / 3), axn = (int)(q - 3LL * bq);
+                        const int bn = aa.order ? aa.order[bq] : bq;
+                        const long long gn = 3LL * bn + axn;
+                        const unsigned long long* dsc = aa.desc + (size_t)gn * (2 + 2 * K);
+                        const unsigned long long d0 = dsc[0];
+                        if (d0 & 1ull) {
+                            int sn, Mn;
+                            if (a.uniform > 0) { Mn = a.uniform; sn = bn * Mn; } else { sn = a.seg_offsets[bn]; Mn = a.seg_offsets[bn + 1] - sn; }
+                            g = gn; b = bn; ax = axn; M = Mn; s0 = sn;
+                            base3 = 3LL * ((long long)sn + bn) + axn;
+                            m = isR ? M / 2 : (M + 1) / 2;
+                            eqmask = dsc[1];
+#pragma unroll
+                            for (int j = 0; j < K; ++j) { rused[j] = dsc[2 + 2 * j]; req[j] = dsc[3 + 2 * j]; ract[j] = req[j]; rup[j] = 0ull; pract[j] = 0ull; }
+                            const double* bc = a.bc + (size_t)bn * 2 * ND * 3 + axn;
+                            x0[0] = a.waypoints[base3 + (isR ? 3 * M : 0)];
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) {
+                                const double v = bc[((isR ? ND : 0) + d) * 3];
+                                x0[d + 1] = (isR && ((d & 1) == 0)) ? -v : v;
+                            }
+                            pin = eqmask; upper = 0ull;
+                            if (a.warm) {
+                                const unsigned long long valid = M >= 2 ? ((1ull << M) - 2ull) : 0ull;
+                                const unsigned long long w0 = a.warm[(size_t)gn * 2] & valid & ~eqmask;
+                                pin |= w0;
+                                upper = a.warm[(size_t)gn * 2 + 1] & w0;
+                            }
+                            it = 0; capped = false; tpend = 1.0; ppin = 0ull; new_kind = -1; new_idx = -1;
+                        }
+                    }
+                }
+            }
+        }
+        const bool act = g >= 0;
+        if (__ballot(act) == 0ull) {
+            if (queue_empty) break;
+            continue;
+        }
+        const int mm = act ? m : 0;
+        bool finish = false;
+        bool single = act && (M == 1);   // no free knot: the rows can only be CHECKED (by the L lane, own segment 0)
+
+        // ================= forward sweep: own knots j = 1 .. m - 1 (slot m - j) =================
+        FullBlocks<R> sa;                 // blocks of own segment j - 1
+        SmallLDL<B> lprev;
+        LDLPack<B>::zero(lprev);          // own knot 0: nothing free, h = its Hermite data
+        double hprev[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) hprev[i] = i < R ? x0[i] : 0.0;
+        bool pprev = false;
+        double zprev = 0.0;
+        // own partial block of a knot: rows of own segment j - 1 (mu part), coupling to the previous block eliminated.
+        // full = true adds the next segment's start block and the coupling to known neighbours behind it (interior own knots);
+        // the meeting knot leaves both to the partner lane.
+        auto block = [&](int j, bool full, double (&D)[B][B], double (&rhs)[B], bool (&fx)[B], double (&vx)[B]) {
+            FullBlocks<R> sb;
+            if (full) sb.build(Tseg(j));
+            double gl[K][R], gr[K][R], rb[K];
+            bool racv[K];
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj) {
+                racv[jj] = sbit(ract[jj], j - 1);
+                rb[jj] = 0.0;
+#pragma unroll
+                for (int c = 0; c < R; ++c) { gl[jj][c] = 0.0; gr[jj][c] = 0.0; }
+                if (racv[jj]) {
+                    rowf(j - 1, jj, gl[jj], gr[jj]);
+                    rb[jj] = sbit(rup[jj], j - 1) ? rhi(j - 1, jj) : rlo(j - 1, jj);
+                }
+            }
+            const bool interior = korig(j) >= 1 && korig(j) <= M - 1;
+            const bool pk = interior && kbit(pin, j);
+            const double zc = pk ? (kbit(upper, j) ? khi(j) : klo(j)) : 0.0;
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                rhs[i] = 0.0;
+#pragma unroll
+                for (int c = 0; c < B; ++c) D[i][c] = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int c = 0; c < R; ++c) D[i][c] = sa.B11[i][c] + (full ? sb.B00(i, c) : 0.0);
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj) {
+#pragma unroll
+                for (int c = 0; c < R; ++c) D[R + jj][c] = gr[jj][c];
+                rhs[R + jj] = rb[jj];
+            }
+            if (pprev) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) rhs[i] -= sa.B01[0][i] * zprev;
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) rhs[R + jj] -= gl[jj][0] * zprev;
+            }
+            if (full) {
+                const bool pnext = kbit(pin, j + 1);   // own knot j + 1 <= m: an interior knot (the meeting knot at the latest)
+                if (pnext) {
+                    const double zn = kbit(upper, j + 1) ? khi(j + 1) : klo(j + 1);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) rhs[i] -= sb.B01[i][0] * zn;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < B; ++i) { fx[i] = false; vx[i] = 0.0; }
+            if (full && pk) { fx[0] = true; vx[0] = zc; }   // (the meeting knot's pin is applied to the COMBINED block)
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj) fx[R + jj] = !racv[jj];
+#pragma unroll
+            for (int i = 0; i < B; ++i)
+#pragma unroll
+                for (int c = 0; c < B; ++c)
+                    if (fx[c] && !fx[i]) rhs[i] -= (i >= c ? D[i][c] : D[c][i]) * vx[c];
+            // coupling to the previous block (rows = x_{j-1}), masked
+            double Mp[R][B];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) Mp[c][i] = sa.B01[c][i];
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) Mp[c][R + jj] = gl[jj][c];
+            }
+#pragma unroll
+            for (int c = 0; c < R; ++c)
+#pragma unroll
+                for (int i = 0; i < B; ++i)
+                    if ((pprev && c == 0) || fx[i] || (pk && i == 0)) Mp[c][i] = 0.0;   // (pk && i == 0 also at the meeting knot: a pinned
+                                                                                           //  position is a known value, its coupling went to the previous block's rhs)
+            double Ep[B][B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                double col[B];
+#pragma unroll
+                for (int c = 0; c < B; ++c) col[c] = c < R ? Mp[c][i] : 0.0;
+                lprev.solve(col);
+#pragma unroll
+                for (int c = 0; c < B; ++c) Ep[c][i] = col[c];
+            }
+#pragma unroll
+            for (int i = 0; i < B; ++i)
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+#pragma unroll
+                    for (int c = 0; c <= i; ++c) D[i][c] -= Mp[q][i] * Ep[q][c];
+                    rhs[i] -= Mp[q][i] * hprev[q];
+                }
+            if (full) { sa = sb; pprev = pk; zprev = zc; }
+        };
+        if (mm >= 1 && !single) sa.build(Tseg(0));
+        for (int j = 1; j < mm; ++j) {
+            double D[B][B], rhs[B], vx[B];
+            bool fx[B];
+            block(j, true, D, rhs, fx, vx);
+#pragma unroll
+            for (int i = 0; i < B; ++i)
+                if (fx[i]) {
+#pragma unroll
+                    for (int c = 0; c < B; ++c) {
+                        if (c <= i) D[i][c] = 0.0;
+                        if (c >= i) D[c][i] = 0.0;
+                    }
+                    D[i][i] = 1.0;
+                    rhs[i] = vx[i];
+                }
+            SmallLDL<B> ldl;
+            ldl.factor(D);
+            ldl.solve(rhs);
+            {
+                double e[NL];
+                LDLPack<B>::get(ldl, e);
+                const int s = mm - j;
+#pragma unroll
+                for (int q = 0; q < NL; ++q) rec_st(s, q, e[q]);
+#pragma unroll
+                for (int q = 0; q < B; ++q) rec_st(s, NL + q, rhs[q]);
+            }
+#pragma unroll
+            for (int i = 0; i < B; ++i) hprev[i] = rhs[i];
+            lprev = ldl;
+        }
+
+        // ================= meeting block [x_c ; mu_L ; mu_R], assembled in the L frame =================
+        double ym[B];             // solution of the own meeting block [x_c (own frame) ; mu_own]
+#pragma unroll
+        for (int i = 0; i < B; ++i) ym[i] = 0.0;
+        bool fxm[B];              // fixed components of the own meeting block (mu part: inactive rows)
+#pragma unroll
+        for (int i = 0; i < B; ++i) fxm[i] = false;
+        {
+            double D[B][B], rhs[B], vx[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                rhs[i] = 0.0; vx[i] = 0.0;
+#pragma unroll
+                for (int c = 0; c < B; ++c) D[i][c] = 0.0;
+            }
+            const bool has = act && !single && mm >= 1;
+            if (has) block(mm, false, D, rhs, fxm, vx);
+            // exchange lower triangles and right-hand sides; conj = F . F on the x part of the partner's (reversed-frame) block
+            double C[BM][BM], r7[BM];
+#pragma unroll
+            for (int i = 0; i < BM; ++i) {
+                r7[i] = 0.0;
+#pragma unroll
+                for (int c = 0; c < BM; ++c) C[i][c] = 0.0;
+            }
+            bool ofx[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) ofx[i] = swap_pair_i(fxm[i] ? 1 : 0) != 0;
+            auto sgn = [](int c) -> double { return (c & 1) ? -1.0 : 1.0; };
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+#pragma unroll
+                for (int c = 0; c <= i; ++c) {
+                    const double own = D[i][c], oth = swap_pair(D[i][c]);
+                    // L-frame value of each lane's entry: x-x entries of the R lane pick up F_i F_c, mu-x entries F_c
+                    const double fo = (i < R ? sgn(i) : 1.0) * (c < R ? sgn(c) : 1.0);
+                    const double vL = isR ? oth : own, vR = isR ? own * fo : oth * fo;   // the L lane's / the R lane's block, L frame
+                    if (i < R) C[i][c] = vL + vR;                                         // x - x: the two halves add
+                    else {
+                        C[i][c] = (c < R || c == i || c < i) ? vL : 0.0;                  // mu_L rows: positions R .. R + K - 1
+                        C[K + i][c < R ? c : K + c] = vR;                                 // mu_R rows: positions R + K .. R + 2 K - 1
+                    }
+                }
+                const double own = rhs[i], oth = swap_pair(rhs[i]);
+                const double fo = i < R ? sgn(i) : 1.0;
+                const double vL = isR ? oth : own, vR = isR ? own * fo : oth * fo;
+                if (i < R) r7[i] = vL + vR;
+                else { r7[i] = vL; r7[K + i] = vR; }
+            }
+            // fixed components of the combined block: the pinned meeting position, inactive rows of either side
+            bool f7[BM];
+            double v7[BM];
+#pragma unroll
+            for (int i = 0; i < BM; ++i) { f7[i] = false; v7[i] = 0.0; }
+            const bool pc = has && mm >= 1 && kbit(pin, mm) && korig(mm) >= 1 && korig(mm) <= M - 1;
+            const double zc = pc ? (kbit(upper, mm) ? khi(mm) : klo(mm)) : 0.0;
+            if (pc) { f7[0] = true; v7[0] = zc; }
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj) {
+                f7[R + jj] = isR ? ofx[R + jj] : fxm[R + jj];
+                f7[R + K + jj] = isR ? fxm[R + jj] : ofx[R + jj];
+            }
+#pragma unroll
+            for (int i = 0; i < BM; ++i)
+#pragma unroll
+                for (int c = 0; c < BM; ++c)
+                    if (f7[c] && !f7[i]) r7[i] -= (i >= c ? C[i][c] : C[c][i]) * v7[c];
+#pragma unroll
+            for (int i = 0; i < BM; ++i)
+                if (f7[i]) {
+#pragma unroll
+                    for (int c = 0; c < BM; ++c) {
+                        if (c <= i) C[i][c] = 0.0;
+                        if (c >= i) C[c][i] = 0.0;
+                    }
+                    C[i][i] = 1.0;
+                    r7[i] = v7[i];
+                }
+            SmallLDL<BM> ldl;
+            ldl.factor(C);
+            ldl.solve(r7);
+            if (has) {
+#pragma unroll
+                for (int c = 0; c < R; ++c) ym[c] = isR ? r7[c] * sgn(c) : r7[c];
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) ym[R + jj] = isR ? r7[R + K + jj] : r7[R + jj];
+#pragma unroll
+                for (int q = 0; q < B; ++q) rec_st(0, NL + q, ym[q]);
+            }
+        }
+
+        // ================= backward sweep + the decisions of this iteration (own constraints only) =================
+        double vmax = 0.0;           // most violated inactive constraint
+        int vkind = -1, vidx = NONE;
+        bool vupper = false;
+        double tmin = 2.0;           // first multiplier to reach zero
+        int tkind = -1, tidx = NONE;
+        bool inconsistent = false;
+        double lam_meet = 0.0, mag_meet = 0.0;   // own half of the meeting knot's box multiplier
+        auto viol_cand = [&](double sc, int kind, int idx, bool up) {
+            if (sc > 1e-12 && (sc > vmax || (sc == vmax && (kind < vkind || (kind == vkind && idx < vidx))))) { vmax = sc; vkind = kind; vidx = idx; vupper = up; }
+        };
+        auto step_cand = [&](double t, int kind, int idx) {
+            if (t < tmin || (t == tmin && (kind < tkind || (kind == tkind && idx < tidx)))) { tmin = t; tkind = kind; tidx = idx; }
+        };
+        // multiplier bookkeeping of one constraint (slot s, constraint c): current value by the pending interpolation, ratio test
+        // (bad: the wrong-signed amount of lam_new, mag: scale of its rounding; rows add |current multiplier| to the scale as qp_rows.h does)
+        auto dual = [&](int s, int c, bool active, bool equality, bool was, double lam_new, double bad, double mag, bool add_lc, int kind, int idx) {
+            double lc = LC(s, c);
+            const double ln = LN(s, c);
+            lc = was ? lc + tpend * (ln - lc) : 0.0;
+            const bool wrong = bad > 1e-13 * (mag + (add_lc ? fabs(lc) : 0.0)) && bad > 0.0;
+            if (active && !equality && wrong && !(new_kind == kind && new_idx == idx)) {
+                const double den = lc - lam_new;
+                double t = den != 0.0 ? lc / den : 0.0;
+                t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+                step_cand(t, kind, idx);
+            }
+            LC(s, c) = active ? lc : 0.0;
+            LN(s, c) = active ? lam_new : 0.0;
+        };
+        if (act && !single) {
+            double yn[B];            // block of own knot j + 1
+#pragma unroll
+            for (int i = 0; i < B; ++i) yn[i] = ym[i];
+            // the rows of own segment mm - 1 (they ride in the meeting block)
+            for (int j = mm - 1; j >= 0; --j) {
+                // own segment j joins own knots j and j + 1; block j + 1 (= yn) carries its rows' multipliers
+                FullBlocks<R> sn;
+                sn.build(Tseg(j));
+                double gl[K][R], gr[K][R];
+                bool usedj[K];
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) {
+                    usedj[jj] = sbit(rused[jj], j);
+#pragma unroll
+                    for (int c = 0; c < R; ++c) { gl[jj][c] = 0.0; gr[jj][c] = 0.0; }
+                    if (usedj[jj]) rowf(j, jj, gl[jj], gr[jj]);
+                }
+                double y[B];
+                const int s = mm - j;
+                if (j >= 1) {
+                    double h[B], t[B];
+#pragma unroll
+                    for (int i = 0; i < B; ++i) { h[i] = rec_ld(s, NL + i); t[i] = 0.0; }
+                    const bool pk = kbit(pin, j), pn = kbit(pin, j + 1);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        if (pk && i == 0) continue;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int c = 0; c < R; ++c)
+                            if (!(pn && c == 0)) acc += sn.B01[i][c] * yn[c];
+#pragma unroll
+                        for (int jj = 0; jj < K; ++jj)
+                            if (sbit(ract[jj], j)) acc += gl[jj][i] * yn[R + jj];
+                        t[i] = acc;
+                    }
+                    SmallLDL<B> ldl;
+                    double e[NL];
+#pragma unroll
+                    for (int q = 0; q < NL; ++q) e[q] = rec_ld(s, q);
+                    LDLPack<B>::set(ldl, e);
+                    ldl.solve(t);
+#pragma unroll
+                    for (int i = 0; i < B; ++i) y[i] = h[i] - t[i];
+#pragma unroll
+                    for (int i = 0; i < B; ++i) rec_st(s, NL + i, y[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < B; ++i) y[i] = i < R ? x0[i] : 0.0;
+                }
+                // ---- rows of own segment j: values (inactive: violation; active: must sit on the bound), multipliers (block j + 1)
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) {
+                    const int os = sorig(j);
+                    const bool aj = sbit(ract[jj], j), ej = sbit(req[jj], j), uj = sbit(rup[jj], j);
+                    if (usedj[jj]) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int c = 0; c < R; ++c) v += gl[jj][c] * y[c] + gr[jj][c] * yn[c];
+                        if (aj) {
+                            const double bnd = uj ? rhi(j, jj) : rlo(j, jj);
+                            if (!(fabs(v - bnd) <= 1e-8 * (1.0 + fabs(bnd)))) inconsistent = true;
+                        } else {
+                            const double l = rlo(j, jj), h = rhi(j, jj);
+                            const double below = l - v, above = v - h;
+                            const double viol = below > above ? below : above;
+                            viol_cand(viol / (1.0 + fabs(below > above ? l : h)), 1 + jj, os, above > below);
+                        }
+                    }
+                    if (usedj[jj]) {
+                        const double mu = yn[R + jj];
+                        const bool was = (pract[jj] >> (os & 63)) & 1ull;
+                        dual(s - 1, 1 + jj, aj, ej, was, mu, uj ? -mu : mu, fabs(mu), true, 1 + jj, os);
+                    }
+                }
+                // ---- box multiplier of own knot j + 1: row 0 of the unmasked block row -- the part of own segment j (left of the knot
+                // in the own direction) now, the part of own segment j + 1 was added one trip earlier (lam_next)
+                {
+                    double la = 0.0, ma = 0.0;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        const double t1 = sn.B01[c][0] * y[c], t2 = sn.B11[0][c] * yn[c];
+                        la += t1 + t2;
+                        ma += fabs(t1) + fabs(t2);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < K; ++jj)
+                        if (sbit(ract[jj], j)) { const double t4 = gr[jj][0] * yn[R + jj]; la += t4; ma += fabs(t4); }
+                    if (j + 1 == mm) {
+                        lam_meet = la;     // own half of the meeting knot's multiplier: finished across the pair below
+                        mag_meet = ma;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < B; ++i) yn[i] = y[i];
+            }
+        }
+        // The interior knot boxes need BOTH adjacent segments; a second, cheap pass over the own knots (state in LDS, no dependent
+        // FP64 chain) evaluates them with x_{j-1}, x_j, x_{j+1} in hand.
+        if (act && !single) {
+            double xa[B], xb[B], xc[B];   // blocks of own knots j - 1, j, j + 1
+#pragma unroll
+            for (int i = 0; i < B; ++i) { xa[i] = i < R ? x0[i] : 0.0; xb[i] = 0.0; xc[i] = 0.0; }
+            if (mm >= 2) {
+#pragma unroll
+                for (int i = 0; i < B; ++i) xb[i] = rec_ld(mm - 1, NL + i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < B; ++i) xb[i] = ym[i];
+            }
+            FullBlocks<R> sl;   // own segment j - 1
+            if (mm >= 2) sl.build(Tseg(0));
+            for (int j = 1; j < mm; ++j) {
+                const int s = mm - j;
+                if (j + 1 < mm) {
+#pragma unroll
+                    for (int i = 0; i < B; ++i) xc[i] = rec_ld(s - 1, NL + i);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < B; ++i) xc[i] = ym[i];
+                }
+                FullBlocks<R> sr;       // own segment j
+                sr.build(Tseg(j));
+                double lam = 0.0, mag = 0.0;
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const double t1 = sl.B01[c][0] * xa[c], t2 = (sl.B11[0][c] + sr.B00(0, c)) * xb[c], t3 = sr.B01[0][c] * xc[c];
+                    lam += t1 + t2 + t3;
+                    mag += fabs(t1) + fabs(t2) + fabs(t3);
+                }
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) {
+                    if (sbit(ract[jj], j - 1)) {   // rows of own segment j - 1: multiplier in block j, functional's end part
+                        double gl[R], gr[R];
+                        rowf(j - 1, jj, gl, gr);
+                        const double t4 = gr[0] * xb[R + jj];
+                        lam += t4; mag += fabs(t4);
+                    }
+                    if (sbit(ract[jj], j)) {       // rows of own segment j: multiplier in block j + 1, functional's start part
+                        double gl[R], gr[R];
+                        rowf(j, jj, gl, gr);
+                        const double t5 = gl[0] * xc[R + jj];
+                        lam += t5; mag += fabs(t5);
+                    }
+                }
+                const int kk = korig(j);
+                const bool pj = kbit(pin, j), ej = kbit(eqmask, j), uj = kbit(upper, j);
+                const bool was = (ppin >> (kk & 63)) & 1ull;
+                dual(s, 0, pj, ej, was, lam, uj ? lam : -lam, mag, false, 0, kk);
+                if (!pj) {
+                    const double l = klo(j), h = khi(j), v = xb[0];
+                    const double below = l - v, above = v - h;
+                    const double viol = below > above ? below : above;
+                    viol_cand(viol / (1.0 + fabs(below > above ? l : h)), 0, kk, above > below);
+                }
+#pragma unroll
+                for (int i = 0; i < B; ++i) { xa[i] = xb[i]; xb[i] = xc[i]; }
+                sl = sr;
+            }
+        }
+        // ---- the meeting knot's box: both halves of its multiplier
+        {
+            const double ol = swap_pair(lam_meet), om = swap_pair(mag_meet);
+            if (act && !single && mm >= 1 && M >= 2) {
+                const int kk = korig(mm);
+                const double lam = (isR ? ol + lam_meet : lam_meet + ol), mag = (isR ? om + mag_meet : mag_meet + om);
+                const bool pj = kbit(pin, mm), ej = kbit(eqmask, mm), uj = kbit(upper, mm);
+                const bool was = (ppin >> (kk & 63)) & 1ull;
+                dual(0, 0, pj, ej, was, lam, uj ? lam : -lam, mag, false, 0, kk);
+                if (!pj) {
+                    const double l = klo(mm), h = khi(mm), v = ym[0];
+                    const double below = l - v, above = v - h;
+                    const double viol = below > above ? below : above;
+                    viol_cand(viol / (1.0 + fabs(below > above ? l : h)), 0, kk, above > below);
+                }
+            }
+        }
+        if (single && !isR) {
+            // the polynomial is fixed by the boundary data; a row it violates makes the problem infeasible
+            bool viol = false;
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj) {
+                if (!(rused[jj] & 1ull)) continue;
+                double gl[R], gr[R];
+                rowf(0, jj, gl, gr);
+                double xM[R];
+                xM[0] = a.waypoints[base3 + 3 * M];
+                const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) xM[d + 1] = bc[(ND + d) * 3];
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < R; ++c) v += gl[c] * x0[c] + gr[c] * xM[c];
+                const double l = rlo(0, jj), h = rhi(0, jj);
+                viol = viol || (l - v > 1e-9 * (1.0 + fabs(l))) || (v - h > 1e-9 * (1.0 + fabs(h)));
+            }
+            capped = viol;
+        }
+        // ================= combine the halves' decisions (order-independent rules: identical in both lanes afterwards) =================
+        {
+            const double ov = swap_pair(vmax), ot = swap_pair(tmin);
+            const int ovk = swap_pair_i(vkind), ovi = swap_pair_i(vidx), ovu = swap_pair_i(vupper ? 1 : 0);
+            const int otk = swap_pair_i(tkind), oti = swap_pair_i(tidx), oinc = swap_pair_i(inconsistent ? 1 : 0), ocap = swap_pair_i(capped ? 1 : 0);
+            if (ovk >= 0 && (vkind < 0 || ov > vmax || (ov == vmax && (ovk < vkind || (ovk == vkind && ovi < vidx))))) { vmax = ov; vkind = ovk; vidx = ovi; vupper = ovu != 0; }
+            if (otk >= 0 && (tkind < 0 || ot < tmin || (ot == tmin && (otk < tkind || (otk == tkind && oti < tidx))))) { tmin = ot; tkind = otk; tidx = oti; }
+            inconsistent = inconsistent || (oinc != 0);
+            capped = capped || (ocap != 0);
+        }
+        // ================= dual active-set step (as qp_rows.h) =================
+        bool done = false;
+        if (act) {
+            if (single) {
+                finish = true;
+            } else {
+                ++it;
+                ppin = pin;
+#pragma unroll
+                for (int j = 0; j < K; ++j) pract[j] = ract[j];
+                if (capped) {
+                    finish = true;
+                } else if (inconsistent) {
+                    if (new_kind == 0) pin &= ~(1ull << new_idx);
+                    else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < K; ++j) ract[j] = req[j];
+                    }
+                    new_kind = -1;
+                    tpend = 1.0;
+                    capped = true;
+                } else if (tkind >= 0) {
+                    tpend = tmin;
+                    if (tkind == 0) pin &= ~(1ull << tidx);
+                    else ract[tkind - 1] &= ~(1ull << tidx);
+                } else {
+                    tpend = 1.0;
+                    new_kind = -1;
+                    new_idx = -1;
+                    if (vkind < 0) {
+                        done = true;
+                    } else if (vkind == 0) {
+                        pin |= 1ull << vidx;
+                        if (vupper) upper |= 1ull << vidx; else upper &= ~(1ull << vidx);
+                        new_kind = 0; new_idx = vidx;
+                    } else {
+                        ract[vkind - 1] |= 1ull << vidx;
+                        if (vupper) rup[vkind - 1] |= 1ull << vidx; else rup[vkind - 1] &= ~(1ull << vidx);
+                        new_kind = vkind; new_idx = vidx;
+                    }
+                }
+                if (!done && !finish && it >= a.max_iter) {
+                    if (new_kind == 0) pin &= ~(1ull << new_idx);
+                    else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
+                    new_kind = -1;
+                    capped = true;
+                }
+                if (done) finish = true;
+            }
+        }
+        // ================= hand-over: Hermite solution of the interior knots (original frame) =================
+        if (finish) {
+            for (int j = 1; j <= mm; ++j) {
+                if (j == mm && isR) continue;      // the meeting knot is written by the L lane
+                const int kk = korig(j);
+                if (kk < 1 || kk > M - 1) continue;
+                double* o = a.xsol + (base3 + 3LL * kk) * R;
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const double v = rec_ld(mm - j, NL + c);
+                    o[c] = (isR && (c & 1)) ? -v : v;
+                }
+            }
+            if (!isR) {
+                if (capped) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
+                if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
+                if (a.active) {
+                    unsigned long long* o = a.active + (size_t)g * (2 + 2 * K);
+                    const unsigned long long valid = M >= 2 ? ((1ull << M) - 2ull) : 0ull;
+                    o[0] = pin & ~eqmask & valid;
+                    o[1] = upper & o[0];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        o[2 + 2 * j] = ract[j] & ~req[j];
+                        o[3 + 2 * j] = rup[j] & o[2 + 2 * j];
+                    }
+                }
+            }
+            g = -1;
+            m = 0;
+        }
+    }
+}
+
+}  // namespace uavqp

@@ -691,6 +691,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 #include "qp_generic2.h"
 #include "qp_corridor.h"
 #include "qp_rows.h"
+#include "qp_rows2.h"
 #include "obstacle_grid.h"
 
 namespace uavqp {
@@ -775,6 +776,7 @@ extern "C" void uavqp_default_settings(uavqp_settings* out) {
     out->generic_waves_per_cu = 0;
     out->corridor_pdas_rounds = 3;
     out->corridor_initial_guess = 1;
+    out->rows_lanes_per_problem = 0;
     out->realloc_dead_band = 1.01;
     out->realloc_overshoot = 1.02;
 }
@@ -786,7 +788,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     if (!(st->eps_prim_inf >= 0.0) || !(st->realloc_dead_band >= 1.0) || !(st->realloc_overshoot >= 1.0) || !(st->realloc_dead_band < INFINITY) ||
         !(st->realloc_overshoot < INFINITY) || st->corridor_pdas_rounds < 0 || st->corridor_pdas_rounds > 64 ||
         (st->generic_lanes_per_traj != 0 && st->generic_lanes_per_traj != 1 && st->generic_lanes_per_traj != 2 && st->generic_lanes_per_traj != 3) || st->generic_waves_per_cu < 0 ||
-        st->generic_waves_per_cu > 32)
+        st->generic_waves_per_cu > 32 || st->rows_lanes_per_problem < 0 || st->rows_lanes_per_problem > 2)
         return UAVQP_ERR_INVALID_ARG;
     const int rc = apply_variant(ctx, st->kernel_variant);
     if (rc != UAVQP_OK) return rc;
@@ -1462,31 +1464,92 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         if (rc1 != UAVQP_OK) return rc1;
     }
     const int K = rows_per_segment, Bk = r + K;
-    const int F = Bk * (Bk + 1) / 2 + Bk + 2 * (1 + K);   // must match rows_solve_kernel's state layout
-    long long grid = (3LL * n_traj + 63) / 64;
-    const long long max_grid = (long long)ctx->num_cus * 4;
-    if (grid > max_grid) grid = max_grid;
-    const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
-    const size_t b_state = sizeof(double) * (size_t)Mmax * F * (size_t)grid * 64;
-    int rc = ensure_ws(ctx, b_xsol + 256 + b_state);
-    if (rc != UAVQP_OK) return rc;
     uavqp::RowsArgs a;
     a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax;
     a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 12 * Mmax * (1 + K) + 30;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.row_tau = d_row_tau; a.row_deriv = d_row_deriv; a.row_lo = d_row_lo; a.row_hi = d_row_hi;
-    a.xsol = ctx->ws; a.queue = (unsigned int*)((char*)ctx->ws + b_xsol); a.ws = (double*)((char*)ctx->ws + b_xsol + 256);
-    UAVQP_HIP(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
     a.status = d_status_out; a.iters = d_iters_out; a.active = (unsigned long long*)d_active_out;
     a.warm = warm ? (const unsigned long long*)ctx->rows_warm : nullptr;
-    hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
-    if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
-    if (r == 3) {
-        if (K == 1) hipLaunchKernelGGL((uavqp::rows_solve_kernel<3, 1>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((uavqp::rows_solve_kernel<3, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+    const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
+    const bool pair_kernel = ctx->settings.rows_lanes_per_problem != 1;
+    int rc;
+    if (pair_kernel) {
+        // two lanes per problem, sweep state in LDS (qp_rows2.h): 80 KiB per single-wave workgroup = two waves per CU
+        const int Fp = Bk * (Bk + 1) / 2 + Bk, NCN = 1 + K;
+        const int NT = uavqp::rows2_lds_knots(r, K);
+        const int kown = (Mmax + 1) / 2;                       // own knots of the longer half, meeting knot included = state slots 0..kown-1
+        const int ws_knots = kown > NT ? kown - NT : 0;
+        const long long pairs = 3LL * n_traj;
+        long long grid = (pairs + 31) / 32;
+        const long long max_grid = (long long)ctx->num_cus * 2;
+        if (grid > max_grid) grid = max_grid;
+        const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort;
+        const size_t b_desc = align256(sizeof(unsigned long long) * (size_t)pairs * (2 + 2 * K));
+        const size_t b_order = deal_by_length ? align256(sizeof(int32_t) * (size_t)n_traj) + 2048 : 0;
+        const size_t b_state = align256(sizeof(double) * (size_t)ws_knots * Fp * (size_t)grid * 64);
+        const size_t b_lam = align256(sizeof(double) * (size_t)kown * 2 * NCN * (size_t)grid * 64);
+        rc = ensure_ws(ctx, b_xsol + 256 + b_desc + b_order + b_state + b_lam);
+        if (rc != UAVQP_OK) return rc;
+        char* p = (char*)ctx->ws;
+        a.xsol = (double*)p; p += b_xsol;
+        a.queue = (unsigned int*)p; p += 256;
+        uavqp::Rows2Args aa;
+        aa.desc = (unsigned long long*)p; p += b_desc;
+        aa.order = nullptr;
+        if (deal_by_length) {
+            int32_t* d_order = (int32_t*)p;
+            int* d_hist = (int*)(p + b_order - 2048);
+            int* d_cursor = d_hist + 256;
+            UAVQP_HIP(hipMemsetAsync(d_hist, 0, 256 * sizeof(int), ctx->stream));
+            int sg = (n_traj + 255) / 256;
+            if (sg > ctx->num_cus * 4) sg = ctx->num_cus * 4;
+            hipLaunchKernelGGL(uavqp::seg_hist_kernel, dim3(sg), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, d_hist);
+            hipLaunchKernelGGL(uavqp::seg_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_hist, d_cursor);
+            hipLaunchKernelGGL(uavqp::seg_scatter_kernel, dim3(sg), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, d_cursor, d_order);
+            aa.order = d_order;
+        }
+        p += b_order;
+        a.ws = (double*)p; p += b_state;
+        aa.lam = (double*)p;
+        aa.ws_knots = ws_knots;
+        aa.lam_knots = kown;
+        UAVQP_HIP(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
+        hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
+        if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
+        aa.r = a;
+        long long pgrid = (pairs + 255) / 256;
+        if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
+#define UAVQP_ROWS2(RR, KK)                                                                                                                  \
+    do {                                                                                                                                     \
+        hipLaunchKernelGGL((uavqp::rows_prep_kernel<RR, KK>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);                       \
+        if (ws_knots > 0) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);  \
+        else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);             \
+    } while (0)
+        if (r == 3 && K == 1) UAVQP_ROWS2(3, 1);
+        else if (r == 3) UAVQP_ROWS2(3, 2);
+        else if (K == 1) UAVQP_ROWS2(4, 1);
+        else UAVQP_ROWS2(4, 2);
+#undef UAVQP_ROWS2
     } else {
-        if (K == 1) hipLaunchKernelGGL((uavqp::rows_solve_kernel<4, 1>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((uavqp::rows_solve_kernel<4, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        const int F = Bk * (Bk + 1) / 2 + Bk + 2 * (1 + K);   // must match rows_solve_kernel's state layout
+        long long grid = (3LL * n_traj + 63) / 64;
+        const long long max_grid = (long long)ctx->num_cus * 4;
+        if (grid > max_grid) grid = max_grid;
+        const size_t b_state = sizeof(double) * (size_t)Mmax * F * (size_t)grid * 64;
+        rc = ensure_ws(ctx, b_xsol + 256 + b_state);
+        if (rc != UAVQP_OK) return rc;
+        a.xsol = ctx->ws; a.queue = (unsigned int*)((char*)ctx->ws + b_xsol); a.ws = (double*)((char*)ctx->ws + b_xsol + 256);
+        UAVQP_HIP(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
+        hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
+        if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
+        if (r == 3) {
+            if (K == 1) hipLaunchKernelGGL((uavqp::rows_solve_kernel<3, 1>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((uavqp::rows_solve_kernel<3, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        } else {
+            if (K == 1) hipLaunchKernelGGL((uavqp::rows_solve_kernel<4, 1>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((uavqp::rows_solve_kernel<4, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        }
     }
     // Hermite solution -> coefficients (the corridor solver's emission kernel; it reads the same fields)
     uavqp::CorridorArgs e{};
