@@ -21,6 +21,16 @@
 #pragma once
 #include "qp_rows.h"
 
+#ifdef UAVQP_ROWS2_TIMING   // probe build (tools/rows_sections.py): cycles of wave 0 per section -> the queue block, bytes 64..
+#define R2_CT_DECL long long r2_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long r2_t = __builtin_readcyclecounter();
+#define R2_CT(k) do { const long long n_ = __builtin_readcyclecounter(); r2_acc[k] += n_ - r2_t; r2_t = n_; } while (0)
+#define R2_CT_FLUSH do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) reinterpret_cast<long long*>(a.queue)[8 + k_] = r2_acc[k_]; } while (0)
+#else
+#define R2_CT_DECL
+#define R2_CT(k) do {} while (0)
+#define R2_CT_FLUSH do {} while (0)
+#endif
+
 namespace uavqp {
 
 constexpr int rows2_lds_knots(int R, int K) { return (80 * 1024) / (64 * 8 * ((R + K) * (R + K + 1) / 2 + (R + K))); }
@@ -30,8 +40,10 @@ struct Rows2Args {
     unsigned long long* desc;   // [problem][2 + 2 K]: {valid | M >= 2 flag, eqmask, rused[K], req[K]} from rows_prep_kernel
     const int32_t* order;       // dealing order of the trajectories (longest first), may be null
     double* lam;                // dual state [wave][own knot 0..kown][2 (1 + K)][lane]: current / new multiplier of the knot box and the rows
+    double* gfun;               // row functionals [segment][K][2 R] (g_l, g_r of p^(d)(tau T) = g_l' x_k + g_r' x_{k+1}, ORIGINAL frame), made once per
+                                // solve by rows_gfun_kernel: they depend on the time allocation only (not on the axis, not on the working set)
     int ws_knots;               // own knots per lane kept in the HBM workspace (beyond the LDS slots)
-    int lam_knots;              // own knots per lane in `lam`
+    int lam_knots;              // own knots per lane in `lam` (= own segments per lane in `gfun`)
 };
 
 // validation + permanent masks, one lane per (trajectory, axis) problem.  desc[0]: bit 0 = valid, bit 1 = has a free knot (M >= 2),
@@ -79,6 +91,23 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
     }
 }
 
+// row functionals of every (segment, row slot): one lane each
+template <int R, int K>
+__global__ __launch_bounds__(256) void rows_gfun_kernel(Rows2Args aa, long long total_segments) {
+    const RowsArgs& a = aa.r;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total_segments * K; e += (long long)gridDim.x * blockDim.x) {
+        const int d = a.row_deriv[e];
+        double gl[R], gr[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
+        const double T = a.times[e / K], tau = a.row_tau[e];
+        if (d >= 0 && d < R && T > 0.0 && T < INFINITY && tau >= 0.0 && tau < 1.0) row_functional<R>(T, tau, d, gl, gr);
+        double* o = aa.gfun + (size_t)e * 2 * R;
+#pragma unroll
+        for (int c = 0; c < R; ++c) { o[c] = gl[c]; o[R + c] = gr[c]; }
+    }
+}
+
 template <int R, int K, bool WS>
 __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
     const RowsArgs& a = aa.r;
@@ -102,6 +131,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
 
     const long long total = (long long)a.n_traj * 3;
     bool queue_empty = false;
+    R2_CT_DECL
 
     // ---- problem state (identical in both lanes of a pair unless noted)
     long long g = -1;
@@ -131,13 +161,16 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
     auto rlo = [&](int s, int j) -> double { return a.row_lo[((size_t)(s0 + sorig(s)) * K + j) * 3 + ax]; };
     auto rhi = [&](int s, int j) -> double { return a.row_hi[((size_t)(s0 + sorig(s)) * K + j) * 3 + ax]; };
     // functional of row slot j of own segment s in the OWN frame: value = gl' x'_s + gr' x'_{s+1}
+    // functional of row slot j of own segment s in the OWN frame: value = gl' x'_s + gr' x'_{s+1}; for the reversed lane the two end
+    // knots swap and odd derivatives change sign
     auto rowf = [&](int s, int j, double (&gl)[R], double (&gr)[R]) {
-        const size_t e = (size_t)(s0 + sorig(s)) * K + j;
+        const double* gp = aa.gfun + ((size_t)(s0 + sorig(s)) * K + j) * 2 * R;
         double ol[R], orr[R];
-        row_functional<R>(Tseg(s), a.row_tau[e], a.row_deriv[e], ol, orr);
+#pragma unroll
+        for (int c = 0; c < R; ++c) { ol[c] = gp[c]; orr[c] = gp[R + c]; }
 #pragma unroll
         for (int c = 0; c < R; ++c) {
-            const double fl = (isR && (c & 1)) ? -orr[c] : orr[c], fr = (isR && (c & 1)) ? -ol[c] : ol[c];
+            const double fl = (c & 1) ? -orr[c] : orr[c], fr = (c & 1) ? -ol[c] : ol[c];
             gl[c] = isR ? fl : ol[c];
             gr[c] = isR ? fr : orr[c];
         }
@@ -194,6 +227,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             }
         }
         const bool act = g >= 0;
+        R2_CT(0);
         if (__ballot(act) == 0ull) {
             if (queue_empty) break;
             continue;
@@ -214,25 +248,47 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         // own partial block of a knot: rows of own segment j - 1 (mu part), coupling to the previous block eliminated.
         // full = true adds the next segment's start block and the coupling to known neighbours behind it (interior own knots);
         // the meeting knot leaves both to the partner lane.
-        auto block = [&](int j, bool full, double (&D)[B][B], double (&rhs)[B], bool (&fx)[B], double (&vx)[B]) {
-            FullBlocks<R> sb;
-            if (full) sb.build(Tseg(j));
-            double gl[K][R], gr[K][R], rb[K];
+        // every global input of a block step: requested together and ONE STEP AHEAD of its use (the loop below loads the inputs of
+        // block j + 1 while block j is eliminated), unconditionally -- what a lane does not need is discarded by the selects
+        struct FIn { double T, gl[K][R], gr[K][R], rl[K], rh[K], bl, bh, nl, nh; };
+        auto load_fin = [&](int j, FIn& f) {
+            const int jc = j < 1 ? 1 : (j > mm ? (mm < 1 ? 1 : mm) : j);       // clamped: a speculative load stays inside the trajectory
+            f.T = Tseg(jc < M ? jc : M - 1);
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj) {
+                rowf(jc - 1, jj, f.gl[jj], f.gr[jj]);
+                f.rl[jj] = rlo(jc - 1, jj);
+                f.rh[jj] = rhi(jc - 1, jj);
+            }
+            f.bl = klo(jc); f.bh = khi(jc);
+            const int jn = jc + 1 <= mm ? jc + 1 : jc;
+            f.nl = klo(jn); f.nh = khi(jn);
+        };
+        auto block = [&](int j, bool full, const FIn& in, double (&D)[B][B], double (&rhs)[B], bool (&fx)[B], double (&vx)[B]) {
+            const double Tj = in.T;
+            double gl[K][R], gr[K][R], rb[K], rlv[K], rhv[K];
             bool racv[K];
 #pragma unroll
             for (int jj = 0; jj < K; ++jj) {
-                racv[jj] = sbit(ract[jj], j - 1);
-                rb[jj] = 0.0;
 #pragma unroll
-                for (int c = 0; c < R; ++c) { gl[jj][c] = 0.0; gr[jj][c] = 0.0; }
-                if (racv[jj]) {
-                    rowf(j - 1, jj, gl[jj], gr[jj]);
-                    rb[jj] = sbit(rup[jj], j - 1) ? rhi(j - 1, jj) : rlo(j - 1, jj);
-                }
+                for (int c = 0; c < R; ++c) { gl[jj][c] = in.gl[jj][c]; gr[jj][c] = in.gr[jj][c]; }
+                rlv[jj] = in.rl[jj];
+                rhv[jj] = in.rh[jj];
+            }
+            const double bl = in.bl, bh = in.bh;
+            const double nl = in.nl, nh = in.nh;
+            FullBlocks<R> sb;
+            if (full) sb.build(Tj);
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj) {
+                racv[jj] = sbit(ract[jj], j - 1);
+                rb[jj] = racv[jj] ? (sbit(rup[jj], j - 1) ? rhv[jj] : rlv[jj]) : 0.0;
+#pragma unroll
+                for (int c = 0; c < R; ++c) { gl[jj][c] = racv[jj] ? gl[jj][c] : 0.0; gr[jj][c] = racv[jj] ? gr[jj][c] : 0.0; }
             }
             const bool interior = korig(j) >= 1 && korig(j) <= M - 1;
             const bool pk = interior && kbit(pin, j);
-            const double zc = pk ? (kbit(upper, j) ? khi(j) : klo(j)) : 0.0;
+            const double zc = pk ? (kbit(upper, j) ? bh : bl) : 0.0;
 #pragma unroll
             for (int i = 0; i < B; ++i) {
                 rhs[i] = 0.0;
@@ -257,11 +313,9 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             }
             if (full) {
                 const bool pnext = kbit(pin, j + 1);   // own knot j + 1 <= m: an interior knot (the meeting knot at the latest)
-                if (pnext) {
-                    const double zn = kbit(upper, j + 1) ? khi(j + 1) : klo(j + 1);
+                const double zn = pnext ? (kbit(upper, j + 1) ? nh : nl) : 0.0;
 #pragma unroll
-                    for (int i = 0; i < R; ++i) rhs[i] -= sb.B01[i][0] * zn;
-                }
+                for (int i = 0; i < R; ++i) rhs[i] -= sb.B01[i][0] * zn;
             }
 #pragma unroll
             for (int i = 0; i < B; ++i) { fx[i] = false; vx[i] = 0.0; }
@@ -309,10 +363,14 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             if (full) { sa = sb; pprev = pk; zprev = zc; }
         };
         if (mm >= 1 && !single) sa.build(Tseg(0));
+        FIn fnx;
+        if (mm >= 1 && !single) load_fin(1, fnx);
         for (int j = 1; j < mm; ++j) {
             double D[B][B], rhs[B], vx[B];
             bool fx[B];
-            block(j, true, D, rhs, fx, vx);
+            const FIn fcur = fnx;
+            load_fin(j + 1, fnx);          // (j + 1 <= mm: the last one is the meeting block's)
+            block(j, true, fcur, D, rhs, fx, vx);
 #pragma unroll
             for (int i = 0; i < B; ++i)
                 if (fx[i]) {
@@ -341,6 +399,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             lprev = ldl;
         }
 
+        R2_CT(1);
         // ================= meeting block [x_c ; mu_L ; mu_R], assembled in the L frame =================
         double ym[B];             // solution of the own meeting block [x_c (own frame) ; mu_own]
 #pragma unroll
@@ -357,7 +416,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 for (int c = 0; c < B; ++c) D[i][c] = 0.0;
             }
             const bool has = act && !single && mm >= 1;
-            if (has) block(mm, false, D, rhs, fxm, vx);
+            if (has) block(mm, false, fnx, D, rhs, fxm, vx);
             // exchange lower triangles and right-hand sides; conj = F . F on the x part of the partner's (reversed-frame) block
             double C[BM][BM], r7[BM];
 #pragma unroll
@@ -432,6 +491,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             }
         }
 
+        R2_CT(2);
         // ================= backward sweep + the decisions of this iteration (own constraints only) =================
         double vmax = 0.0;           // most violated inactive constraint
         int vkind = -1, vidx = NONE;
@@ -446,39 +506,86 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         auto step_cand = [&](double t, int kind, int idx) {
             if (t < tmin || (t == tmin && (kind < tkind || (kind == tkind && idx < tidx)))) { tmin = t; tkind = kind; tidx = idx; }
         };
-        // multiplier bookkeeping of one constraint (slot s, constraint c): current value by the pending interpolation, ratio test
+        // multiplier bookkeeping of one constraint: current value by the pending interpolation, ratio test; lc / ln: its stored current /
+        // new multiplier in, the values to store out
         // (bad: the wrong-signed amount of lam_new, mag: scale of its rounding; rows add |current multiplier| to the scale as qp_rows.h does)
-        auto dual = [&](int s, int c, bool active, bool equality, bool was, double lam_new, double bad, double mag, bool add_lc, int kind, int idx) {
-            double lc = LC(s, c);
-            const double ln = LN(s, c);
+        auto dual = [&](double& lc, double& ln, bool active, bool equality, bool was, double lam_new, double bad, double mag, bool add_lc, int kind, int idx) {
             lc = was ? lc + tpend * (ln - lc) : 0.0;
             const bool wrong = bad > 1e-13 * (mag + (add_lc ? fabs(lc) : 0.0)) && bad > 0.0;
             if (active && !equality && wrong && !(new_kind == kind && new_idx == idx)) {
                 const double den = lc - lam_new;
-                double t = den != 0.0 ? lc / den : 0.0;
+                double t = den != 0.0 ? lc * fast_rcp(den) : 0.0;   // (fast_rcp: full float64 accuracy for normal arguments, a third of the instructions of a division)
                 t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
                 step_cand(t, kind, idx);
             }
-            LC(s, c) = active ? lc : 0.0;
-            LN(s, c) = active ? lam_new : 0.0;
+            lc = active ? lc : 0.0;
+            ln = active ? lam_new : 0.0;
         };
         if (act && !single) {
-            double yn[B];            // block of own knot j + 1
+            double yn[B], ynn[B];    // blocks of own knots j + 1, j + 2
 #pragma unroll
-            for (int i = 0; i < B; ++i) yn[i] = ym[i];
-            // the rows of own segment mm - 1 (they ride in the meeting block)
+            for (int i = 0; i < B; ++i) { yn[i] = ym[i]; ynn[i] = 0.0; }
+            FullBlocks<R> snn;       // own segment j + 1
+            double glp0[K];          // position components of g_l of the ACTIVE rows of own segment j + 1 (0 otherwise)
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj) glp0[jj] = 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int c = 0; c < R; ++c) { snn.B11[i][c] = 0.0; snn.B01[i][c] = 0.0; }
+            // global inputs of a backward step (own segment j): duration, functionals and bounds of its rows, box of own knot j + 1, stored
+            // multipliers of block j + 1
+            // The part the x_j chain needs at once (duration, functionals) is requested ONE STEP AHEAD; the rest (bounds, stored multipliers:
+            // "late" work) together at the top of its step.  (Everything one step ahead was measured slower: 51.7 k vs 41.0 k cycles per trip
+            // -- the second full input set pushes the loop into the accumulator registers.)
+            struct BInA { double T, gl[K][R], gr[K][R]; };
+            struct BInB { double rl[K], rh[K], bl, bh, lc[NCN], ln[NCN]; };
+            auto load_bina = [&](int j, BInA& f) {
+                const int jc = j < 0 ? 0 : j;
+                f.T = Tseg(jc);
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) rowf(jc, jj, f.gl[jj], f.gr[jj]);
+            };
+            auto load_binb = [&](int j, BInB& f) {
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) {
+                    f.rl[jj] = rlo(j, jj);
+                    f.rh[jj] = rhi(j, jj);
+                }
+                f.bl = klo(j + 1); f.bh = khi(j + 1);
+                const int sl = mm - j - 1;
+#pragma unroll
+                for (int c = 0; c < NCN; ++c) { f.lc[c] = LC(sl, c); f.ln[c] = LN(sl, c); }
+            };
+            BInA anx;
+            load_bina(mm - 1, anx);
             for (int j = mm - 1; j >= 0; --j) {
                 // own segment j joins own knots j and j + 1; block j + 1 (= yn) carries its rows' multipliers
-                FullBlocks<R> sn;
-                sn.build(Tseg(j));
-                double gl[K][R], gr[K][R];
+                const int sl1 = mm - j - 1;                 // slot of own knot j + 1
+                const BInA ba_ = anx;
+                load_bina(j - 1, anx);
+                BInB bc_;
+                load_binb(j, bc_);
+                const double Tj = ba_.T;
+                double gl[K][R], gr[K][R], rlv[K], rhv[K], lcv[NCN], lnv[NCN];
                 bool usedj[K];
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) {
+#pragma unroll
+                    for (int c = 0; c < R; ++c) { gl[jj][c] = ba_.gl[jj][c]; gr[jj][c] = ba_.gr[jj][c]; }
+                    rlv[jj] = bc_.rl[jj];
+                    rhv[jj] = bc_.rh[jj];
+                }
+                const double bl = bc_.bl, bh = bc_.bh;
+#pragma unroll
+                for (int c = 0; c < NCN; ++c) { lcv[c] = bc_.lc[c]; lnv[c] = bc_.ln[c]; }
+                FullBlocks<R> sn;
+                sn.build(Tj);
 #pragma unroll
                 for (int jj = 0; jj < K; ++jj) {
                     usedj[jj] = sbit(rused[jj], j);
 #pragma unroll
-                    for (int c = 0; c < R; ++c) { gl[jj][c] = 0.0; gr[jj][c] = 0.0; }
-                    if (usedj[jj]) rowf(j, jj, gl[jj], gr[jj]);
+                    for (int c = 0; c < R; ++c) { gl[jj][c] = usedj[jj] ? gl[jj][c] : 0.0; gr[jj][c] = usedj[jj] ? gr[jj][c] : 0.0; }
                 }
                 double y[B];
                 const int s = mm - j;
@@ -514,6 +621,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     for (int i = 0; i < B; ++i) y[i] = i < R ? x0[i] : 0.0;
                 }
                 // ---- rows of own segment j: values (inactive: violation; active: must sit on the bound), multipliers (block j + 1)
+                double la = 0.0, ma = 0.0;   // own knot j + 1's box multiplier: the part of own segment j
 #pragma unroll
                 for (int jj = 0; jj < K; ++jj) {
                     const int os = sorig(j);
@@ -523,106 +631,70 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
 #pragma unroll
                         for (int c = 0; c < R; ++c) v += gl[jj][c] * y[c] + gr[jj][c] * yn[c];
                         if (aj) {
-                            const double bnd = uj ? rhi(j, jj) : rlo(j, jj);
+                            const double bnd = uj ? rhv[jj] : rlv[jj];
                             if (!(fabs(v - bnd) <= 1e-8 * (1.0 + fabs(bnd)))) inconsistent = true;
+                            const double t4 = gr[jj][0] * yn[R + jj];
+                            la += t4; ma += fabs(t4);
                         } else {
-                            const double l = rlo(j, jj), h = rhi(j, jj);
+                            const double l = rlv[jj], h = rhv[jj];
                             const double below = l - v, above = v - h;
                             const double viol = below > above ? below : above;
-                            viol_cand(viol / (1.0 + fabs(below > above ? l : h)), 1 + jj, os, above > below);
+                            viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), 1 + jj, os, above > below);
                         }
-                    }
-                    if (usedj[jj]) {
                         const double mu = yn[R + jj];
                         const bool was = (pract[jj] >> (os & 63)) & 1ull;
-                        dual(s - 1, 1 + jj, aj, ej, was, mu, uj ? -mu : mu, fabs(mu), true, 1 + jj, os);
+                        dual(lcv[1 + jj], lnv[1 + jj], aj, ej, was, mu, uj ? -mu : mu, fabs(mu), true, 1 + jj, os);
+                    } else {
+                        lcv[1 + jj] = 0.0;
+                        lnv[1 + jj] = 0.0;
                     }
                 }
-                // ---- box multiplier of own knot j + 1: row 0 of the unmasked block row -- the part of own segment j (left of the knot
-                // in the own direction) now, the part of own segment j + 1 was added one trip earlier (lam_next)
-                {
-                    double la = 0.0, ma = 0.0;
-#pragma unroll
-                    for (int c = 0; c < R; ++c) {
-                        const double t1 = sn.B01[c][0] * y[c], t2 = sn.B11[0][c] * yn[c];
-                        la += t1 + t2;
-                        ma += fabs(t1) + fabs(t2);
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < K; ++jj)
-                        if (sbit(ract[jj], j)) { const double t4 = gr[jj][0] * yn[R + jj]; la += t4; ma += fabs(t4); }
-                    if (j + 1 == mm) {
-                        lam_meet = la;     // own half of the meeting knot's multiplier: finished across the pair below
-                        mag_meet = ma;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < B; ++i) yn[i] = y[i];
-            }
-        }
-        // The interior knot boxes need BOTH adjacent segments; a second, cheap pass over the own knots (state in LDS, no dependent
-        // FP64 chain) evaluates them with x_{j-1}, x_j, x_{j+1} in hand.
-        if (act && !single) {
-            double xa[B], xb[B], xc[B];   // blocks of own knots j - 1, j, j + 1
-#pragma unroll
-            for (int i = 0; i < B; ++i) { xa[i] = i < R ? x0[i] : 0.0; xb[i] = 0.0; xc[i] = 0.0; }
-            if (mm >= 2) {
-#pragma unroll
-                for (int i = 0; i < B; ++i) xb[i] = rec_ld(mm - 1, NL + i);
-            } else {
-#pragma unroll
-                for (int i = 0; i < B; ++i) xb[i] = ym[i];
-            }
-            FullBlocks<R> sl;   // own segment j - 1
-            if (mm >= 2) sl.build(Tseg(0));
-            for (int j = 1; j < mm; ++j) {
-                const int s = mm - j;
-                if (j + 1 < mm) {
-#pragma unroll
-                    for (int i = 0; i < B; ++i) xc[i] = rec_ld(s - 1, NL + i);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < B; ++i) xc[i] = ym[i];
-                }
-                FullBlocks<R> sr;       // own segment j
-                sr.build(Tseg(j));
-                double lam = 0.0, mag = 0.0;
+                // ---- box of own knot j + 1: multiplier = row 0 of the unmasked block row (own segments j and j + 1, x_j, x_{j+1}, x_{j+2},
+                // the multipliers of the active rows of both segments); free position outside its box?
 #pragma unroll
                 for (int c = 0; c < R; ++c) {
-                    const double t1 = sl.B01[c][0] * xa[c], t2 = (sl.B11[0][c] + sr.B00(0, c)) * xb[c], t3 = sr.B01[0][c] * xc[c];
-                    lam += t1 + t2 + t3;
-                    mag += fabs(t1) + fabs(t2) + fabs(t3);
+                    const double t1 = sn.B01[c][0] * y[c], t2 = sn.B11[0][c] * yn[c];
+                    la += t1 + t2;
+                    ma += fabs(t1) + fabs(t2);
                 }
+                if (j + 1 == mm) {
+                    lam_meet = la;     // own half of the meeting knot's multiplier: finished across the pair below
+                    mag_meet = ma;
+                } else {
+                    double lam = la, mag = ma;
 #pragma unroll
-                for (int jj = 0; jj < K; ++jj) {
-                    if (sbit(ract[jj], j - 1)) {   // rows of own segment j - 1: multiplier in block j, functional's end part
-                        double gl[R], gr[R];
-                        rowf(j - 1, jj, gl, gr);
-                        const double t4 = gr[0] * xb[R + jj];
-                        lam += t4; mag += fabs(t4);
+                    for (int c = 0; c < R; ++c) {
+                        const double t2 = snn.B00(0, c) * yn[c], t3 = snn.B01[0][c] * ynn[c];
+                        lam += t2 + t3;
+                        mag += fabs(t2) + fabs(t3);
                     }
-                    if (sbit(ract[jj], j)) {       // rows of own segment j: multiplier in block j + 1, functional's start part
-                        double gl[R], gr[R];
-                        rowf(j, jj, gl, gr);
-                        const double t5 = gl[0] * xc[R + jj];
-                        lam += t5; mag += fabs(t5);
-                    }
-                }
-                const int kk = korig(j);
-                const bool pj = kbit(pin, j), ej = kbit(eqmask, j), uj = kbit(upper, j);
-                const bool was = (ppin >> (kk & 63)) & 1ull;
-                dual(s, 0, pj, ej, was, lam, uj ? lam : -lam, mag, false, 0, kk);
-                if (!pj) {
-                    const double l = klo(j), h = khi(j), v = xb[0];
-                    const double below = l - v, above = v - h;
-                    const double viol = below > above ? below : above;
-                    viol_cand(viol / (1.0 + fabs(below > above ? l : h)), 0, kk, above > below);
-                }
 #pragma unroll
-                for (int i = 0; i < B; ++i) { xa[i] = xb[i]; xb[i] = xc[i]; }
-                sl = sr;
+                    for (int jj = 0; jj < K; ++jj) { const double t5 = glp0[jj] * ynn[R + jj]; lam += t5; mag += fabs(t5); }
+                    const int kk = korig(j + 1);
+                    const bool pj = kbit(pin, j + 1), ej = kbit(eqmask, j + 1), uj = kbit(upper, j + 1);
+                    const bool was = (ppin >> (kk & 63)) & 1ull;
+                    dual(lcv[0], lnv[0], pj, ej, was, lam, uj ? lam : -lam, mag, false, 0, kk);
+                    if (!pj) {
+                        const double l = bl, h = bh, v = yn[0];
+                        const double below = l - v, above = v - h;
+                        const double viol = below > above ? below : above;
+                        viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), 0, kk, above > below);
+                    }
+                }
+                // the block's multipliers back (the meeting knot's box -- slot 0, constraint 0 -- belongs to the pair step below)
+#pragma unroll
+                for (int c = 0; c < NCN; ++c)
+                    if (c > 0 || j + 1 < mm) { LC(sl1, c) = lcv[c]; LN(sl1, c) = lnv[c]; }
+                // ---- rotate
+#pragma unroll
+                for (int i = 0; i < B; ++i) { ynn[i] = yn[i]; yn[i] = y[i]; }
+                snn = sn;
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) glp0[jj] = sbit(ract[jj], j) ? gl[jj][0] : 0.0;
             }
         }
+        R2_CT(3);
+        R2_CT(4);
         // ---- the meeting knot's box: both halves of its multiplier
         {
             const double ol = swap_pair(lam_meet), om = swap_pair(mag_meet);
@@ -631,12 +703,15 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 const double lam = (isR ? ol + lam_meet : lam_meet + ol), mag = (isR ? om + mag_meet : mag_meet + om);
                 const bool pj = kbit(pin, mm), ej = kbit(eqmask, mm), uj = kbit(upper, mm);
                 const bool was = (ppin >> (kk & 63)) & 1ull;
-                dual(0, 0, pj, ej, was, lam, uj ? lam : -lam, mag, false, 0, kk);
+                double lc0 = LC(0, 0), ln0 = LN(0, 0);
+                dual(lc0, ln0, pj, ej, was, lam, uj ? lam : -lam, mag, false, 0, kk);
+                LC(0, 0) = lc0;
+                LN(0, 0) = ln0;
                 if (!pj) {
                     const double l = klo(mm), h = khi(mm), v = ym[0];
                     const double below = l - v, above = v - h;
                     const double viol = below > above ? below : above;
-                    viol_cand(viol / (1.0 + fabs(below > above ? l : h)), 0, kk, above > below);
+                    viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), 0, kk, above > below);
                 }
             }
         }
@@ -722,6 +797,10 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 if (done) finish = true;
             }
         }
+        R2_CT(5);
+#ifdef UAVQP_ROWS2_TIMING
+        r2_acc[7] += 1;
+#endif
         // ================= hand-over: Hermite solution of the interior knots (original frame) =================
         if (finish) {
             for (int j = 1; j <= mm; ++j) {
@@ -753,7 +832,9 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             g = -1;
             m = 0;
         }
+        R2_CT(6);
     }
+    R2_CT_FLUSH;
 }
 
 }  // namespace uavqp

@@ -1410,6 +1410,16 @@ extern "C" int uavqp_debug_corridor_stamps(uavqp_ctx* ctx, long long* out7) {
 }
 #endif
 
+#ifdef UAVQP_ROWS2_TIMING
+// probe build only (tools/rows_sections.py): cycles wave 0 of the last pair-kernel rows solve spent per section
+extern "C" int uavqp_debug_rows2_stamps(uavqp_ctx* ctx, long long* out8) {
+    if (!ctx || !out8 || !ctx->dbg_queue) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    UAVQP_HIP(hipMemcpy(out8, (char*)ctx->dbg_queue + 64, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return UAVQP_OK;
+}
+#endif
+
 #ifdef G2_TIMING
 // (probe build) s_memtime stamps of wave 0 of the last ragged pair-kernel launch: tools/generic2_sections.py
 extern "C" int uavqp_debug_generic2_stamps(uavqp_ctx* ctx, long long* out9) {
@@ -1489,11 +1499,14 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         const size_t b_order = deal_by_length ? align256(sizeof(int32_t) * (size_t)n_traj) + 2048 : 0;
         const size_t b_state = align256(sizeof(double) * (size_t)ws_knots * Fp * (size_t)grid * 64);
         const size_t b_lam = align256(sizeof(double) * (size_t)kown * 2 * NCN * (size_t)grid * 64);
-        rc = ensure_ws(ctx, b_xsol + 256 + b_desc + b_order + b_state + b_lam);
+        const long long total_seg = rows - n_traj;
+        const size_t b_gfun = align256(sizeof(double) * (size_t)total_seg * K * 2 * r);
+        rc = ensure_ws(ctx, b_xsol + 256 + b_desc + b_order + b_state + b_lam + b_gfun);
         if (rc != UAVQP_OK) return rc;
         char* p = (char*)ctx->ws;
         a.xsol = (double*)p; p += b_xsol;
         a.queue = (unsigned int*)p; p += 256;
+        ctx->dbg_queue = a.queue;
         uavqp::Rows2Args aa;
         aa.desc = (unsigned long long*)p; p += b_desc;
         aa.order = nullptr;
@@ -1511,7 +1524,8 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         }
         p += b_order;
         a.ws = (double*)p; p += b_state;
-        aa.lam = (double*)p;
+        aa.lam = (double*)p; p += b_lam;
+        aa.gfun = (double*)p;
         aa.ws_knots = ws_knots;
         aa.lam_knots = kown;
         UAVQP_HIP(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
@@ -1520,9 +1534,13 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         aa.r = a;
         long long pgrid = (pairs + 255) / 256;
         if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
+        long long ggrid = (total_seg * K + 255) / 256;
+        if (ggrid > (long long)ctx->num_cus * 16) ggrid = (long long)ctx->num_cus * 16;
+        if (ggrid < 1) ggrid = 1;
 #define UAVQP_ROWS2(RR, KK)                                                                                                                  \
     do {                                                                                                                                     \
         hipLaunchKernelGGL((uavqp::rows_prep_kernel<RR, KK>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);                       \
+        hipLaunchKernelGGL((uavqp::rows_gfun_kernel<RR, KK>), dim3((unsigned)ggrid), dim3(256), 0, ctx->stream, aa, total_seg);           \
         if (ws_knots > 0) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);  \
         else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);             \
     } while (0)
