@@ -543,14 +543,15 @@ def main():
         fp64 = kernels = None
         if world == 1 and not args.no_fp64:
             prof_steps = 2 if args.config == 5 else 40
+            trace_steps = 2 if args.config == 5 else 1000   # the trace is cheap: enough launches that the average is the steady state
             f64 = measure_fp64(args, prof_steps)
-            kt = measure_kernel_times(args, prof_steps)
+            kt = measure_kernel_times(args, trace_steps)
             if f64 and kt:
                 kernels = []
                 tot_us = sum(v["total_us"] for v in kt.values())
                 for name, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_us"]):
                     fl = f64.get(name, {}).get("flops_per_launch", 0.0)
-                    kernels.append({"kernel": name, "launches_per_step": v["calls"] / (prof_steps + 1), "avg_us": v["avg_us"],
+                    kernels.append({"kernel": name, "launches_per_step": v["calls"] / (trace_steps + 1), "avg_us": v["avg_us"],
                                     "share_of_gpu_time": v["total_us"] / tot_us if tot_us else None, "fp64_flops_per_launch": fl,
                                     "fp64_tflops": fl / (v["avg_us"] * 1e-6) / 1e12 if v["avg_us"] > 0 else None,
                                     "fp64_frac_of_vector_peak": fl / (v["avg_us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if v["avg_us"] > 0 else None})

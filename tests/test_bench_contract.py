@@ -1,4 +1,4 @@
-"""CPU: the bench.py contract, checked on the committed round-2 bench line (profiles/r02_bench4096.json -- produced by
+"""CPU: the bench.py contract, checked on the committed round-3 bench line (profiles/r03_bench4096.json -- produced by
 `python bench.py` on the MI355X box, tools/collect_profiles.sh) and on the script's defaults.  No GPU, no oracle."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_key():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench4096.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench4096.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -29,6 +29,13 @@ def test_committed_bench_line_has_every_contract_key():
     assert r["kernel_ms"] <= d["ms_per_step"] * (1 + 1e-9) and r["kernel_ms"] > 0.9 * d["ms_per_step"]
     assert r["working_set_bytes"] > 256 * 2 ** 20               # the steps rotate over more than the Infinity Cache
     assert d["timing"]["repeats"] >= 10 and "pipelined" in d and d["pipelined"]["value"] > 0
+    assert d["pipelined"]["steps"] >= 200                       # the overlapped leg has its own step count (independent of --steps)
+    # FP64 roof next to the HBM one, from the SQ instruction counters of the same command
+    f = r["fp64"]
+    assert f["peak"] == 78.6 and f["unit"] == "TFLOP/s" and abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-12
+    w = f["wave_insts_per_launch"]
+    assert abs(f["flops_per_launch"] - 64.0 * (w["ADD_F64"] + w["MUL_F64"] + 2 * w["FMA_F64"] + w["TRANS_F64"])) < 1e-6 * f["flops_per_launch"]
+    assert d["kernels"][0]["kernel"].startswith("solve_twisted_kernel<4, 8,") and abs(d["kernels"][0]["launches_per_step"] - 1.0) < 0.05
     assert r["algorithmic_bytes_per_launch"] == 4096 * 1960            # SURVEY.md section 8-d figure x units per launch
     assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.5 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
@@ -38,9 +45,9 @@ def test_committed_bench_line_has_every_contract_key():
 
 
 def test_rocprof_summary_agrees_with_the_bench_line():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench4096.json")))
-    txt = open(os.path.join(ROOT, "profiles", "r02_bench4096_kernel_stats.csv")).read()
-    m = re.search(r'"void uavqp::solve_twisted_kernel<4, 8, 8, 8>\(uavqp::BatchArgs\)",(\d+),(\d+),([\d.]+)', txt)
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench4096.json")))
+    txt = open(os.path.join(ROOT, "profiles", "r03_bench4096_kernel_stats.csv")).read()
+    m = re.search(r'"void uavqp::solve_twisted_kernel<4, 8, 4, 16>\(uavqp::BatchArgs\)",(\d+),(\d+),([\d.]+)', txt)
     assert m, "headline kernel missing from the rocprofv3 --stats summary"
     avg_us = float(m.group(3)) / 1e3
     assert abs(avg_us - d["roofline"]["kernel_ms"] * 1e3) < 0.05 * avg_us      # same kernel, same command: within 5 %

@@ -1,8 +1,9 @@
 #!/bin/bash
 # usage (on the GPU box): tools/collect_profiles.sh <round-tag>     -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/)
 # The bench line, the rocprofv3 --kernel-trace --stats summary of the SAME command, the PMC counters of the headline kernel, the
-# other configs (tools/bench_configs.py) with their kernel stats and HBM traffic, the corridor solver's counters and sections.
-TAG=${1:-r02}
+# other configs (bench.py --config 4 / 5 with their per-kernel tables, tools/bench_configs.py) with kernel stats and HBM traffic,
+# the A/B of the two general-rows kernels, the per-wave timeline of the headline kernel.
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -14,12 +15,19 @@ cp $(find $O/prof4096 -name "*kernel_stats.csv" | head -1) $O/bench4096_kernel_s
 for B in 65536 1048576; do
   python $R/bench.py --batch $B --steps 50 --cpu-sample 0 --pipelined-streams 0 > $O/bench_$B.json 2>> $O/bench4096.err
 done
-python $R/bench.py --config 4 --steps 50 --cpu-sample 0 --no-traffic --no-fp64 > $O/bench_config4.json 2>> $O/bench4096.err
+python $R/bench.py --config 4 --steps 50 --cpu-sample 0 > $O/bench_config4.json 2>> $O/bench4096.err
+python $R/bench.py --config 5 --steps 10 --cpu-sample 0 > $O/bench_config5.json 2>> $O/bench4096.err
 python $R/tools/bench_configs.py > $O/other_configs.jsonl 2> $O/other_configs.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_configs -o c -- python $R/tools/bench_configs.py > /dev/null 2>> $O/other_configs.err
 cp $(find $O/prof_configs -name "*kernel_stats.csv" | head -1) $O/other_configs_kernel_stats.csv
 $R/tools/pmc_configs.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_configs.txt $O/pmc_other_configs.txt
 $R/tools/pmc.sh s4k "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" -- --no-traffic --pipelined-streams 0 --graph 0 --steps 50 --repeats 1 > $O/pmc_bench4096.txt 2>&1
 $R/tools/pmc.sh l1m "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU" -- --batch 1048576 --no-traffic --pipelined-streams 0 --graph 0 --steps 10 --repeats 1 > $O/pmc_bench1m.txt 2>&1
-$R/tools/pmc_corridor.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_corridor.txt $O/pmc_corridor.txt
+cd $R
+python tools/rows_ab.py 65536 > $O/rows_ab.jsonl 2>> $O/other_configs.err
+python tools/rows_ab.py 64 small >> $O/rows_ab.jsonl 2>> $O/other_configs.err
+python tools/config1_latency.py > $O/config1_latency.txt 2>> $O/other_configs.err
+if [ -x tools/ubench/tw/h_16 ]; then
+  ( cd tools/ubench/tw; for v in h_16 h_base h_t32; do echo "== $v 4096"; ./$v 4096; done; echo "== h_base 8192"; ./h_base 8192; echo "== h_t32 65536"; ./h_t32 65536 12 ) > $O/headline_timeline.txt 2>&1
+fi
 ls -la $O

@@ -33,7 +33,11 @@
 
 namespace uavqp {
 
-constexpr int rows2_lds_knots(int R, int K) { return (80 * 1024) / (64 * 8 * ((R + K) * (R + K + 1) / 2 + (R + K))); }
+#ifndef UAVQP_ROWS2_LDS_KB
+#define UAVQP_ROWS2_LDS_KB 80   // LDS per single-wave workgroup: 80 KiB = two waves per CU with the whole state of a 16-segment problem on chip
+#endif
+constexpr int rows2_waves_per_cu() { return 160 / UAVQP_ROWS2_LDS_KB; }
+constexpr int rows2_lds_knots(int R, int K) { return (UAVQP_ROWS2_LDS_KB * 1024) / (64 * 8 * ((R + K) * (R + K + 1) / 2 + (R + K))); }
 
 struct Rows2Args {
     RowsArgs r;

@@ -1492,7 +1492,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         const int ws_knots = kown > NT ? kown - NT : 0;
         const long long pairs = 3LL * n_traj;
         long long grid = (pairs + 31) / 32;
-        const long long max_grid = (long long)ctx->num_cus * 2;
+        const long long max_grid = (long long)ctx->num_cus * uavqp::rows2_waves_per_cu();
         if (grid > max_grid) grid = max_grid;
         const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort;
         const size_t b_desc = align256(sizeof(unsigned long long) * (size_t)pairs * (2 + 2 * K));
