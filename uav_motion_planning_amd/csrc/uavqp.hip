@@ -1289,6 +1289,24 @@ extern "C" int uavqp_traj_length_device(uavqp_ctx* ctx, int r, int n_traj, int u
     return UAVQP_OK;
 }
 
+// Dealing order of a ragged batch (longest trajectory first; seg_hist / seg_scan / seg_scatter_kernel): order [n_traj] at `storage`,
+// histogram and cursors in its last 2048 bytes (storage = align256(4 n_traj) + 2048 bytes).  The order depends on the segment counts
+// only: a caller that re-solves the same batch (the config-5 pipeline) makes it once and passes it to corridor_warm_impl.
+static size_t length_order_bytes(int n_traj) { return align256(sizeof(int32_t) * (size_t)n_traj) + 2048; }
+static int make_length_order(uavqp_ctx* ctx, const int32_t* d_seg_offsets, int n_traj, char* storage, const int32_t** d_order_out) {
+    int32_t* d_order = (int32_t*)storage;
+    int* d_hist = (int*)(storage + length_order_bytes(n_traj) - 2048);
+    int* d_cursor = d_hist + 256;
+    UAVQP_HIP(hipMemsetAsync(d_hist, 0, 256 * sizeof(int), ctx->stream));
+    int sg = (n_traj + 255) / 256;
+    if (sg > ctx->num_cus * 4) sg = ctx->num_cus * 4;
+    hipLaunchKernelGGL(uavqp::seg_hist_kernel, dim3(sg), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, d_hist);
+    hipLaunchKernelGGL(uavqp::seg_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_hist, d_cursor);
+    hipLaunchKernelGGL(uavqp::seg_scatter_kernel, dim3(sg), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, d_cursor, d_order);
+    *d_order_out = d_order;
+    return UAVQP_OK;
+}
+
 // total_segments < 0: unknown -- for a ragged batch the last CSR offset is then read back from the device (4 bytes, one stream
 // synchronisation); callers that know it (the host-pointer entries, the rows solver's second phase, the corridor pipeline) pass it
 // and the call stays asynchronous.
@@ -1296,7 +1314,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
                               const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
                               const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
                               double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
-                              uint64_t* d_active_set, int warm_start, long long total_segments) {
+                              uint64_t* d_active_set, int warm_start, long long total_segments, const int32_t* d_order_ready = nullptr) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
     if (n_traj == 0) return UAVQP_OK;
     if (!d_waypoints || !d_times || !d_bc || !d_corr_lo || !d_corr_hi || !d_coeff_out || !d_status_out) return UAVQP_ERR_INVALID_ARG;
@@ -1334,8 +1352,8 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
     const size_t b_queue = 256;
     const size_t b_desc = align256(sizeof(unsigned long long) * 3 * (size_t)n_traj);
-    const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort;
-    const size_t b_order = deal_by_length ? align256(sizeof(int32_t) * (size_t)n_traj) + 2048 : 0;   // order + histogram + cursors
+    const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort && !d_order_ready;
+    const size_t b_order = deal_by_length ? length_order_bytes(n_traj) : 0;   // order + histogram + cursors
     const size_t b_state = sizeof(double) * (size_t)ws_knots * F * (size_t)grid * 64;
     const bool guess = !warm_start && ctx->settings.corridor_initial_guess != 0;     // cold start from the closed-form set of the prep kernel
     const size_t b_guess = guess ? align256(sizeof(unsigned long long) * 6 * (size_t)n_traj) : 0;
@@ -1349,19 +1367,10 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     a.desc = (unsigned long long*)((char*)ctx->ws + b_xsol + b_queue);
     a.ws = ws_knots > 0 ? (double*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order) : nullptr;
     a.ws_knots = ws_knots;
-    a.order = nullptr;
+    a.order = d_order_ready;
     if (deal_by_length) {
-        char* po = (char*)ctx->ws + b_xsol + b_queue + b_desc;
-        int32_t* d_order = (int32_t*)po;
-        int* d_hist = (int*)(po + b_order - 2048);
-        int* d_cursor = d_hist + 256;
-        UAVQP_HIP(hipMemsetAsync(d_hist, 0, 256 * sizeof(int), ctx->stream));
-        int sg = (n_traj + 255) / 256;
-        if (sg > ctx->num_cus * 4) sg = ctx->num_cus * 4;
-        hipLaunchKernelGGL(uavqp::seg_hist_kernel, dim3(sg), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, d_hist);
-        hipLaunchKernelGGL(uavqp::seg_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_hist, d_cursor);
-        hipLaunchKernelGGL(uavqp::seg_scatter_kernel, dim3(sg), dim3(256), 0, ctx->stream, d_seg_offsets, n_traj, d_cursor, d_order);
-        a.order = d_order;
+        rc = make_length_order(ctx, d_seg_offsets, n_traj, (char*)ctx->ws + b_xsol + b_queue + b_desc, &a.order);
+        if (rc != UAVQP_OK) return rc;
     }
 #ifdef UAVQP_CORRIDOR_TIMING
     a.stamps = (long long*)((char*)a.queue + 64);   // debug build: section cycles of wave 0, read back by uavqp_debug_corridor_stamps

@@ -183,10 +183,12 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     const int n_rows = total_segments + n_traj;
     const bool checking = P.check_samples > 0;
 
-    // scratch: [counters 64 B][iters n][changed n][first_hit n][active n x 6 x 8][roomy n][flag n]
+    // scratch: [counters 64 B][iters n][changed n][first_hit n][active n x 6 x 8][roomy n][flag n][dealing order of the corridor solves]
     const size_t o_it = 256, o_ch = o_it + align256(sizeof(int32_t) * (size_t)n), o_fh = o_ch + align256(sizeof(int32_t) * (size_t)n);
     const size_t o_as = o_fh + align256(sizeof(int32_t) * (size_t)n), o_rm = o_as + align256(sizeof(uint64_t) * 6 * (size_t)n);
-    const size_t o_fl = o_rm + align256((size_t)n), need = o_fl + align256((size_t)n);
+    const size_t o_fl = o_rm + align256((size_t)n), o_or = o_fl + align256((size_t)n);
+    const bool deal_by_length = uni == 0 && n >= 64 && ctx->settings.ragged_window_sort;
+    const size_t need = o_or + (deal_by_length ? length_order_bytes(n) : 0);
     int rc = ensure_pipe_ws(ctx, need);
     if (rc != UAVQP_OK) return rc;
     char* base = (char*)ctx->d_pipe;
@@ -206,9 +208,15 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
         UAVQP_HIP(hipStreamSynchronize(s));
         return UAVQP_OK;
     };
+    // every corridor solve of the call deals the same trajectories: their order by segment count is made once
+    const int32_t* d_order = nullptr;
+    if (deal_by_length) {
+        rc = make_length_order(ctx, d_seg_offsets, n, base + o_or, &d_order);
+        if (rc != UAVQP_OK) return rc;
+    }
     auto corridor_solve = [&](int warm) {
         return corridor_warm_impl(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_corr_lo, d_corr_hi, d_coeff_out,
-                                  d_status_out, d_iters, d_active, warm, total_segments);
+                                  d_status_out, d_iters, d_active, warm, total_segments, d_order);
     };
     auto reallocate = [&]() -> int {      // + count of the trajectories it stretched
         int rc_ = uavqp_time_reallocate_device(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
