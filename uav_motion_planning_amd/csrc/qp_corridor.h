@@ -211,7 +211,12 @@ __global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
     }
 }
 
-constexpr int corridor_lds_knots(int R) { return R == 3 ? 8 : 5; }
+#ifndef UAVQP_CORRIDOR_WAVES_PER_CU
+#define UAVQP_CORRIDOR_WAVES_PER_CU 4   // single-wave workgroups per CU = 160 KiB of LDS / the state kept on chip per wave (4: one wave per SIMD)
+#endif
+constexpr int corridor_waves_per_cu() { return UAVQP_CORRIDOR_WAVES_PER_CU; }
+// own knots per lane whose record (F = r (r + 1) / 2 + r + 1 doubles) stays in LDS: 40 KiB per wave -> 8 (r = 3) / 5 (r = 4)
+constexpr int corridor_lds_knots(int R) { return (160 * 1024 / UAVQP_CORRIDOR_WAVES_PER_CU) / (64 * 8 * (R * (R + 1) / 2 + R + 1)); }
 
 // wave-uniform maximum of a small non-negative per-lane integer (< 64): six ballots
 __device__ __forceinline__ int wave_max_small(int v) {

@@ -1332,7 +1332,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     // 32 problems in flight per wave, refilled from the work counter.
     const long long pairs = 3LL * n_traj;
     long long grid = (pairs + 31) / 32;
-    const long long max_grid = (long long)ctx->num_cus * 4;
+    const long long max_grid = (long long)ctx->num_cus * uavqp::corridor_waves_per_cu();
     if (grid > max_grid) grid = max_grid;
     const int NT = uavqp::corridor_lds_knots(r);
     const int F = r * (r + 1) / 2 + r + 1;  // must match corridor_solve_kernel's state layout
