@@ -111,7 +111,10 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *   generic_lanes_per_traj 0 auto, 1 = one lane per trajectory, 2 = a lane pair per trajectory (two-sided elimination),
  *                          3 = one lane per (trajectory, axis)
  *   generic_waves_per_cu   0 auto, > 0: resident waves per CU of the generic kernel
- *   corridor_pdas_rounds   block-pivoting rounds before the single-pivot active-set phase (default 3)
+ *   corridor_pdas_rounds   block-pivoting rounds before the single-pivot active-set phase of a COLD corridor solve (default 3)
+ *   corridor_pdas_rounds_warm  the same for a warm-started one (default 0: measured on config 5's outer loop, block rounds from
+ *                          the carried working set only disturb it -- largest iteration counts 57 / 54 / 37 / 27 with 3 rounds, 41 / 43 /
+ *                          22 / 12 with none and the previous positions as the starting point)
  *   corridor_initial_guess 1 (default): a cold corridor solve starts from the knots whose boxes the end-state polynomial misses
  *                          (closed form) instead of the empty working set; 0: empty set.  Same result.
  *   rows_lanes_per_problem uavqp_solve_rows_batch_*: 0 auto / 2 = a lane pair per (trajectory, axis) problem with the sweep state in LDS
@@ -130,7 +133,7 @@ typedef struct uavqp_settings {
     int32_t corridor_pdas_rounds;
     int32_t corridor_initial_guess;
     int32_t rows_lanes_per_problem;
-    int32_t reserved_;
+    int32_t corridor_pdas_rounds_warm;
     double realloc_dead_band;
     double realloc_overshoot;
 } uavqp_settings;
@@ -196,6 +199,10 @@ int uavqp_solve_corridor_batch_host(uavqp_ctx* ctx, int r, int n_traj, int unifo
  *   warm_start == 0: the buffer is only written (working set at the solution);
  *   warm_start != 0: it is read as the initial working set (any bit pattern is a valid guess: wrong guesses cost
  *                    iterations, never correctness) and overwritten with the final one.
+ *   warm_start == 2: in addition d_coeff_out is READ first: it holds the polynomials of the previous solve of the same batch
+ *                    (same boxes, e.g. other durations), and the feasible starting point of the active-set method takes its free
+ *                    positions from their knot positions (clipped into the boxes -- any content is admissible) instead of the
+ *                    waypoints: a start close to the new minimiser is blocked by few bounds on its way there.
  * A trajectory that ends UAVQP_MAX_ITER_REACHED writes an empty set.  No reference counterpart. */
 int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                      const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,

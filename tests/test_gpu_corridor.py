@@ -179,7 +179,10 @@ def test_warm_started_corridor_solve(gpu_ctx, r, ragged):
     """uavqp_solve_corridor_warm_device: (1) restarting from the working set of the solution takes exactly one
     iteration and reproduces the cold solve bit for bit (same pins, same pinned values, same arithmetic);
     (2) ANY bit pattern is an admissible guess -- random sets still end at the same minimiser (1e-9 relative);
-    (3) after a 10 % time re-allocation the previous working set is a good guess: far fewer iterations than cold."""
+    (3) after a 10 % time re-allocation the previous working set is a good guess: far fewer iterations than cold;
+    (4) warm_start = 2 additionally reads the previous polynomials from coeff_out as the starting point: same minimiser whatever
+    is found there (the previous solution, NaNs, huge numbers), and about as few iterations as (3) from the previous solution (its benefit shows after large changes: config 5's
+    outer loop, tools/corridor_tail_probe.py)."""
     import torch
     dev = torch.device("cuda", 0)
     up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
@@ -197,8 +200,8 @@ def test_warm_started_corridor_solve(gpu_ctx, r, ragged):
     d_wp, d_T, d_bc, d_lo, d_hi = up(b["waypoints"]), up(b["times"]), up(b["bc"]), up(lo), up(hi)
     nco = int(so[-1]) * 6 * r
 
-    def run(active, warm, times=d_T):
-        out = torch.zeros(nco, dtype=torch.float64, device=dev)
+    def run(active, warm, times=d_T, out_init=None):
+        out = torch.zeros(nco, dtype=torch.float64, device=dev) if out_init is None else out_init.clone()
         st = torch.zeros(n, dtype=torch.int32, device=dev)
         it = torch.zeros(n, dtype=torch.int32, device=dev)
         gpu_ctx.solve_corridor_device(r, n, uni, mx, d_so, d_wp, times, d_bc, d_lo, d_hi, out, st, it, active, warm)
@@ -231,6 +234,18 @@ def test_warm_started_corridor_solve(gpu_ctx, r, ragged):
     c2_cold, it2_cold = run(None, False, d_T2)
     assert np.max(np.abs(c2_warm - c2_cold)) <= 1e-9 * np.max(np.abs(c2_cold))
     assert it2_warm.mean() < 0.5 * it2_cold.mean()
+    # (4) the previous polynomials as the starting point
+    prev = torch.from_numpy(c_cold).to(dev)
+    act3 = act.clone()
+    c3, it3 = run(act3, 2, d_T2, out_init=prev)
+    assert np.max(np.abs(c3 - c2_cold)) <= 1e-9 * np.max(np.abs(c2_cold))
+    assert np.array_equal(act3.cpu().numpy(), act2.cpu().numpy())
+    assert it3.mean() <= 1.1 * it2_warm.mean() + 0.1            # (a 10 % stretch barely moves the set: both need 1-3 iterations)
+    for junk_val in (float("nan"), 1e300, -1e300):
+        c4, _ = run(act.clone(), 2, d_T2, out_init=torch.full((nco,), junk_val, dtype=torch.float64, device=dev))
+        assert np.max(np.abs(c4 - c2_cold)) <= 1e-9 * np.max(np.abs(c2_cold))
+    c5, _ = run(None, 0, d_T2, out_init=torch.full((nco,), float("nan"), dtype=torch.float64, device=dev))   # cold: coeff_out is write-only
+    assert np.array_equal(c5, c2_cold)
 
 
 def test_mid_segment_samples_by_knot_insertion(gpu_ctx, oracle):

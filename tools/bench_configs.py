@@ -151,7 +151,7 @@ def main():
     def outer_loop_warm(record=False):
         d["times"].copy_(T0)
         for rnd in range(5):
-            ctx.solve_corridor_device(r, n, 0, 24, d_so, d["waypoints"], d["times"], d["bc"], d_lo, d_hi, out, st, it, act, rnd > 0)
+            ctx.solve_corridor_device(r, n, 0, 24, d_so, d["waypoints"], d["times"], d["bc"], d_lo, d_hi, out, st, it, act, 2 if rnd > 0 else 0)
             if record:
                 it_rounds.append(float(it.float().mean()))
             ctx.time_reallocate_device(r, n, 0, d_so, d["times"], out, 7.0, 10.0, samples_per_seg=16, max_stretch=2.0, changed=ch)

@@ -41,12 +41,19 @@ for cap in (5, 10, 20, 30, 50, 80):
     ms = timeit(cold, s, n=3, warm=1)
     print(json.dumps({"max_iter": cap, "ms": ms, "capped": int((st.cpu().numpy() != 1).sum())}), flush=True)
 ctx.set_settings(max_iter=0)
-d["times"].copy_(T0)
-for rnd in range(5):
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(s)
-    ctx.solve_corridor_device(r, n, 0, 24, d_so, d["waypoints"], d["times"], d["bc"], d_lo, d_hi, out, st, it, act, rnd > 0)
-    ev1.record(s); s.synchronize()
-    hist("round %d (%.3f ms)" % (rnd, ev0.elapsed_time(ev1)))
-    ctx.time_reallocate_device(r, n, 0, d_so, d["times"], out, 7.0, 10.0, samples_per_seg=16, max_stretch=2.0, changed=ch)
-    print(json.dumps({"stretched_in_round": int((ch > 0).sum())}), flush=True)
+for pdas, WARM in ((3, 1), (3, 2), (0, 1), (0, 2), (1, 1), (2, 1), (5, 1), (8, 1)):
+    ctx.set_settings(corridor_pdas_rounds=pdas)
+    d["times"].copy_(T0)
+    rows_ = []
+    tot = 0.0
+    for rnd in range(5):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(s)
+        ctx.solve_corridor_device(r, n, 0, 24, d_so, d["waypoints"], d["times"], d["bc"], d_lo, d_hi, out, st, it, act, (WARM if rnd > 0 else 0))
+        ev1.record(s); s.synchronize()
+        x = it.cpu().numpy(); ms = ev0.elapsed_time(ev1); tot += ms
+        rows_.append((round(ms, 3), round(float(x.mean()), 2), int(x.max())))
+        ctx.time_reallocate_device(r, n, 0, d_so, d["times"], out, 7.0, 10.0, samples_per_seg=16, max_stretch=2.0, changed=ch)
+    print(json.dumps({"pdas_rounds": pdas, "warm_mode": WARM, "total_ms": round(tot, 3), "per_round(ms, mean it, max it)": rows_, "solved": int((st.cpu().numpy() == 1).sum()),
+                      "still_stretching": int((ch > 0).sum())}), flush=True)
+ctx.set_settings(corridor_pdas_rounds=3)

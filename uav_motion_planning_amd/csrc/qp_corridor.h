@@ -51,7 +51,8 @@ struct CorridorArgs {
     unsigned int* queue;           // work counter, zeroed before the launch
     const int32_t* order;          // optional dealing order of the trajectories (null = index order)
     unsigned long long* active;    // [n_traj][3][2] working set in/out (may be null)
-    int warm;                      // read `active` as the initial working set
+    int warm;                      // 1: read `active` as the initial working set; 2: also start the free positions from the knot positions of the
+                                   // polynomials found in `coeff` (the previous solve's output, clipped into the boxes) instead of the waypoints
     unsigned long long* guess;     // [n_traj][3][2] cold start: the closed-form starting set of corridor_prep_kernel (may be null)
 #ifdef UAVQP_CORRIDOR_TIMING
     long long* stamps;             // debug build only (tools/): cycles per section of wave 0 -> [refill, forward, meeting, backward, decide, hand-over, iterations]
@@ -413,6 +414,12 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
         const double* const HI = a.corr_hi + base3;
         const double* const TT = a.times + s0;
         const double* const WP = a.waypoints + base3;
+        // initial positions of a problem's first sweep: the waypoints, or (warm = 2) the start of every segment of the polynomials the
+        // caller left in `coeff` -- c_0 of segment k of this axis = p(knot k); whatever is found there is clipped into the box first
+        const bool zprev = a.warm == 2;
+        const int axis = (int)(base3 - 3LL * ((long long)s0 + b));
+        const double* const ZS = zprev ? a.coeff + ((size_t)3 * s0 + (size_t)axis * M) * (2 * R) : WP;
+        const int zstride = zprev ? 2 * R : 3;
         // slot s <-> original knot kbase + ksign s, original segment of own segment (m - s) = tbase + ksign s
         const int ksign = isR ? 1 : -1, kbase = isR ? M - mm : mm, tbase = isR ? M - 1 - mm : mm;
         auto kslot = [&](int s) -> int { return kbase + ksign * s; };
@@ -481,10 +488,10 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                 Tn = TT[tclamp(tbase + ksign * (sj - 1))];   // own segment j + 1 = m - (sj - 1)
                 if (sj >= 2) ld_xz(sj - 2, rx, rz);
                 {
-                    const int k2 = 3 * kclamp(kslot(sj - 2));
+                    const int kk2 = kclamp(kslot(sj - 2)), k2 = 3 * kk2;
                     rl = LO[k2];
                     rh = HI[k2];
-                    rw = WP[k2];
+                    rw = ZS[(zprev ? max(min(kk2, M - 1), 0) : kk2) * zstride];   // (a lane without a problem has M = 0: stay in bounds)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // (3)

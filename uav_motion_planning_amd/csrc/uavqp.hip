@@ -775,6 +775,7 @@ extern "C" void uavqp_default_settings(uavqp_settings* out) {
     out->generic_lanes_per_traj = 0;
     out->generic_waves_per_cu = 0;
     out->corridor_pdas_rounds = 3;
+    out->corridor_pdas_rounds_warm = 0;
     out->corridor_initial_guess = 1;
     out->rows_lanes_per_problem = 0;
     out->realloc_dead_band = 1.01;
@@ -786,7 +787,7 @@ static int apply_variant(uavqp_ctx* ctx, int variant);
 extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     if (!ctx || !st || st->struct_size != (int32_t)sizeof(uavqp_settings)) return UAVQP_ERR_INVALID_ARG;
     if (!(st->eps_prim_inf >= 0.0) || !(st->realloc_dead_band >= 1.0) || !(st->realloc_overshoot >= 1.0) || !(st->realloc_dead_band < INFINITY) ||
-        !(st->realloc_overshoot < INFINITY) || st->corridor_pdas_rounds < 0 || st->corridor_pdas_rounds > 64 ||
+        !(st->realloc_overshoot < INFINITY) || st->corridor_pdas_rounds < 0 || st->corridor_pdas_rounds > 64 || st->corridor_pdas_rounds_warm < 0 || st->corridor_pdas_rounds_warm > 64 ||
         (st->generic_lanes_per_traj != 0 && st->generic_lanes_per_traj != 1 && st->generic_lanes_per_traj != 2 && st->generic_lanes_per_traj != 3) || st->generic_waves_per_cu < 0 ||
         st->generic_waves_per_cu > 32 || st->rows_lanes_per_problem < 0 || st->rows_lanes_per_problem > 2)
         return UAVQP_ERR_INVALID_ARG;
@@ -1323,9 +1324,9 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     UAVQP_HIP(hipSetDevice(ctx->device));
     const int Mmax = uniform_segments > 0 ? uniform_segments : max_segments;
     uavqp::CorridorArgs a;
-    a.active = (unsigned long long*)d_active_set; a.warm = warm_start ? 1 : 0;
+    a.active = (unsigned long long*)d_active_set; a.warm = warm_start == 2 ? 2 : (warm_start ? 1 : 0);
     a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax; a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 8 * Mmax + 20;
-    a.pdas_rounds = ctx->settings.corridor_pdas_rounds;
+    a.pdas_rounds = warm_start ? ctx->settings.corridor_pdas_rounds_warm : ctx->settings.corridor_pdas_rounds;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.coeff = d_coeff_out; a.status = d_status_out; a.iters = d_iters_out;
     // Persistent single-wave workgroups, one per SIMD (the sweep state of a lane pair lives in LDS: 4 x 40 KiB per CU),

@@ -208,6 +208,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
         UAVQP_HIP(hipStreamSynchronize(s));
         return UAVQP_OK;
     };
+    // (warm = 2: d_coeff_out still holds the previous round's polynomials -- their knot positions are the re-solve's starting point)
     // every corridor solve of the call deals the same trajectories: their order by segment count is made once
     const int32_t* d_order = nullptr;
     if (deal_by_length) {
@@ -236,7 +237,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     // 3. outer loop
     int rounds = 0, still = 0;
     for (int rnd = 0; rnd < P.max_rounds; ++rnd) {
-        rc = corridor_solve(rnd > 0);
+        rc = corridor_solve(rnd > 0 ? 2 : 0);
         if (rc != UAVQP_OK) return rc;
         ++rounds;
         rc = reallocate();
@@ -246,7 +247,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     }
     if (still != 0) {
         // cap reached with durations changed by the last re-allocation: one more solve so that the coefficients match d_times
-        rc = corridor_solve(1);
+        rc = corridor_solve(2);
         if (rc != UAVQP_OK) return rc;
     }
     // 4. check + repair
@@ -288,13 +289,13 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
             const double shrink = (repairs + 1 == P.repair_rounds) ? 0.0 : 0.5;
             hipLaunchKernelGGL(uavqp::pipe_shrink_kernel, dim3(n < ctx->num_cus * 32 ? n : ctx->num_cus * 32), dim3(64), 0, s, n, uni, d_seg_offsets,
                                d_waypoints, d_corr_lo, d_corr_hi, (const uint8_t*)d_flag, shrink);
-            rc = corridor_solve(1);
+            rc = corridor_solve(2);
             if (rc != UAVQP_OK) break;
             rc = reallocate();
             if (rc != UAVQP_OK) break;
             still = (int)h_cnt->changed;
             if (still > 0) {
-                rc = corridor_solve(1);
+                rc = corridor_solve(2);
                 if (rc != UAVQP_OK) break;
             }
             ++repairs;

@@ -115,12 +115,13 @@ class Context:
     def solve_corridor_device(self, r, n_traj, uniform_segments, max_segments, seg_offsets, waypoints, times, bc, corr_lo, corr_hi,
                               coeff_out, status_out, iters_out=None, active_set=None, warm_start=False):
         """Corridor-constrained solve on device buffers; active_set ([n_traj,3,2] int64/uint64 device tensor) carries the
-        working set between the re-solves of an outer loop (warm_start=True reads it)."""
+        working set between the re-solves of an outer loop (warm_start=True reads it; warm_start=2 also starts the free positions from
+        the polynomials found in coeff_out -- include/uavqp.h)."""
         def p(x):
             return x if isinstance(x, int) or x is None else _ptr(x)
         rc = _lib.lib().uavqp_solve_corridor_warm_device(self._h, r, n_traj, uniform_segments, max_segments, p(seg_offsets), p(waypoints),
                                                          p(times), p(bc), p(corr_lo), p(corr_hi), p(coeff_out), p(status_out),
-                                                         p(iters_out), p(active_set), 1 if warm_start else 0)
+                                                         p(iters_out), p(active_set), int(warm_start))
         _lib.check(rc, "uavqp_solve_corridor_warm_device")
 
     def solve_rows_device(self, r, n_traj, uniform_segments, max_segments, seg_offsets, waypoints, times, bc, corr_lo, corr_hi,
