@@ -268,31 +268,26 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             const int jn = jc + 1 <= mm ? jc + 1 : jc;
             f.nl = klo(jn); f.nh = khi(jn);
         };
-        auto block = [&](int j, bool full, const FIn& in, double (&D)[B][B], double (&rhs)[B], bool (&fx)[B], double (&vx)[B]) {
+        // Known components need no case analysis (the steps stay single basic blocks):
+        //   * an INACTIVE row has its functionals zeroed and a unit diagonal: its mu row / column is decoupled and solves to 0;
+        //   * a PINNED position (interior knots only; the meeting knot's is applied to the combined block) moves D[.][0] z to the right-hand
+        //     side, becomes the identity row, and is masked out of the coupling to the previous block -- all by selects on pk.
+        auto block = [&](int j, bool full, const FIn& in, double (&D)[B][B], double (&rhs)[B], bool (&racv)[K]) {
             const double Tj = in.T;
-            double gl[K][R], gr[K][R], rb[K], rlv[K], rhv[K];
-            bool racv[K];
-#pragma unroll
-            for (int jj = 0; jj < K; ++jj) {
-#pragma unroll
-                for (int c = 0; c < R; ++c) { gl[jj][c] = in.gl[jj][c]; gr[jj][c] = in.gr[jj][c]; }
-                rlv[jj] = in.rl[jj];
-                rhv[jj] = in.rh[jj];
-            }
-            const double bl = in.bl, bh = in.bh;
-            const double nl = in.nl, nh = in.nh;
+            double gl[K][R], gr[K][R], rb[K];
             FullBlocks<R> sb;
             if (full) sb.build(Tj);
 #pragma unroll
             for (int jj = 0; jj < K; ++jj) {
                 racv[jj] = sbit(ract[jj], j - 1);
-                rb[jj] = racv[jj] ? (sbit(rup[jj], j - 1) ? rhv[jj] : rlv[jj]) : 0.0;
+                rb[jj] = racv[jj] ? (sbit(rup[jj], j - 1) ? in.rh[jj] : in.rl[jj]) : 0.0;
 #pragma unroll
-                for (int c = 0; c < R; ++c) { gl[jj][c] = racv[jj] ? gl[jj][c] : 0.0; gr[jj][c] = racv[jj] ? gr[jj][c] : 0.0; }
+                for (int c = 0; c < R; ++c) { gl[jj][c] = racv[jj] ? in.gl[jj][c] : 0.0; gr[jj][c] = racv[jj] ? in.gr[jj][c] : 0.0; }
             }
             const bool interior = korig(j) >= 1 && korig(j) <= M - 1;
-            const bool pk = interior && kbit(pin, j);
-            const double zc = pk ? (kbit(upper, j) ? bh : bl) : 0.0;
+            const bool pk = full & interior & kbit(pin, j);
+            const double zc = pk ? (kbit(upper, j) ? in.bh : in.bl) : 0.0;
+            const double zpm = pprev ? zprev : 0.0;
 #pragma unroll
             for (int i = 0; i < B; ++i) {
                 rhs[i] = 0.0;
@@ -300,38 +295,33 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 for (int c = 0; c < B; ++c) D[i][c] = 0.0;
             }
 #pragma unroll
-            for (int i = 0; i < R; ++i)
+            for (int i = 0; i < R; ++i) {
 #pragma unroll
                 for (int c = 0; c < R; ++c) D[i][c] = sa.B11[i][c] + (full ? sb.B00(i, c) : 0.0);
+                rhs[i] -= sa.B01[0][i] * zpm;
+            }
 #pragma unroll
             for (int jj = 0; jj < K; ++jj) {
 #pragma unroll
                 for (int c = 0; c < R; ++c) D[R + jj][c] = gr[jj][c];
-                rhs[R + jj] = rb[jj];
-            }
-            if (pprev) {
-#pragma unroll
-                for (int i = 0; i < R; ++i) rhs[i] -= sa.B01[0][i] * zprev;
-#pragma unroll
-                for (int jj = 0; jj < K; ++jj) rhs[R + jj] -= gl[jj][0] * zprev;
+                D[R + jj][R + jj] = racv[jj] ? 0.0 : 1.0;
+                rhs[R + jj] = rb[jj] - gl[jj][0] * zpm;
             }
             if (full) {
                 const bool pnext = kbit(pin, j + 1);   // own knot j + 1 <= m: an interior knot (the meeting knot at the latest)
-                const double zn = pnext ? (kbit(upper, j + 1) ? nh : nl) : 0.0;
+                const double zn = pnext ? (kbit(upper, j + 1) ? in.nh : in.nl) : 0.0;
 #pragma unroll
                 for (int i = 0; i < R; ++i) rhs[i] -= sb.B01[i][0] * zn;
             }
 #pragma unroll
-            for (int i = 0; i < B; ++i) { fx[i] = false; vx[i] = 0.0; }
-            if (full && pk) { fx[0] = true; vx[0] = zc; }   // (the meeting knot's pin is applied to the COMBINED block)
-#pragma unroll
-            for (int jj = 0; jj < K; ++jj) fx[R + jj] = !racv[jj];
-#pragma unroll
-            for (int i = 0; i < B; ++i)
-#pragma unroll
-                for (int c = 0; c < B; ++c)
-                    if (fx[c] && !fx[i]) rhs[i] -= (i >= c ? D[i][c] : D[c][i]) * vx[c];
-            // coupling to the previous block (rows = x_{j-1}), masked
+            for (int i = 1; i < B; ++i) {
+                rhs[i] -= D[i][0] * zc;
+                D[i][0] = pk ? 0.0 : D[i][0];
+            }
+            D[0][0] = pk ? 1.0 : D[0][0];
+            // coupling to the previous block (rows = x_{j-1}); (pk: a pinned position is a known value -- its coupling went to the previous
+            // block's right-hand side; at the meeting knot too, where pk comes from the caller through the combined block)
+            const bool pkm = interior & kbit(pin, j);
             double Mp[R][B];
 #pragma unroll
             for (int c = 0; c < R; ++c) {
@@ -341,11 +331,9 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 for (int jj = 0; jj < K; ++jj) Mp[c][R + jj] = gl[jj][c];
             }
 #pragma unroll
-            for (int c = 0; c < R; ++c)
+            for (int i = 0; i < B; ++i) Mp[0][i] = pprev ? 0.0 : Mp[0][i];
 #pragma unroll
-                for (int i = 0; i < B; ++i)
-                    if ((pprev && c == 0) || fx[i] || (pk && i == 0)) Mp[c][i] = 0.0;   // (pk && i == 0 also at the meeting knot: a pinned
-                                                                                           //  position is a known value, its coupling went to the previous block's rhs)
+            for (int c = 0; c < R; ++c) Mp[c][0] = pkm ? 0.0 : Mp[c][0];
             double Ep[B][B];
 #pragma unroll
             for (int i = 0; i < B; ++i) {
@@ -364,28 +352,18 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     for (int c = 0; c <= i; ++c) D[i][c] -= Mp[q][i] * Ep[q][c];
                     rhs[i] -= Mp[q][i] * hprev[q];
                 }
+            rhs[0] = pk ? zc : rhs[0];
             if (full) { sa = sb; pprev = pk; zprev = zc; }
         };
         if (mm >= 1 && !single) sa.build(Tseg(0));
         FIn fnx;
         if (mm >= 1 && !single) load_fin(1, fnx);
         for (int j = 1; j < mm; ++j) {
-            double D[B][B], rhs[B], vx[B];
-            bool fx[B];
+            double D[B][B], rhs[B];
+            bool racv[K];
             const FIn fcur = fnx;
             load_fin(j + 1, fnx);          // (j + 1 <= mm: the last one is the meeting block's)
-            block(j, true, fcur, D, rhs, fx, vx);
-#pragma unroll
-            for (int i = 0; i < B; ++i)
-                if (fx[i]) {
-#pragma unroll
-                    for (int c = 0; c < B; ++c) {
-                        if (c <= i) D[i][c] = 0.0;
-                        if (c >= i) D[c][i] = 0.0;
-                    }
-                    D[i][i] = 1.0;
-                    rhs[i] = vx[i];
-                }
+            block(j, true, fcur, D, rhs, racv);
             SmallLDL<B> ldl;
             ldl.factor(D);
             ldl.solve(rhs);
@@ -408,19 +386,17 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         double ym[B];             // solution of the own meeting block [x_c (own frame) ; mu_own]
 #pragma unroll
         for (int i = 0; i < B; ++i) ym[i] = 0.0;
-        bool fxm[B];              // fixed components of the own meeting block (mu part: inactive rows)
-#pragma unroll
-        for (int i = 0; i < B; ++i) fxm[i] = false;
         {
-            double D[B][B], rhs[B], vx[B];
+            double D[B][B], rhs[B];
+            bool racm[K];
 #pragma unroll
             for (int i = 0; i < B; ++i) {
-                rhs[i] = 0.0; vx[i] = 0.0;
+                rhs[i] = 0.0;
 #pragma unroll
                 for (int c = 0; c < B; ++c) D[i][c] = 0.0;
             }
             const bool has = act && !single && mm >= 1;
-            if (has) block(mm, false, fnx, D, rhs, fxm, vx);
+            if (has) block(mm, false, fnx, D, rhs, racm);
             // exchange lower triangles and right-hand sides; conj = F . F on the x part of the partner's (reversed-frame) block
             double C[BM][BM], r7[BM];
 #pragma unroll
@@ -429,9 +405,6 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
 #pragma unroll
                 for (int c = 0; c < BM; ++c) C[i][c] = 0.0;
             }
-            bool ofx[B];
-#pragma unroll
-            for (int i = 0; i < B; ++i) ofx[i] = swap_pair_i(fxm[i] ? 1 : 0) != 0;
             auto sgn = [](int c) -> double { return (c & 1) ? -1.0 : 1.0; };
 #pragma unroll
             for (int i = 0; i < B; ++i) {
@@ -453,35 +426,16 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 if (i < R) r7[i] = vL + vR;
                 else { r7[i] = vL; r7[K + i] = vR; }
             }
-            // fixed components of the combined block: the pinned meeting position, inactive rows of either side
-            bool f7[BM];
-            double v7[BM];
-#pragma unroll
-            for (int i = 0; i < BM; ++i) { f7[i] = false; v7[i] = 0.0; }
+            // the pinned meeting position (inactive rows of either side are decoupled unit rows already, see block())
             const bool pc = has && mm >= 1 && kbit(pin, mm) && korig(mm) >= 1 && korig(mm) <= M - 1;
             const double zc = pc ? (kbit(upper, mm) ? khi(mm) : klo(mm)) : 0.0;
-            if (pc) { f7[0] = true; v7[0] = zc; }
 #pragma unroll
-            for (int jj = 0; jj < K; ++jj) {
-                f7[R + jj] = isR ? ofx[R + jj] : fxm[R + jj];
-                f7[R + K + jj] = isR ? fxm[R + jj] : ofx[R + jj];
+            for (int i = 1; i < BM; ++i) {
+                r7[i] -= C[i][0] * zc;
+                C[i][0] = pc ? 0.0 : C[i][0];
             }
-#pragma unroll
-            for (int i = 0; i < BM; ++i)
-#pragma unroll
-                for (int c = 0; c < BM; ++c)
-                    if (f7[c] && !f7[i]) r7[i] -= (i >= c ? C[i][c] : C[c][i]) * v7[c];
-#pragma unroll
-            for (int i = 0; i < BM; ++i)
-                if (f7[i]) {
-#pragma unroll
-                    for (int c = 0; c < BM; ++c) {
-                        if (c <= i) C[i][c] = 0.0;
-                        if (c >= i) C[c][i] = 0.0;
-                    }
-                    C[i][i] = 1.0;
-                    r7[i] = v7[i];
-                }
+            C[0][0] = pc ? 1.0 : C[0][0];
+            r7[0] = pc ? zc : r7[0];
             SmallLDL<BM> ldl;
             ldl.factor(C);
             ldl.solve(r7);
