@@ -311,3 +311,56 @@ def test_corridor_pipeline_helper_one_call(oracle):
                 end = sum(np.prod(np.arange(p - d + 1, p + 1)) * c[:, j - 1, p] * t ** (p - d) for p in range(d, 8))
                 start = np.prod(np.arange(1, d + 1)) * c[:, j, d]
                 assert np.allclose(end, start, rtol=0, atol=1e-7 * max(1.0, np.abs(c).max()))
+
+
+def test_pipeline_entry_rejects_bad_arguments_and_handles_empty_and_uniform_batches(gpu_ctx):
+    """uavqp_corridor_pipeline_device through its raw C signature: invalid arguments are refused before anything is launched (the
+    output buffers stay untouched), an empty batch is a no-op, a UNIFORM batch (seg_offsets = NULL) runs the same sequence, and a second
+    call on the same inputs reproduces the first bit for bit (the loop control comes from device counters, nothing is left over in the
+    ctx between calls)."""
+    import ctypes
+    import torch
+    from uav_motion_planning_amd import _lib
+    lib = U.lib()
+    dev = torch.device("cuda", 0)
+    r, n, M = 4, 96, 9
+    b = W.uniform_batch(5, n, M, r, time_mode="distance")
+    obs = W.pillar_cloud(5, n_pillars=40, resolution=0.3)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_wp, d_bc, d_obs = up(b["waypoints"].reshape(-1, 3)), up(b["bc"]), up(obs)
+    rows, tot = n * (M + 1), n * M
+    pp = _lib.PipelineParams()
+    lib.uavqp_default_pipeline_params(ctypes.byref(pp))
+
+    def call(pp_, n_=n, uni=M, total=tot, times=None, wp=d_wp, mx=M):
+        T = up(b["times"]) if times is None else times
+        coef = torch.full((tot * 6 * r,), -7.0, dtype=torch.float64, device=dev)
+        st = torch.full((n,), -99, dtype=torch.int32, device=dev)
+        lo = torch.zeros((rows, 3), dtype=torch.float64, device=dev); hi = torch.zeros((rows, 3), dtype=torch.float64, device=dev)
+        fh = torch.zeros(n, dtype=torch.int32, device=dev)
+        res = _lib.PipelineResult()
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        rc = lib.uavqp_corridor_pipeline_device(gpu_ctx._h, r, n_, uni, mx, total, None, p(wp), p(T), p(d_bc), p(d_obs), obs.shape[0], None,
+                                                ctypes.byref(pp_), p(coef), p(st), p(lo), p(hi), p(fh), ctypes.byref(res))
+        gpu_ctx.synchronize()
+        return rc, coef, st, T, fh, res
+
+    bad = []
+    for field, val in (("robot_r", 0.0), ("robot_h", -1.0), ("v_max", 0.0), ("a_max", float("nan")), ("max_rounds", 0), ("max_stretch", 1.0),
+                       ("check_samples", 1), ("repair_rounds", -1), ("struct_size", 8)):
+        q = _lib.PipelineParams()
+        lib.uavqp_default_pipeline_params(ctypes.byref(q))
+        setattr(q, field, val)
+        bad.append(call(q))
+    bad.append(call(pp, total=tot - 1))            # total_segments must be n * uniform_segments
+    bad.append(call(pp, wp=None))                  # null buffer
+    bad.append(call(pp, uni=0, mx=M))              # ragged layout without offsets
+    for rc, coef, st, *_ in bad:
+        assert rc == -1 and bool((coef == -7.0).all()) and bool((st == -99).all())
+    rc, coef, st, *_ = call(pp, n_=0, total=0)
+    assert rc == 0 and bool((coef == -7.0).all())
+    rc1, c1, s1, T1, f1, res1 = call(pp)
+    rc2, c2, s2, T2, f2, res2 = call(pp)
+    assert rc1 == 0 and rc2 == 0 and bool((s1 == U.UAVQP_SOLVED).all()) and res1.unsolved == 0 and 1 <= res1.rounds <= pp.max_rounds
+    assert torch.equal(c1, c2) and torch.equal(T1, T2) and torch.equal(f1, f2) and res1.rounds == res2.rounds and res1.repairs == res2.repairs
+    assert bool((T1 >= up(b["times"]) * (1 - 1e-15)).all()) and not bool((c1 == -7.0).any())
