@@ -119,6 +119,9 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *                          (closed form) instead of the empty working set; 0: empty set.  Same result.
  *   rows_lanes_per_problem uavqp_solve_rows_batch_*: 0 auto / 2 = a lane pair per (trajectory, axis) problem with the sweep state in LDS
  *                          (default), 1 = one lane per problem, state in an HBM workspace (the round-2 kernel, kept for A/B).  Same result.
+ *   cloud_window           1 (default): uavqp_corridor_from_cloud_device sorts rows and points along the cloud's longest axis and scans,
+ *                          per block of neighbouring rows, only the points that can still change a box (large clouds, no clearance
+ *                          output); 0: always the exhaustive scan.  Identical boxes.
  *   realloc_dead_band      uavqp_time_reallocate_device stretches only when the limit ratio exceeds this (default 1.01)
  *   realloc_overshoot      ... and then by overshoot * ratio (default 1.02) */
 typedef struct uavqp_settings {
@@ -134,6 +137,8 @@ typedef struct uavqp_settings {
     int32_t corridor_initial_guess;
     int32_t rows_lanes_per_problem;
     int32_t corridor_pdas_rounds_warm;
+    int32_t cloud_window;
+    int32_t reserved_;
     double realloc_dead_band;
     double realloc_overshoot;
 } uavqp_settings;

@@ -364,3 +364,38 @@ def test_pipeline_entry_rejects_bad_arguments_and_handles_empty_and_uniform_batc
     assert rc1 == 0 and rc2 == 0 and bool((s1 == U.UAVQP_SOLVED).all()) and res1.unsolved == 0 and 1 <= res1.rounds <= pp.max_rounds
     assert torch.equal(c1, c2) and torch.equal(T1, T2) and torch.equal(f1, f2) and res1.rounds == res2.rounds and res1.repairs == res2.repairs
     assert bool((T1 >= up(b["times"]) * (1 - 1e-15)).all()) and not bool((c1 == -7.0).any())
+
+
+@pytest.mark.parametrize("axis_perm,scale", [((0, 1, 2), 1.0), ((1, 0, 2), 1.0), ((2, 1, 0), 1.0), ((0, 1, 2), 0.2)])
+def test_windowed_cloud_scan_gives_the_boxes_of_the_exhaustive_scan_bit_for_bit(gpu_ctx, axis_perm, scale):
+    """uavqp_settings.cloud_window: rows and points sorted along the cloud's longest axis, every block of neighbouring rows scans only the
+    points within reach = max(r, h) (1 + 3 h_max / min(r, h)) of its interval.  A point farther away cannot change a box, so the
+    result must equal the exhaustive scan's BITWISE -- whichever axis is the longest (coordinates permuted), for a map smaller than the
+    reach (scale 0.2: every window is the whole cloud), with rows far outside the cloud, a NaN point and duplicated points."""
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    r, n, h_max = 4, 700, 0.8
+    b = W.ragged_batch(5, n, r, m_lo=4, m_hi=16)
+    so = b["seg_offsets"]
+    wp = np.asarray(b["waypoints"]).reshape(-1, 3).copy() * scale
+    wp[:40] += 500.0                                   # a few rows far away from everything
+    obs = W.pillar_cloud(5, n_pillars=60, resolution=0.2) * scale
+    obs = np.concatenate([obs, obs[:100], [[np.nan, 1.0, 1.0]], [[3.0, np.inf, 0.5]]])
+    wp, obs = wp[:, axis_perm], obs[:, axis_perm]
+    rows = wp.shape[0]
+    assert obs.shape[0] >= 4096 and rows >= 4096
+    coef, st = gpu_ctx.solve_batch_host(r, so, wp, b["times"], b["bc"])
+    d_so, d_wp, d_T, d_coef, d_obs = up(so.astype(np.int32)), up(wp), up(np.asarray(b["times"]).reshape(-1)), up(coef), up(obs)
+    res = {}
+    for mode in (0, 1):
+        gpu_ctx.set_settings(cloud_window=mode)
+        lo = torch.full((rows, 3), np.nan, dtype=torch.float64, device=dev); hi = torch.full((rows, 3), np.nan, dtype=torch.float64, device=dev)
+        gpu_ctx.corridor_from_cloud_device(r, n, 0, d_so, rows, d_wp, d_T, d_coef, d_obs, obs.shape[0], ROBOT_R, ROBOT_H, h_max, lo, hi, None)
+        gpu_ctx.synchronize()
+        res[mode] = (lo.cpu().numpy(), hi.cpu().numpy())
+    gpu_ctx.set_settings(cloud_window=1)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    width = res[1][1] - res[1][0]
+    assert not np.isnan(width).any() and (width > 0).any() and (width.max(axis=1) == 0).any()     # a real mix, every row written
+    assert np.allclose(width[1:so[1]], 2 * h_max)                                                 # the far-away rows: nothing in reach

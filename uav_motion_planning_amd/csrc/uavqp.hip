@@ -776,6 +776,8 @@ extern "C" void uavqp_default_settings(uavqp_settings* out) {
     out->generic_waves_per_cu = 0;
     out->corridor_pdas_rounds = 3;
     out->corridor_pdas_rounds_warm = 0;
+    out->cloud_window = 1;
+    out->reserved_ = 0;
     out->corridor_initial_guess = 1;
     out->rows_lanes_per_problem = 0;
     out->realloc_dead_band = 1.01;
@@ -797,6 +799,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     ctx->settings.warm_start = st->warm_start ? 1 : 0;
     ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
     ctx->settings.corridor_initial_guess = st->corridor_initial_guess ? 1 : 0;
+    ctx->settings.cloud_window = st->cloud_window ? 1 : 0;
     return UAVQP_OK;
 }
 
@@ -1963,7 +1966,39 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
     a.robot_r = robot_r; a.robot_h = robot_h; a.h_max = h_max; a.lo = d_corr_lo; a.hi = d_corr_hi; a.clearance = d_clearance;
     long long grid = ((long long)n_rows + 255) / 256;
     if (grid > (long long)ctx->num_cus * 16) grid = (long long)ctx->num_cus * 16;
-    if (r == 3)
+    a.sort = nullptr; a.row_perm = nullptr; a.row_start = nullptr; a.pt_start = nullptr; a.pts_sorted = nullptr; a.reach = 0.0;
+    // Large clouds, boxes only: rows and points sorted along the cloud's longest axis, every block scans the points within `reach`
+    // of its rows (obstacle_grid.h, cloud_window_kernel) -- identical boxes, fewer pairs.  The clearance output needs the exhaustive min.
+    const bool windowed = !d_clearance && n_obs >= 4096 && n_rows >= 4096 && ctx->settings.cloud_window != 0;
+    if (windowed) {
+        const double rmax = robot_r > robot_h ? robot_r : robot_h, rmin = robot_r > robot_h ? robot_h : robot_r;
+        a.reach = rmax * (1.0 + 3.0 * h_max / rmin) * (1.0 + 1e-9) + 1e-9;
+        const size_t b_cs = 256, b_ph = align256(sizeof(int32_t) * (uavqp::CLOUD_PT_BINS + 1)), b_rh = align256(sizeof(int32_t) * (uavqp::CLOUD_ROW_BINS + 1));
+        const size_t b_pts = align256(sizeof(double) * 3 * (size_t)n_obs), b_perm = align256(sizeof(int32_t) * (size_t)n_rows);
+        const int rc = ensure_ws(ctx, b_cs + 2 * b_ph + 2 * b_rh + b_pts + b_perm);
+        if (rc != UAVQP_OK) return rc;
+        char* p = (char*)ctx->ws;
+        uavqp::CloudSort* d_cs = (uavqp::CloudSort*)p; p += b_cs;
+        int32_t* d_pstart = (int32_t*)p; p += b_ph;
+        int32_t* d_pcur = (int32_t*)p; p += b_ph;
+        int32_t* d_rstart = (int32_t*)p; p += b_rh;
+        int32_t* d_rcur = (int32_t*)p; p += b_rh;
+        double* d_pts = (double*)p; p += b_pts;
+        int32_t* d_perm = (int32_t*)p;
+        long long sgrid = ((long long)n_obs + n_rows + 511) / 512;   // every block: one contiguous slice of the keys, bins counted in LDS
+        if (sgrid > (long long)ctx->num_cus * 2) sgrid = (long long)ctx->num_cus * 2;
+        hipLaunchKernelGGL(uavqp::cloud_sort_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_obstacles, n_obs, a.reach, d_cs, d_pstart, d_rstart);
+        hipLaunchKernelGGL(uavqp::cloud_sort_hist_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, d_waypoints, n_rows,
+                           (const uavqp::CloudSort*)d_cs, d_pstart, d_rstart);
+        hipLaunchKernelGGL(uavqp::cloud_sort_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_pstart, d_pcur, d_rstart, d_rcur);
+        hipLaunchKernelGGL(uavqp::cloud_sort_scatter_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, d_waypoints, n_rows,
+                           (const uavqp::CloudSort*)d_cs, d_pcur, d_rcur, d_pts, d_perm);
+        a.sort = d_cs; a.row_perm = d_perm; a.row_start = d_rstart; a.pt_start = d_pstart; a.pts_sorted = d_pts;
+        if (r == 3)
+            hipLaunchKernelGGL(uavqp::cloud_window_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(uavqp::cloud_window_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+    } else if (r == 3)
         hipLaunchKernelGGL(uavqp::cloud_corridor_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL(uavqp::cloud_corridor_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
