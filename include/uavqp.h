@@ -119,6 +119,8 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *                          (closed form) instead of the empty working set; 0: empty set.  Same result.
  *   rows_lanes_per_problem uavqp_solve_rows_batch_*: 0 auto / 2 = a lane pair per (trajectory, axis) problem with the sweep state in LDS
  *                          (default), 1 = one lane per problem, state in an HBM workspace (the round-2 kernel, kept for A/B).  Same result.
+ *   corridor_tail_shape    1 (default): small batches of long r = 4 corridor problems run two waves per CU with twice the sweep state on
+ *                          chip (shorter iterations: such a solve is as slow as its slowest problem); 0: always four waves per CU.  Same result.
  *   cloud_window           1 (default): uavqp_corridor_from_cloud_device sorts rows and points along the cloud's longest axis and scans,
  *                          per block of neighbouring rows, only the points that can still change a box (large clouds, no clearance
  *                          output); 0: always the exhaustive scan.  Identical boxes.
@@ -138,7 +140,7 @@ typedef struct uavqp_settings {
     int32_t rows_lanes_per_problem;
     int32_t corridor_pdas_rounds_warm;
     int32_t cloud_window;
-    int32_t reserved_;
+    int32_t corridor_tail_shape;
     double realloc_dead_band;
     double realloc_overshoot;
 } uavqp_settings;

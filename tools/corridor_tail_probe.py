@@ -41,8 +41,8 @@ for cap in (5, 10, 20, 30, 50, 80):
     ms = timeit(cold, s, n=3, warm=1)
     print(json.dumps({"max_iter": cap, "ms": ms, "capped": int((st.cpu().numpy() != 1).sum())}), flush=True)
 ctx.set_settings(max_iter=0)
-for pdas, WARM in ((3, 1), (3, 2), (0, 1), (0, 2), (1, 1), (2, 1), (5, 1), (8, 1)):
-    ctx.set_settings(corridor_pdas_rounds=pdas)
+for shape, pdas, WARM in ((0, 0, 2), (1, 0, 2), (0, 0, 2), (1, 0, 2)):
+    ctx.set_settings(corridor_pdas_rounds_warm=pdas, corridor_tail_shape=shape)
     d["times"].copy_(T0)
     rows_ = []
     tot = 0.0
@@ -54,6 +54,6 @@ for pdas, WARM in ((3, 1), (3, 2), (0, 1), (0, 2), (1, 1), (2, 1), (5, 1), (8, 1
         x = it.cpu().numpy(); ms = ev0.elapsed_time(ev1); tot += ms
         rows_.append((round(ms, 3), round(float(x.mean()), 2), int(x.max())))
         ctx.time_reallocate_device(r, n, 0, d_so, d["times"], out, 7.0, 10.0, samples_per_seg=16, max_stretch=2.0, changed=ch)
-    print(json.dumps({"pdas_rounds": pdas, "warm_mode": WARM, "total_ms": round(tot, 3), "per_round(ms, mean it, max it)": rows_, "solved": int((st.cpu().numpy() == 1).sum()),
+    print(json.dumps({"tail_shape": shape, "pdas_rounds_warm": pdas, "warm_mode": WARM, "total_ms": round(tot, 3), "per_round(ms, mean it, max it)": rows_, "solved": int((st.cpu().numpy() == 1).sum()),
                       "still_stretching": int((ch > 0).sum())}), flush=True)
-ctx.set_settings(corridor_pdas_rounds=3)
+ctx.set_settings(corridor_pdas_rounds_warm=0, corridor_tail_shape=1)

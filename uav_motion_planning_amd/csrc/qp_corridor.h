@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
 #define UAVQP_CORRIDOR_WAVES_PER_CU 4   // single-wave workgroups per CU = 160 KiB of LDS / the state kept on chip per wave (4: one wave per SIMD)
 #endif
 constexpr int corridor_waves_per_cu() { return UAVQP_CORRIDOR_WAVES_PER_CU; }
-// own knots per lane whose record (F = r (r + 1) / 2 + r + 1 doubles) stays in LDS: 40 KiB per wave -> 8 (r = 3) / 5 (r = 4)
-constexpr int corridor_lds_knots(int R) { return (160 * 1024 / UAVQP_CORRIDOR_WAVES_PER_CU) / (64 * 8 * (R * (R + 1) / 2 + R + 1)); }
+// own knots per lane whose record (F = r (r + 1) / 2 + r + 1 doubles) stays in LDS: 40 KiB per wave -> 8 (r = 3) / 5 (r = 4).
+// WPC = waves per CU the kernel is built for; the host picks 2 (twice the knots on chip, half the waves) for small batches of long
+// r = 4 problems, whose solve time is the slowest problem's iteration count times the duration of ONE iteration.
+constexpr int corridor_lds_knots(int R, int WPC = UAVQP_CORRIDOR_WAVES_PER_CU) { return (160 * 1024 / WPC) / (64 * 8 * (R * (R + 1) / 2 + R + 1)); }
 
 // wave-uniform maximum of a small non-negative per-lane integer (< 64): six ballots
 __device__ __forceinline__ int wave_max_small(int v) {
@@ -250,10 +252,10 @@ __device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a
 // the backward sweep ends early; slot numbers (and with them the LDS-or-workspace test, slot < NT) are wave-uniform.
 // WS: some halves are longer than NT knots, their far slots live in the HBM workspace (one uniform branch per record access);
 // WS = false compiles every such test away (config 3: the whole state is in LDS).
-template <int R, bool WS>
+template <int R, bool WS, int WPC = UAVQP_CORRIDOR_WAVES_PER_CU>
 __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
     constexpr int ND = R - 1;
-    constexpr int NT = corridor_lds_knots(R);
+    constexpr int NT = corridor_lds_knots(R, WPC);
     // sweep state per own knot: LDL' factors of S_j (strict lower triangle + inverse pivots: R (R + 1) / 2 numbers), x_j (first
     // h_j, overwritten by the solution in the backward sweep) and the current position iterate z_j.  E_j = S_j^-1 M_j is NOT
     // stored: it is re-derived where needed.  (Explicit inverses -- cofactors / 2 x 2 blocks instead of the factorisation, one

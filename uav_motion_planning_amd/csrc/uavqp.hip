@@ -777,7 +777,7 @@ extern "C" void uavqp_default_settings(uavqp_settings* out) {
     out->corridor_pdas_rounds = 3;
     out->corridor_pdas_rounds_warm = 0;
     out->cloud_window = 1;
-    out->reserved_ = 0;
+    out->corridor_tail_shape = 1;
     out->corridor_initial_guess = 1;
     out->rows_lanes_per_problem = 0;
     out->realloc_dead_band = 1.01;
@@ -800,6 +800,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
     ctx->settings.corridor_initial_guess = st->corridor_initial_guess ? 1 : 0;
     ctx->settings.cloud_window = st->cloud_window ? 1 : 0;
+    ctx->settings.corridor_tail_shape = st->corridor_tail_shape ? 1 : 0;
     return UAVQP_OK;
 }
 
@@ -1336,9 +1337,16 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     // 32 problems in flight per wave, refilled from the work counter.
     const long long pairs = 3LL * n_traj;
     long long grid = (pairs + 31) / 32;
-    const long long max_grid = (long long)ctx->num_cus * uavqp::corridor_waves_per_cu();
+    const int own_max_ = ((uniform_segments > 0 ? uniform_segments : max_segments) + 1) / 2;
+    // Small batches of long snap problems are bound by the slowest problem's chain of iterations, not by throughput: two waves per CU
+    // with ten instead of five own knots per lane on chip make every iteration of a 24-segment problem ~13 % shorter (config 5: five
+    // rounds 5.85 -> 5.64 ms) where four waves per CU would not be kept busy anyway; large batches (config 3) lose 50 % that way.
+    const bool tail_shape = r == 4 && UAVQP_CORRIDOR_WAVES_PER_CU == 4 && own_max_ > uavqp::corridor_lds_knots(4) && pairs <= 4LL * ctx->num_cus * 2 * 32 &&
+                            ctx->settings.corridor_tail_shape != 0;
+    const int wpc = tail_shape ? 2 : uavqp::corridor_waves_per_cu();
+    const long long max_grid = (long long)ctx->num_cus * wpc;
     if (grid > max_grid) grid = max_grid;
-    const int NT = uavqp::corridor_lds_knots(r);
+    const int NT = uavqp::corridor_lds_knots(r, wpc);
     const int F = r * (r + 1) / 2 + r + 1;  // must match corridor_solve_kernel's state layout
     const int own_max = (Mmax + 1) / 2;        // own knots of the longer half, meeting knot included
     const int ws_knots = own_max > NT ? own_max - NT : 0;
@@ -1396,7 +1404,10 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
         else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
         if (chunks > 0) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<3>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, a, chunks);
     } else {
-        if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        if (tail_shape) {
+            if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, true, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, false, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+        } else if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
         if (chunks > 0) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<4>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, a, chunks);
     }
