@@ -121,7 +121,7 @@ def test_cpp_facades_mirror_of_test_qpsolve():
     subprocess.check_call(["g++", "-O2", "-std=c++14", f"-I{pkg}/cpp", f"-I{pkg}/cpp/eigen_shim",
                            os.path.join(ROOT, "tests", "cpp", "test_qpsolve_mirror.cpp"), f"{pkg}/cpp/minimum_control.cpp",
                            f"-L{pkg}", "-luavqp", f"-Wl,-rpath,{pkg}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "MinimumControl KAT" in out.stdout and "TrajOptimizer KAT" in out.stdout
 
