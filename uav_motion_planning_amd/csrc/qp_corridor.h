@@ -532,7 +532,8 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                     }
                     D[0][0] = pk ? 1.0 : D[0][0];
                     // masked coupling block between (j-1, j) and E = S_{j-1}^-1 Mp from the previous inverse
-                    double Mp[R][R], Ep[R][R];
+                    // Schur update D -= Mp' S_{j-1}^-1 Mp through the factors: Y = L^-1 Mp, D -= Y' (D^-1 Y) -- forward substitutions only
+                    double Mp[R][R], Yp[R][R], Zp[R][R];
 #pragma unroll
                     for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -542,16 +543,16 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                         double col[R];
 #pragma unroll
                         for (int i = 0; i < R; ++i) col[i] = Mp[i][c];
-                        lprev.solve(col);
+                        lprev.forward(col);
 #pragma unroll
-                        for (int i = 0; i < R; ++i) Ep[i][c] = col[i];
+                        for (int i = 0; i < R; ++i) { Yp[i][c] = col[i]; Zp[i][c] = col[i] * lprev.dinv[i]; }
                     }
 #pragma unroll
                     for (int i = 0; i < R; ++i)
 #pragma unroll
                         for (int q = 0; q < R; ++q) {
 #pragma unroll
-                            for (int c = 0; c <= i; ++c) D[i][c] -= Mp[q][i] * Ep[q][c];
+                            for (int c = 0; c <= i; ++c) D[i][c] -= Yp[q][i] * Zp[q][c];
                             rhs[i] -= Mp[q][i] * hprev[q];
                         }
                     rhs[0] = pk ? zc : rhs[0];   // pinned: row 0 of the system is the identity

@@ -124,6 +124,13 @@ struct SmallLDL {
             }
         }
     }
+    // x <- L^-1 x (forward substitution only);  S^-1 = L^-T D^-1 L^-1, so M' S^-1 M = Y' D^-1 Y with Y = L^-1 M
+    __device__ __forceinline__ void forward(double (&x)[N]) const {
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+#pragma unroll
+            for (int k = 0; k < i; ++k) x[i] -= l[i][k] * x[k];
+    }
     // x <- S^-1 x
     __device__ __forceinline__ void solve(double (&x)[N]) const {
 #pragma unroll
