@@ -361,7 +361,8 @@ int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  * minimum_control.cpp:98-125 -- so parity is per inner solve, SURVEY.md section 8-a').  Host-side C++ sequencing of the entry points
  * above on device buffers:
  *   uavqp_solve_batch_device (the reference's equality problem) -> uavqp_corridor_from_cloud_device (boxes, attitude of that solve)
- *   -> at most max_rounds x (uavqp_solve_corridor_warm_device, working set carried over + uavqp_time_reallocate_device; the loop ends
+ *   -> at most max_rounds x (uavqp_solve_corridor_warm_device -- from the second round on warm_start = 2: working set carried over, previous
+ *   polynomials as the starting point -- + uavqp_time_reallocate_device; the loop ends
  *   as soon as a re-allocation stretches nothing; if the cap is reached with durations still changing, one more solve makes the
  *   coefficients match d_times) -> uavqp_ellipsoid_check_grid_device on check_samples samples per trajectory (ONE time grid for the
  *   batch: dt = longest total duration / (check_samples - 1)) -> at most repair_rounds x (the boxes of every colliding trajectory
