@@ -6,7 +6,7 @@
 //     fill them the way setParam / localCloudCallback do);
 //   * the bodies of KinoAstar::isCollisionFree (kino_astar.cpp:721-758) and KinoAstar::toPCL (:761-774): oracle/Makefile cuts
 //     exactly these two function definitions out of kino_astar.cpp AT BUILD TIME (awk, from the line of the signature to the closing
-//     brace in column 0) into oracle/_ref/kino_astar_extract.inc -- a build product, git-ignored, never part of this repository --
+//     brace in column 0) into kino_astar_extract.inc in a TEMPORARY directory that exists for the duration of the compile only --
 //     and this file includes it.  The rest of kino_astar.cpp (the search itself, ROS plumbing, grid map) is out of scope and would
 //     need all of Eigen, PCL and ROS.
 // What is NOT: Eigen (ref_shim/Eigen/Eigen: Vector3d / Matrix3d with Eigen's formulas for normalized() and the 3 x 3 inverse()),
