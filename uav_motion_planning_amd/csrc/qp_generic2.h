@@ -329,11 +329,17 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
             for (int ax = 0; ax < 3; ++ax) dpa[ax] = dpb[ax];
         };
         // The records of the LAST NKR own knots (the ones next to the meeting knot: the first the backward sweep needs) stay in
-        // registers -- three peeled steps behind the loop, three peeled trips in front of the backward loop; only the knots before
-        // them go through the HBM workspace.  Config 4 (own eliminated knots per lane: 1..11, mean ~6): the workspace round trip
-        // drops from 86 MB to ~40 MB per dispatch, and every wave issues 27 fewer vector-memory stores and 27 fewer loads (a
-        // vector-memory instruction costs the wave ~100 cycles of issue).  One wave per SIMD: the 108 registers are there.
-        constexpr int NKR = 3;
+        // registers -- NKR peeled steps behind the loop, NKR peeled trips in front of the backward loop; only the knots before them
+        // go through the HBM workspace.  With one wave per SIMD the register file has 512 registers per lane and the compiler parks
+        // what does not fit the 256 architectural ones in the accumulator registers (v_accvgpr_write / _read: two instructions per
+        // double and direction instead of a 16-byte store, a 16-byte load and their ~1-2 us round trip through L2 / HBM).
+        // Config 4 (own eliminated knots per lane 1..11) is HBM-bound on its ACTUAL traffic -- 213 MB per dispatch at 5 TB/s with
+        // NKR = 3 (algorithmic: 109 MB) --, so every record kept on chip is time: NKR = 3 / 5 / 6 / 7 -> 43.8 / 39.3 / 38.4 / 38.6 us
+        // per launch, 213 / 183 / 171 / 162 MB (r = 4: 7 records = 252 accumulator registers, no scratch; r = 3 records are 10 doubles).
+#ifndef G2_NKR
+#define G2_NKR (R == 3 ? 11 : 7)
+#endif
+        constexpr int NKR = G2_NKR;
         const int ne = m > 0 ? m - 1 : 0;                  // own eliminated knots 1..ne
         const int n_ws = ne > NKR ? ne - NKR : 0;          // ... of which 1..n_ws go through the workspace
         // (a plain per-lane loop: lanes that are done are masked off and keep their state in place -- a wave-uniform loop with
@@ -344,12 +350,14 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
 #pragma unroll
             for (int f2 = 0; f2 < F / 2; ++f2) G2_WS_ST(W2(j, f2), make_double2(rec[2 * f2], rec[2 * f2 + 1]));
         }
-        double R0[F], R1[F], R2[F];   // records of own knots ne, ne - 1, ne - 2
+        double RK[NKR][F];   // records of own knots ne, ne - 1, .., ne - NKR + 1
 #pragma unroll
-        for (int f = 0; f < F; ++f) { R0[f] = 0.0; R1[f] = 0.0; R2[f] = 0.0; }
-        if (ne >= 3) elim_step(ne - 2, R2);
-        if (ne >= 2) elim_step(ne - 1, R1);
-        if (ne >= 1) elim_step(ne, R0);
+        for (int k = 0; k < NKR; ++k)
+#pragma unroll
+            for (int f = 0; f < F; ++f) RK[k][f] = 0.0;
+#pragma unroll
+        for (int k = NKR - 1; k >= 0; --k)
+            if (ne >= k + 1) elim_step(ne - k, RK[k]);
         G2_STAMP(4);
         // every duration of the trajectory has been seen by one of the two lanes
         bool ok;
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
         {
             double recA[F], recB[F], Tc, pa[3], pe[3];   // records of own knots mm-1-i (trip i even: A, odd: B), data of the trip's segment
             {
-                const int j1 = mm >= 5 ? mm - 4 : 1, j2 = mm >= 6 ? mm - 5 : 1;   // trips 0..2 take their records from registers
+                const int j1 = mm >= NKR + 2 ? mm - 1 - NKR : 1, j2 = mm >= NKR + 3 ? mm - 2 - NKR : 1;   // trips 0..NKR-1 take their records from registers
                 load_rec(j1, recA);
                 load_rec(j2, recB);
 #pragma unroll
@@ -525,9 +533,9 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
                 wave_lds_sync();
                 G2_ACC(4);
             };
-            if (__ballot(0 < mm) != 0ull) trip(0, R0, R0, std::false_type{}, std::false_type{});
-            if (__ballot(1 < mm) != 0ull) trip(1, R1, R1, std::false_type{}, std::false_type{});
-            if (__ballot(2 < mm) != 0ull) trip(2, R2, R2, std::false_type{}, std::false_type{});
+#pragma unroll
+            for (int k = 0; k < NKR; ++k)
+                if (__ballot(k < mm) != 0ull) trip(k, RK[k], RK[k], std::false_type{}, std::false_type{});
             for (int i = NKR; __ballot(i < mm) != 0ull; i += 2) {
                 trip(i, recA, recB, std::false_type{}, std::true_type{});
                 if (__ballot(i + 1 < mm) == 0ull) break;
