@@ -76,7 +76,7 @@ def test_settings_struct_matches_the_header_and_defaults_are_the_references():
     _lib.lib().uavqp_default_settings(ctypes.byref(st))
     assert st.struct_size == ctypes.sizeof(_lib.Settings)
     assert st.warm_start == 1 and st.eps_prim_inf == 1e-3 and st.max_iter == 0
-    assert st.ragged_window_sort == 1 and st.corridor_pdas_rounds == 3 and st.corridor_initial_guess == 1
+    assert st.ragged_window_sort == 1 and st.corridor_pdas_rounds == 3 and st.corridor_initial_guess == 2
     assert st.realloc_dead_band == 1.01 and st.realloc_overshoot == 1.02
 
 

@@ -35,7 +35,7 @@ for cfg in (3, 5):
 
     def run():
         ctx.solve_corridor_device(r, n, uni, mx, None if uni else d_so, d["waypoints"], d["times"], d["bc"], d_lo, d_hi, out, st, it)
-    modes = (1, 0, 1, 0) if len(sys.argv) > 2 and sys.argv[2] == "ab" else (1,)   # A/B of uavqp_settings.corridor_initial_guess in one process
+    modes = (2, 1, 2, 1) if len(sys.argv) > 2 and sys.argv[2] == "ab" else (2,)   # A/B of uavqp_settings.corridor_initial_guess in one process (2: dual prelude, 1: closed-form set)
     for guess in modes:
         ctx.set_settings(corridor_initial_guess=guess)
         for _ in range(2):

@@ -54,6 +54,10 @@ struct CorridorArgs {
     int warm;                      // 1: read `active` as the initial working set; 2: also start the free positions from the knot positions of the
                                    // polynomials found in `coeff` (the previous solve's output, clipped into the boxes) instead of the waypoints
     unsigned long long* guess;     // [n_traj][3][2] cold start: the closed-form starting set of corridor_prep_kernel (may be null)
+    int guess_closed_form;         // 1: corridor_prep_kernel fills `guess` with the closed-form set; 0: it only zeroes it (corridor_dual_kernel, qp_corridor_dual.h, writes it)
+#ifdef UAVQP_DUAL_DEBUG
+    double* dbg;                   // debug build only (tools/corridor_dual_gpu_probe.py): G, unconstrained minimisers, trip counts of the first trajectories
+#endif
 #ifdef UAVQP_CORRIDOR_TIMING
     long long* stamps;             // debug build only (tools/): cycles per section of wave 0 -> [refill, forward, meeting, backward, decide, hand-over, iterations]
 #endif
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
             double c[NC];
 #pragma unroll
             for (int j = 0; j < NC; ++j) c[j] = 0.0;
-            const bool want = a.guess != nullptr && M >= 2;
+            const bool want = a.guess != nullptr && a.guess_closed_form && M >= 2;
             if (want) {
                 const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
                 double ys[ND], ye[ND];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
                 g_act |= (unsigned long long)(above | below) << k;
                 g_up |= (unsigned long long)above << k;
             }
-            g_act &= ~eq;
+            g_act &= want ? ~eq : 0ull;
             g_up &= g_act;
         }
         if (!ok) atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);

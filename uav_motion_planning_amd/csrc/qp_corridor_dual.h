@@ -1,0 +1,551 @@
+// qp_corridor_dual.h -- the starting working set of the corridor solve (qp_corridor.h) from a DUAL active-set method in POSITION
+// space (round 4).  Same QP as qp_corridor.h (the reference's interior-waypoint equalities, minimum_control.cpp:34-42,118-124,
+// relaxed to boxes lo <= p_k <= hi); nothing here decides a result: the set found is handed to corridor_solve_kernel as its
+// cold-start guess, which verifies the KKT conditions with its own exact block solve (one iteration when the set is right, its usual
+// primal iterations from there when rounding made this kernel miss a near-degenerate bound).
+//
+// Why: corridor_solve_kernel pays one block-tridiagonal solve over ALL knots (~550 instructions per knot and lane pair) per change
+// of the working set, 12.5 of them per problem on config 3, and its batches are as slow as their slowest problem (config 5: up to
+// 54 solves).  Eliminating the derivatives once leaves a dense strictly convex QP in the n = M - 1 knot positions,
+//        min 1/2 p' Hp p - f' p,   lo <= p <= hi,     G = Hp^-1 = [H^-1]_pp  (H: the block-tridiagonal Hermite Hessian),
+// whose inverse Hessian G depends on the time allocation only (shared by the three axes).  On G the Goldfarb-Idnani dual method is
+// a sequence of symmetric SWEEPS of an n x n tableau T = sweep(G, W): T_FF = G_FF - G_FW G_WW^-1 G_WF (response of the free
+// positions to a multiplier), T_FW = G_FW G_WW^-1, T_WW = -G_WW^-1.  A bound that enters or leaves the working set W is one rank-one
+// update of the tableau (n^2 FMAs) -- no factorisation, no solve.  Constraint choice: steepest dual ascent, violation^2 / T_qq
+// (tools/corridor_dual_probe.py: 5.9 exchanges mean / 14 max on config 3 against 11.8 / 28 for "most violated"; the working set at
+// the end equals the primal method's on 450 / 450 problems of configs 3 and 5).
+//
+// Layout: L lanes (8 or 16: one half / one whole DPP row) per trajectory, lane l owns the tableau columns l and l + L in registers
+// with compile-time row indices; 64 / L trajectories per wave, their three axes one after the other.
+//   * G: the block LDL' chain (S_k, E_k = S_k^-1 X_k) is computed once per trajectory -- replicated in the lanes of the group, the
+//     records go through LDS --, then Z_kk = S_k^-1 + E_k Z_{k+1,k+1} E_k' backwards and, per owned column j, the vector
+//     recursion Z_{k,j} e_0 = -E_k Z_{k+1,j} e_0: G_kj = e_0' Z_{k,j} e_0.  The same pass leaves Z_{1,j} e_0 and e_0' Z_{j,n}, from
+//     which the unconstrained minimiser of every axis follows by two small dot products (its right-hand side lives at the first
+//     and last interior knot only).
+//   * a sweep on pivot k (runtime, per group): the owner lane writes its column to LDS (the only way to index registers by a
+//     run-time value is not to: the column leaves through memory), patched so that ONE generic update A[i] -= u[i] * s serves
+//     every row including row k:  u_k = t_k - sign(t_k), s_c = t_c / t_k, s_k = 1 - 1 / |t_k|; the diagonal is kept apart.
+//   * reductions over the group (best entering constraint, first blocking multiplier) are DPP butterflies on doubles that carry
+//     the column index in their low mantissa bits.
+// Rows and columns beyond n are zero and never selected; ragged batches pad the chain with decoupled identity knots.
+#pragma once
+#include "qp_corridor.h"
+
+namespace uavqp {
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// butterfly over the L lanes of a group (quad swaps, half-row mirror, row mirror): every lane ends with the result
+template <int L>
+__device__ __forceinline__ double group_max(double v) {
+    v = __builtin_fmax(v, dpp_f64<0xB1>(v));
+    v = __builtin_fmax(v, dpp_f64<0x4E>(v));
+    v = __builtin_fmax(v, dpp_f64<0x141>(v));
+    if (L == 16) v = __builtin_fmax(v, dpp_f64<0x140>(v));
+    return v;
+}
+template <int L>
+__device__ __forceinline__ double group_min(double v) {
+    v = __builtin_fmin(v, dpp_f64<0xB1>(v));
+    v = __builtin_fmin(v, dpp_f64<0x4E>(v));
+    v = __builtin_fmin(v, dpp_f64<0x141>(v));
+    if (L == 16) v = __builtin_fmin(v, dpp_f64<0x140>(v));
+    return v;
+}
+// a non-negative double with a 6-bit code in its low mantissa bits (order-preserving up to 64 ulp)
+__device__ __forceinline__ double pack_code(double v, int code) {
+    return __longlong_as_double((__double_as_longlong(v) & ~63ll) | (long long)code);
+}
+__device__ __forceinline__ int code_of(double v) { return (int)(__double_as_longlong(v) & 63ll); }
+// 1/x: hardware seed + one Newton step (2e-15 relative, tools/ubench/rcp_accuracy.hip) -- this kernel decides nothing finally
+__device__ __forceinline__ double rcp1(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// The lanes of a group talk to each other through LDS without a barrier (single-wave workgroup: the DS operations of a wave execute
+// in program order).  The COMPILER knows nothing of that: to it a store under `if (owner)` followed by a load of the same address is
+// single-thread data flow (it forwards the owner's value to the owner and an earlier load to everybody else).  lds_publish() is the
+// compiler-side half of the hand-over: nothing emitted, no memory access moved or forwarded across it.
+__device__ __forceinline__ void lds_publish() { asm volatile("" ::: "memory"); }
+typedef double2 __attribute__((may_alias)) double2_a;
+
+// LDS of one group, in doubles.  Slots of RS doubles: the chain record of knot k (S_k^-1: NE numbers, E_k: R R) sits in slot k - 1,
+// row i of G in slot i -- the backward pass reads record k first and then writes rows >= k - 1 of G over the records it no
+// longer needs (slots >= k - 1), so G and the chain records share their memory.  Then the column buffer and 8 scalars.
+constexpr int corridor_dual_slot(int R, int NRW) { return NRW > ((R * (R + 1) / 2 + R * R + 1) & ~1) ? NRW : ((R * (R + 1) / 2 + R * R + 1) & ~1); }
+constexpr int corridor_dual_lds_doubles(int R, int L, int NRW) {
+    return NRW * corridor_dual_slot(R, NRW) + 2 * (NRW + 2) + 8;
+}
+
+// One group of L lanes per trajectory; the block handles 64 / L trajectories at a time, grid-stride over the batch in the dealing
+// order of the solve kernel (a.order, longest first), so that the trajectories of a wave are of similar length.
+template <int R, int L, int NRW>
+__global__ __launch_bounds__(64, (NRW <= 24 ? 2 : 1)) void corridor_dual_kernel(CorridorArgs a, int n_lo, int max_trips_extra) {
+    constexpr int ND = R - 1, NG = 64 / L, NE = R * (R + 1) / 2, LOG2L = (L == 16) ? 4 : 3;
+    constexpr int RS = corridor_dual_slot(R, NRW), CBS = NRW + 2;
+    constexpr int O_CB = NRW * RS, O_SC = O_CB + 2 * CBS, GRP = corridor_dual_lds_doubles(R, L, NRW);
+    static_assert(NRW % 2 == 0 && NRW <= 2 * L && NRW <= 32, "rows: even, at most two columns per lane, codes are 5 bits");
+    static_assert(O_CB % 2 == 0 && GRP % 2 == 0 && RS % 2 == 0, "16-byte aligned rows");
+    __shared__ __attribute__((aligned(16))) double s_all[NG * GRP];
+    using Inv = SmallLDL<R>;
+    const int lane = threadIdx.x, l = lane & (L - 1), grp = lane >> LOG2L;
+    double* const sg = s_all + grp * GRP;
+    double* const CB = sg + O_CB;     // [2][NRW + 2]: the two columns of the lane that owns the pivot; element NRW is a constant zero
+    double* const SC = sg + O_SC;
+    auto ES = [&](int k) -> double* { return sg + (k - 1) * RS; };   // chain record of knot k = 1..NRW
+    auto GR = [&](int i) -> double* { return sg + i * RS; };         // row i of G
+    const int cidx[2] = {l, l + L};                                         // owned columns (variable j <-> interior knot j + 1)
+    const int crd[2] = {cidx[0] < NRW ? cidx[0] : NRW, cidx[1] < NRW ? cidx[1] : NRW};   // row of the column buffer a lane reads (NRW: the zero)
+    const int crow[2] = {min(cidx[0], NRW - 1), min(cidx[1], NRW - 1)};    // clamped row of G
+
+    const long long n_batches = ((long long)a.n_traj + NG - 1) / NG;
+    for (long long bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
+        // ---------------- the group's trajectory ----------------
+        const long long bq = bt * NG + grp;
+        const bool have = bq < a.n_traj;
+        const int b = have ? (a.order ? a.order[bq] : (int)bq) : 0;
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        unsigned long long dsc[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) dsc[ax] = have ? a.desc[3LL * b + ax] : 0ull;
+        // (a batch of mixed lengths is covered by two launches: this one takes the trajectories with n_lo <= M - 1 <= NRW interior knots)
+        const bool solve_any = ((dsc[0] | dsc[1] | dsc[2]) & 1ull) && M >= 2 && M - 1 <= NRW && M - 1 >= n_lo;
+        if (__ballot(solve_any) == 0ull) continue;
+        if (!solve_any) M = 2;                       // (keeps every index below in range; nothing is written for this group)
+        const int n = M - 1;                         // variables = interior knots 1..n
+        const double* const TT = a.times + s0;
+        // durations through LDS (the column buffer is free until the dual phase): one coalesced load per lane instead of a dependent
+        // global load per chain knot; a group without a problem reads nothing
+        lds_publish();
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+            if (cidx[sl] < NRW) CB[cidx[sl]] = (solve_any && cidx[sl] < M) ? TT[cidx[sl]] : 1.0;
+        if (l == 0) CB[NRW] = (solve_any && NRW < M) ? TT[NRW] : 1.0;
+        lds_publish();
+        auto ldT = [&](int i) -> double { return CB[i]; };
+        int kmax = n;                                // longest chain of the wave: uniform loop bounds
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
+        kmax = __builtin_amdgcn_readfirstlane(kmax);
+        lds_publish();
+
+        // ---------------- forward: block LDL' chain, replicated in the lanes of the group ----------------
+        FullBlocks<R> sa;
+        sa.build(ldT(0));
+        Inv lprev;
+        LDLPack<R>::zero(lprev);
+#pragma unroll 1
+        for (int k = 1; k <= kmax; ++k) {
+            const bool vk = k <= n;
+            FullBlocks<R> sb;
+            sb.build(ldT(min(k, M - 1)));
+            const double cpl = (vk && k >= 2) ? 1.0 : 0.0;          // coupling X_{k-1} between knots k - 1 and k
+            double D[R][R], Mp[R][R], Yp[R][R], Zp[R][R];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const double dv = sa.B11[i][c] + sb.B00(i, c);
+                    D[i][c] = vk ? dv : (i == c ? 1.0 : 0.0);
+                    Mp[i][c] = sa.B01[i][c] * cpl;
+                }
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                double col[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) col[i] = Mp[i][c];
+                lprev.forward(col);
+#pragma unroll
+                for (int i = 0; i < R; ++i) { Yp[i][c] = col[i]; Zp[i][c] = col[i] * lprev.dinv[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+#pragma unroll
+                    for (int c = 0; c <= i; ++c) D[i][c] -= Yp[q][i] * Zp[q][c];
+            // E_{k-1} = S_{k-1}^-1 X_{k-1} = L^-T (D^-1 L^-1 X): back-substitution of Zp
+            if (k >= 2) {
+                double E[R][R];
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+#pragma unroll
+                    for (int i = R - 1; i >= 0; --i) {
+                        double v = Zp[i][c];
+#pragma unroll
+                        for (int q = i + 1; q < R; ++q) v -= lprev.l[q][i] * E[q][c];
+                        E[i][c] = v;
+                    }
+                }
+                if (l == 0) {
+                    double* const rec = ES(k - 1);
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int c = 0; c < R; ++c) rec[NE + i * R + c] = E[i][c];
+                }
+            }
+            Inv ldl;
+            ldl.factor(D);
+            {   // S_k^-1 (symmetric, lower triangle): columns of the identity through the factors
+                double Si[R][R];
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    double col[R];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+                    ldl.solve(col);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) Si[i][c] = col[i];
+                }
+                if (l == 0) {
+                    double* const rec = ES(k);
+                    int f = 0;
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int c = 0; c <= i; ++c) rec[f++] = Si[i][c];
+                }
+            }
+            lprev = ldl;
+            sa = sb;
+        }
+        if (l == 0) {   // E of the last chain knot: nothing behind it
+            double* const rec = ES(kmax);
+#pragma unroll
+            for (int i = 0; i < R * R; ++i) rec[NE + i] = 0.0;
+        }
+        lds_publish();
+
+        // ---------------- backward: diagonal blocks of H^-1, the last block column, the owned columns of G ----------------
+        double Zk1[R][R], Zkn[R][R], cv[2][R], wv[2][R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            cv[0][i] = 0.0; cv[1][i] = 0.0; wv[0][i] = 0.0; wv[1][i] = 0.0;
+#pragma unroll
+            for (int c = 0; c < R; ++c) { Zk1[i][c] = 0.0; Zkn[i][c] = 0.0; }
+        }
+#pragma unroll 1
+        for (int k = kmax; k >= 1; --k) {
+            double Si[R][R], E[R][R];
+            {
+                const double* const rec = ES(k);
+                int f = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int c = 0; c <= i; ++c) { Si[i][c] = rec[f]; Si[c][i] = Si[i][c]; ++f; }
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int c = 0; c < R; ++c) E[i][c] = rec[NE + i * R + c];
+            }
+            lds_publish();    // (the record is in registers before rows of G are written over this and older slots)
+            double P[R][R], Zkk[R][R];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = 0; q < R; ++q) v += E[i][q] * Zk1[q][c];
+                    P[i][c] = v;
+                }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int c = 0; c <= i; ++c) {
+                    double v = Si[i][c];
+#pragma unroll
+                    for (int q = 0; q < R; ++q) v += P[i][q] * E[c][q];
+                    Zkk[i][c] = v;
+                    Zkk[c][i] = v;
+                }
+            const double dn = (k == n) ? 1.0 : 0.0;
+            {
+                double Zn[R][R];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        double v = dn * Zkk[i][c];
+#pragma unroll
+                        for (int q = 0; q < R; ++q) v -= E[i][q] * Zkn[q][c];
+                        Zn[i][c] = v;
+                    }
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int c = 0; c < R; ++c) Zkn[i][c] = Zn[i][c];
+            }
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int kj = cidx[sl] + 1;
+                const double dj = (k == kj) ? 1.0 : 0.0;
+                double nv[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    double v = dj * Zkk[i][0];
+#pragma unroll
+                    for (int q = 0; q < R; ++q) v -= E[i][q] * cv[sl][q];
+                    nv[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) { cv[sl][i] = nv[i]; wv[sl][i] = fma(dj, Zkn[0][i], wv[sl][i]); }   // w_j = e_0' Z_{j,n}: picked up at k = j + 1
+                if (k <= kj && kj <= n) {    // entry (k - 1, j) and its mirror
+                    GR(k - 1)[cidx[sl]] = nv[0];
+                    GR(cidx[sl])[k - 1] = nv[0];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int c = 0; c < R; ++c) Zk1[i][c] = Zkk[i][c];
+        }
+        // rows and columns beyond n hold what the chain records left there: they must be neutral in the sweeps
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+            if (cidx[sl] < NRW) {
+                double* const row = GR(cidx[sl]);
+#pragma unroll 1
+                for (int i = cidx[sl] >= n ? 0 : n; i < NRW; ++i) row[i] = 0.0;
+            }
+        lds_publish();
+        // cv[sl] = Z_{1,j} e_0, wv[sl] = e_0' Z_{j,n} of the owned columns
+        const int nrows = __builtin_amdgcn_readfirstlane(min(NRW, (kmax + 1) & ~1));   // tableau rows the wave touches (even)
+#ifdef UAVQP_DUAL_DEBUG
+        // per trajectory (dealing position bq < 64): [0, 1024) G row-major [32][32];  [1024 + 96 ax + 32 what + col]: what 0 = p_unc, 1 = trips, 2 = p at the end
+        double* const dbg = (a.dbg && have && bq < 64) ? a.dbg + bq * 2048 : nullptr;
+        if (dbg) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+                if (cidx[sl] < n)
+                    for (int i = 0; i < n; ++i) dbg[i * 32 + cidx[sl]] = GR(cidx[sl])[i];
+        }
+#endif
+
+        // ---------------- per axis: unconstrained minimiser and boxes of the owned columns (all loads in flight together) ----------------
+        double y0[3][2], lo3[3][2], hi3[3][2];
+        {
+            FullBlocks<R> seg0, segl;
+            seg0.build(ldT(0));
+            segl.build(ldT(M - 1));
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const bool on = solve_any && (dsc[ax] & 1ull);
+                const long long base3 = 3LL * ((long long)s0 + b) + ax;
+                const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+                double x0[R], xM[R], r1[R], rn[R];
+                x0[0] = on ? a.waypoints[base3] : 0.0;
+                xM[0] = on ? a.waypoints[base3 + 3LL * M] : 0.0;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { x0[d + 1] = on ? bc[d * 3] : 0.0; xM[d + 1] = on ? bc[(ND + d) * 3] : 0.0; }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    double v1 = 0.0, vn = 0.0;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) { v1 -= seg0.B01[c][i] * x0[c]; vn -= segl.B01[i][c] * xM[c]; }
+                    r1[i] = v1;
+                    rn[i] = vn;
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const bool vc = on && cidx[sl] < n;
+                    const int kk = min(cidx[sl] + 1, M - 1);
+                    lo3[ax][sl] = vc ? a.corr_lo[base3 + 3LL * kk] : 0.0;
+                    hi3[ax][sl] = vc ? a.corr_hi[base3 + 3LL * kk] : 0.0;
+                    double v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) v += cv[sl][c] * r1[c] + wv[sl][c] * rn[c];
+                    y0[ax][sl] = vc ? v : 0.0;
+                }
+            }
+        }
+        lds_publish();
+        if (l == 0) { CB[NRW] = 0.0; CB[NRW + 1] = 0.0; CB[CBS + NRW] = 0.0; CB[CBS + NRW + 1] = 0.0; }
+        lds_publish();
+
+        // ---------------- the three axes, one after the other for the whole wave ----------------
+        // (Groups at their own pace -- a finished group starting its next axis while the others still iterate -- was built first:
+        // the hand-over / set-up code then runs once per group and axis instead of once per axis, ~500 instructions each time for
+        // the whole wave, which cost more than the idle trips of a group that waits for the slowest of its wave do.)
+        // Per owned column: y = the position while the bound is free, MINUS its multiplier while it is in the working set (both move
+        // by +t d along a dual step); sw = +1 / -1 while a lower / upper bound is in the working set (0: free, or an equality row).
+        double A[2][NRW];
+        const int max_trips = 4 * n + 16 + max_trips_extra;
+#pragma unroll 1
+        for (int axis = 0; axis < 3; ++axis) {
+        const unsigned long long dcur = axis == 0 ? dsc[0] : (axis == 1 ? dsc[1] : dsc[2]);
+        const bool on = solve_any && (dcur & 1ull);
+        int q = -1, trips = 0;
+        double sdir = 0.0, muq = 0.0;        // direction of the entering constraint, its multiplier so far
+        double dg[2], y[2], lo[2], hi[2], tol[2], sw[2] = {0.0, 0.0}, eqb[2];
+        bool valid[2], inW[2] = {false, false};
+        lds_publish();
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            valid[sl] = on && cidx[sl] < n;
+            const int kk = min(cidx[sl] + 1, M - 1);
+            lo[sl] = axis == 0 ? lo3[0][sl] : (axis == 1 ? lo3[1][sl] : lo3[2][sl]);
+            hi[sl] = axis == 0 ? hi3[0][sl] : (axis == 1 ? hi3[1][sl] : hi3[2][sl]);
+            y[sl] = axis == 0 ? y0[0][sl] : (axis == 1 ? y0[1][sl] : y0[2][sl]);
+            tol[sl] = 1e-12 * (1.0 + fmin(fabs(lo[sl]), fabs(hi[sl])));
+            eqb[sl] = (valid[sl] && ((dcur >> kk) & 1ull)) ? 1e300 : 0.0;
+            dg[sl] = valid[sl] ? GR(crow[sl])[crow[sl]] : 1.0;
+            const double* const row = GR(crow[sl]);     // (rows / columns beyond n are zero)
+#pragma unroll
+            for (int i = 0; i < NRW; i += 2) {
+                const double2 tt = *reinterpret_cast<const double2_a*>(row + i);
+                A[sl][i] = tt.x;
+                A[sl][i + 1] = tt.y;
+            }
+        }
+#ifdef UAVQP_DUAL_DEBUG
+        if (dbg)
+            for (int sl = 0; sl < 2; ++sl) if (valid[sl]) dbg[1024 + 96 * axis + cidx[sl]] = y[sl];
+#endif
+        bool done = !on;
+        for (;;) {
+            lds_publish();
+            // ---- entering constraint: steepest dual ascent, violation^2 / T_qq.  A group without one is done with this axis: every
+            // position inside its box (or the trip budget spent: the solve kernel goes on from any set)
+            if (__ballot(!done && q < 0) != 0ull) {
+                double key = 0.0;
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const double below = lo[sl] - y[sl], above = y[sl] - hi[sl];
+                    const double v = fmax(below, above);
+                    const bool cand = valid[sl] && !inW[sl] && v > tol[sl] && dg[sl] > 0.0;
+                    const double kv = fmax(fmin(v * v * __builtin_amdgcn_rcp(dg[sl]), 1e299), eqb[sl]);
+                    const double pk = pack_code(kv, (below > above ? 32 : 0) | cidx[sl]);
+                    key = fmax(key, cand ? pk : 0.0);
+                }
+                key = group_max<L>(key);
+                if (!done && q < 0) {
+                    if (key > 1e-300 && trips < max_trips) { const int cd = code_of(key); q = cd & 31; sdir = (cd & 32) ? 1.0 : -1.0; muq = 0.0; }
+                    else done = true;
+                }
+            }
+            if (__ballot(!done) == 0ull) break;
+            const bool go = !done;
+
+            const int qq = go ? q : 0;
+            const int lq = qq & (L - 1), slq = qq >> LOG2L;
+            const bool own_q = go && (l == lq);
+            // ---- direction: column q of the tableau (owner -> LDS -> everyone's own rows), full step length
+            if (own_q) {
+#pragma unroll
+                for (int i = 0; i < NRW; i += 2) {
+                    *reinterpret_cast<double2_a*>(CB + i) = make_double2(A[0][i], A[0][i + 1]);
+                    *reinterpret_cast<double2_a*>(CB + CBS + i) = make_double2(A[1][i], A[1][i + 1]);
+                }
+                const double dq = slq ? dg[1] : dg[0], pq = slq ? y[1] : y[0];
+                const double bq_ = sdir > 0.0 ? (slq ? lo[1] : lo[0]) : (slq ? hi[1] : hi[0]);
+                const double pv = rcp1(dq);
+                CB[slq * CBS + qq] = dq;
+                SC[0] = (bq_ - pq) * sdir * pv;
+                SC[1] = pv;
+                SC[2] = bq_;
+            }
+            lds_publish();
+            double d[2];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) d[sl] = sdir * CB[slq * CBS + crd[sl]];
+            const double t1 = SC[0];
+            // ---- first multiplier of the working set to reach zero: mu / d with mu = -y, for bounds whose multiplier moves towards zero
+            double rmin = 1e300;
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const bool blocks = sw[sl] * d[sl] > 0.0;
+                const double ratio = fmin(fmax(-y[sl] * rcp1(d[sl]), 0.0), 1e299);
+                rmin = fmin(rmin, blocks ? pack_code(ratio, cidx[sl]) : 1e300);
+            }
+            rmin = group_min<L>(rmin);
+            const bool partial = go && rmin < t1;
+            const double t = go ? (partial ? rmin : t1) : 0.0;
+            const int kp = partial ? code_of(rmin) & 31 : qq;        // pivot of this trip
+            const int lk = kp & (L - 1), slk = kp >> LOG2L;
+            const bool own_k = go && (l == lk);
+            // ---- step (rows beyond n and lanes beyond the tableau have d = 0)
+            y[0] = fma(t, d[0], y[0]);
+            y[1] = fma(t, d[1], y[1]);
+            muq = fma(sdir, t, muq);
+            // ---- sweep on the pivot: the constraint q enters (full step) or the blocking one leaves (partial step)
+            if (__ballot(partial) != 0ull) {
+                if (own_k && partial) {
+#pragma unroll
+                    for (int i = 0; i < NRW; i += 2) {
+                        *reinterpret_cast<double2_a*>(CB + i) = make_double2(A[0][i], A[0][i + 1]);
+                        *reinterpret_cast<double2_a*>(CB + CBS + i) = make_double2(A[1][i], A[1][i + 1]);
+                    }
+                    SC[1] = rcp1(slk ? dg[1] : dg[0]);
+                }
+            }
+            if (own_k) {
+                const double tk = slk ? dg[1] : dg[0];
+                CB[slk * CBS + kp] = tk - (partial ? -1.0 : 1.0);    // (entering: T_qq > 0; leaving: -[G_WW^-1]_kk < 0)
+            }
+            lds_publish();
+            {
+                const double piv = go ? SC[1] : 0.0;
+                const double bnd_q = SC[2];
+                double s[2];
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const double tc = CB[slk * CBS + crd[sl]];
+                    const bool pc = own_k && sl == slk;
+                    s[sl] = tc * piv;                                   // (pivot column: (t_k - sign) / t_k = 1 - 1 / |t_k|, by the patch)
+                    const double dn = fma(-tc, s[sl], dg[sl]);
+                    dg[sl] = pc ? -piv : dn;
+                    // the pivot's column changes sides: entering, y = -multiplier; leaving, y = the bound it sat on
+                    const double yb = sw[sl] < 0.0 ? hi[sl] : lo[sl];
+                    y[sl] = pc ? (partial ? yb : -muq) : y[sl];
+                    sw[sl] = pc ? ((partial || eqb[sl] != 0.0) ? 0.0 : sdir) : sw[sl];
+                    inW[sl] = pc ? !partial : inW[sl];
+                }
+                (void)bnd_q;
+#pragma unroll
+                for (int i = 0; i < NRW; i += 2) {
+                    if (i < nrows) {
+                        const double2 u = *reinterpret_cast<const double2_a*>(CB + slk * CBS + i);
+#pragma unroll
+                        for (int sl = 0; sl < 2; ++sl) {
+                            A[sl][i] = fma(-u.x, s[sl], A[sl][i]);
+                            A[sl][i + 1] = fma(-u.y, s[sl], A[sl][i + 1]);
+                        }
+                    }
+                }
+            }
+            if (go) {
+                if (!partial) q = -1;
+                ++trips;
+            }
+        }
+        // ---- hand the working set of this axis over (bit k = interior knot k, as the solve kernel reads it)
+        {
+            const unsigned long long bw0 = __ballot(inW[0] && sw[0] != 0.0), bw1 = __ballot(inW[1] && sw[1] != 0.0);
+            const unsigned long long bu0 = __ballot(inW[0] && sw[0] < 0.0), bu1 = __ballot(inW[1] && sw[1] < 0.0);
+#ifdef UAVQP_DUAL_DEBUG
+            if (on && dbg)
+                for (int sl = 0; sl < 2; ++sl) if (valid[sl]) { dbg[1024 + 96 * axis + 64 + cidx[sl]] = y[sl]; dbg[1024 + 96 * axis + 32 + cidx[sl]] = (double)trips; }
+#endif
+            if (on && l == 0) {
+                const unsigned long long gm = (L == 16) ? 0xFFFFull : 0xFFull;
+                const unsigned long long act = (((bw0 >> (grp * L)) & gm) << 1) | (((bw1 >> (grp * L)) & gm) << (1 + L));
+                const unsigned long long upm = (((bu0 >> (grp * L)) & gm) << 1) | (((bu1 >> (grp * L)) & gm) << (1 + L));
+                a.guess[2 * (3LL * b + axis)] = act;
+                a.guess[2 * (3LL * b + axis) + 1] = upm;
+            }
+        }
+        }
+    }
+}
+
+}  // namespace uavqp

@@ -690,6 +690,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 #include "qp_twisted.h"
 #include "qp_generic2.h"
 #include "qp_corridor.h"
+#include "qp_corridor_dual.h"
 #include "qp_rows.h"
 #include "qp_rows2.h"
 #include "obstacle_grid.h"
@@ -733,6 +734,8 @@ struct uavqp_ctx {
     size_t ws_bytes = 0;
     uavqp::Comm comm;         // RCCL communicator of the multi-GPU entry points (uavqp_comm_create)
     void* dbg_queue = nullptr;  // (debug builds) where the last corridor solve kept its work counter
+    void* dbg_dual = nullptr;   // (UAVQP_DUAL_DEBUG builds) dump area of corridor_dual_kernel
+    void* dbg_guess = nullptr;  // (UAVQP_DUAL_DEBUG builds) the starting sets of the last cold corridor solve
     int32_t* perm = nullptr;  // ragged dealing permutation (window_sort_kernel); behind it the packed {b, s0, M, 0} records
     size_t perm_count = 0;
     uint64_t* rows_warm = nullptr;   // [n_traj][3][2] working set of the box-only phase of uavqp_solve_rows_batch_device
@@ -778,7 +781,7 @@ extern "C" void uavqp_default_settings(uavqp_settings* out) {
     out->corridor_pdas_rounds_warm = 0;
     out->cloud_window = 1;
     out->corridor_tail_shape = 1;
-    out->corridor_initial_guess = 1;
+    out->corridor_initial_guess = 2;
     out->rows_lanes_per_problem = 0;
     out->realloc_dead_band = 1.01;
     out->realloc_overshoot = 1.02;
@@ -798,7 +801,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     ctx->settings = *st;
     ctx->settings.warm_start = st->warm_start ? 1 : 0;
     ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
-    ctx->settings.corridor_initial_guess = st->corridor_initial_guess ? 1 : 0;
+    ctx->settings.corridor_initial_guess = st->corridor_initial_guess < 0 ? 0 : (st->corridor_initial_guess > 2 ? 2 : st->corridor_initial_guess);
     ctx->settings.cloud_window = st->cloud_window ? 1 : 0;
     ctx->settings.corridor_tail_shape = st->corridor_tail_shape ? 1 : 0;
     return UAVQP_OK;
@@ -1330,7 +1333,13 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     uavqp::CorridorArgs a;
     a.active = (unsigned long long*)d_active_set; a.warm = warm_start == 2 ? 2 : (warm_start ? 1 : 0);
     a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax; a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 8 * Mmax + 20;
-    a.pdas_rounds = warm_start ? ctx->settings.corridor_pdas_rounds_warm : ctx->settings.corridor_pdas_rounds;
+    // cold start: 0 = empty set, 1 = closed-form set of the prep kernel, 2 = the set the position-space dual method ends with
+    // (qp_corridor_dual.h; trajectories of up to 33 segments, longer batches fall back to 1) -- then no block-pivot rounds: the set
+    // only has to be verified
+    const int gmode = warm_start ? 0 : ctx->settings.corridor_initial_guess;
+    const bool dual = gmode == 2 && Mmax >= 2 && Mmax - 1 <= 32;
+    a.pdas_rounds = warm_start ? ctx->settings.corridor_pdas_rounds_warm : (dual ? 0 : ctx->settings.corridor_pdas_rounds);
+    a.guess_closed_form = (gmode != 0 && !dual) ? 1 : 0;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.coeff = d_coeff_out; a.status = d_status_out; a.iters = d_iters_out;
     // Persistent single-wave workgroups, one per SIMD (the sweep state of a lane pair lives in LDS: 4 x 40 KiB per CU),
@@ -1367,7 +1376,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort && !d_order_ready;
     const size_t b_order = deal_by_length ? length_order_bytes(n_traj) : 0;   // order + histogram + cursors
     const size_t b_state = sizeof(double) * (size_t)ws_knots * F * (size_t)grid * 64;
-    const bool guess = !warm_start && ctx->settings.corridor_initial_guess != 0;     // cold start from the closed-form set of the prep kernel
+    const bool guess = gmode != 0;     // cold start from a starting set (closed form: prep kernel; dual method: corridor_dual_kernel)
     const size_t b_guess = guess ? align256(sizeof(unsigned long long) * 6 * (size_t)n_traj) : 0;
     int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state + b_guess);
     if (rc != UAVQP_OK) return rc;
@@ -1384,6 +1393,16 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
         rc = make_length_order(ctx, d_seg_offsets, n_traj, (char*)ctx->ws + b_xsol + b_queue + b_desc, &a.order);
         if (rc != UAVQP_OK) return rc;
     }
+#ifdef UAVQP_DUAL_DEBUG
+    {
+        static double* s_dbg = nullptr;
+        if (!s_dbg) { UAVQP_HIP(hipMalloc(&s_dbg, 64 * 2048 * sizeof(double))); }
+        UAVQP_HIP(hipMemsetAsync(s_dbg, 0, 64 * 2048 * sizeof(double), ctx->stream));
+        a.dbg = s_dbg;
+        ctx->dbg_dual = s_dbg;
+        ctx->dbg_guess = a.guess;
+    }
+#endif
 #ifdef UAVQP_CORRIDOR_TIMING
     a.stamps = (long long*)((char*)a.queue + 64);   // debug build: section cycles of wave 0, read back by uavqp_debug_corridor_stamps
 #endif
@@ -1398,6 +1417,27 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
         if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
         if (r == 3) hipLaunchKernelGGL(uavqp::corridor_prep_kernel<3>, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(uavqp::corridor_prep_kernel<4>, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
+    }
+    if (dual) {
+        // groups of 8 lanes (two tableau columns each) for the trajectories of up to 17 segments, whole DPP rows for the longer ones: a batch
+        // of mixed lengths gets both launches, each skipping (per wave: the dealing order is by length) what the other one takes
+        auto launch_dual = [&](int L, int NRW, int n_lo) {
+            const long long nb = ((long long)n_traj + 64 / L - 1) / (64 / L);
+            const int lds_b = 8 * (64 / L) * uavqp::corridor_dual_lds_doubles(r, L, NRW);
+            int wpc_d = (160 * 1024) / lds_b;
+            const int wmax = NRW <= 24 ? 8 : 4;                   // (registers: two waves per SIMD up to 24 tableau rows, one beyond)
+            if (wpc_d > wmax) wpc_d = wmax;
+            if (wpc_d < 1) wpc_d = 1;
+            const long long dgrid = nb < (long long)ctx->num_cus * wpc_d ? nb : (long long)ctx->num_cus * wpc_d;
+#define UAVQP_DUAL_LAUNCH(R_, L_, N_) hipLaunchKernelGGL((uavqp::corridor_dual_kernel<R_, L_, N_>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, a, n_lo, 0)
+            if (r == 3) { if (NRW == 16) UAVQP_DUAL_LAUNCH(3, 8, 16); else if (NRW == 24) UAVQP_DUAL_LAUNCH(3, 16, 24); else UAVQP_DUAL_LAUNCH(3, 16, 32); }
+            else { if (NRW == 16) UAVQP_DUAL_LAUNCH(4, 8, 16); else if (NRW == 24) UAVQP_DUAL_LAUNCH(4, 16, 24); else UAVQP_DUAL_LAUNCH(4, 16, 32); }
+#undef UAVQP_DUAL_LAUNCH
+        };
+        const int nvar = Mmax - 1;
+        const bool mixed = uniform_segments == 0;
+        if (nvar <= 16 || mixed) launch_dual(8, 16, 1);
+        if (nvar > 16) launch_dual(16, nvar <= 24 ? 24 : 32, mixed ? 17 : 1);
     }
     if (r == 3) {
         if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
@@ -1423,6 +1463,18 @@ extern "C" int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_tra
     return corridor_warm_impl(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times, d_bc, d_corr_lo, d_corr_hi,
                               d_coeff_out, d_status_out, d_iters_out, d_active_set, warm_start, -1);
 }
+
+#ifdef UAVQP_DUAL_DEBUG
+// debug build only (tools/corridor_dual_gpu_probe.py): what corridor_dual_kernel computed for the first 64 trajectories of the last
+// cold corridor solve, and the starting sets [n_traj][3][2] it handed to the solve kernel
+extern "C" int uavqp_debug_corridor_dual(uavqp_ctx* ctx, double* out_64x2048, unsigned long long* out_guess, int n_traj) {
+    if (!ctx || !ctx->dbg_dual) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    UAVQP_HIP(hipMemcpy(out_64x2048, ctx->dbg_dual, 64 * 2048 * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_guess && ctx->dbg_guess) UAVQP_HIP(hipMemcpy(out_guess, ctx->dbg_guess, sizeof(unsigned long long) * 6 * (size_t)n_traj, hipMemcpyDeviceToHost));
+    return UAVQP_OK;
+}
+#endif
 
 #ifdef UAVQP_CORRIDOR_TIMING
 // debug build only (tools/corridor_sections.py): cycles wave 0 of the last corridor solve spent per section
