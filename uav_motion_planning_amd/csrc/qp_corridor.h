@@ -54,6 +54,8 @@ struct CorridorArgs {
     int warm;                      // 1: read `active` as the initial working set; 2: also start the free positions from the knot positions of the
                                    // polynomials found in `coeff` (the previous solve's output, clipped into the boxes) instead of the waypoints
     unsigned long long* guess;     // [n_traj][3][2] cold start: the closed-form starting set of corridor_prep_kernel (may be null)
+    const int32_t* only_i32;       // optional masks of an outer loop (uavqp_pipeline.h): when either is given, only the trajectories with a non-zero
+    const unsigned char* only_u8;  // entry in one of them take part; the others keep their coefficients, status, iteration count and working set
     int guess_closed_form;         // 1: corridor_prep_kernel fills `guess` with the closed-form set; 0: it only zeroes it (corridor_dual_kernel, qp_corridor_dual.h, writes it)
 #ifdef UAVQP_DUAL_DEBUG
     double* dbg;                   // debug build only (tools/corridor_dual_gpu_probe.py): G, unconstrained minimisers, trip counts of the first trajectories
@@ -100,6 +102,18 @@ struct FullBlocks {
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+}
+// does trajectory b take part in this solve?  (no mask: all do)
+__device__ __forceinline__ bool corridor_takes_part(const int32_t* only_i32, const unsigned char* only_u8, int b) {
+    if (!only_i32 && !only_u8) return true;
+    return (only_i32 && only_i32[b] != 0) || (only_u8 && only_u8[b] != 0);
+}
+__global__ void corridor_reset_kernel(int32_t* status, int32_t* iters, int n, const int32_t* only_i32, const unsigned char* only_u8) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && corridor_takes_part(only_i32, only_u8, i)) {
+        status[i] = (int32_t)UAVQP_SOLVED;
+        if (iters) iters[i] = 0;
+    }
 }
 
 __device__ __forceinline__ int swap_pair_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
@@ -174,6 +188,11 @@ __global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
     const long long total = (long long)a.n_traj * 3;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(q / 3), ax = (int)(q - 3LL * b);
+        if (!corridor_takes_part(a.only_i32, a.only_u8, b)) {   // not part of this solve: no problem, nothing reported
+            a.desc[q] = 0ull;
+            if (a.guess) { a.guess[2 * q] = 0ull; a.guess[2 * q + 1] = 0ull; }
+            continue;
+        }
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
         const long long base3 = 3LL * ((long long)s0 + b) + ax;
@@ -954,7 +973,7 @@ __global__ __launch_bounds__(256) void corridor_emit_kernel(CorridorArgs a, long
                 M = a.seg_offsets[b + 1] - s0;
             }
             const int st = a.status[b];
-            if (!(st == UAVQP_INVALID_INPUT || M < 1)) {   // (those are left untouched)
+            if (!(st == UAVQP_INVALID_INPUT || M < 1) && corridor_takes_part(a.only_i32, a.only_u8, b)) {   // (those are left untouched)
                 keep = true;
                 const int rem = (int)(e - 3LL * s0), ax = rem / M, k = rem - ax * M;
                 const size_t row0 = (size_t)(s0 + b);

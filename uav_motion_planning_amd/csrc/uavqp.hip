@@ -1322,7 +1322,8 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
                               const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
                               const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
                               double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
-                              uint64_t* d_active_set, int warm_start, long long total_segments, const int32_t* d_order_ready = nullptr) {
+                              uint64_t* d_active_set, int warm_start, long long total_segments, const int32_t* d_order_ready = nullptr,
+                              const int32_t* d_only_i32 = nullptr, const unsigned char* d_only_u8 = nullptr) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
     if (n_traj == 0) return UAVQP_OK;
     if (!d_waypoints || !d_times || !d_bc || !d_corr_lo || !d_corr_hi || !d_coeff_out || !d_status_out) return UAVQP_ERR_INVALID_ARG;
@@ -1340,6 +1341,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     const bool dual = gmode == 2 && Mmax >= 2 && Mmax - 1 <= 32;
     a.pdas_rounds = warm_start ? ctx->settings.corridor_pdas_rounds_warm : (dual ? 0 : ctx->settings.corridor_pdas_rounds);
     a.guess_closed_form = (gmode != 0 && !dual) ? 1 : 0;
+    a.only_i32 = d_only_i32; a.only_u8 = d_only_u8;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.coeff = d_coeff_out; a.status = d_status_out; a.iters = d_iters_out;
     // Persistent single-wave workgroups, one per SIMD (the sweep state of a lane pair lives in LDS: 4 x 40 KiB per CU),
@@ -1407,8 +1409,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     a.stamps = (long long*)((char*)a.queue + 64);   // debug build: section cycles of wave 0, read back by uavqp_debug_corridor_stamps
 #endif
     UAVQP_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
-    if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
+    hipLaunchKernelGGL(uavqp::corridor_reset_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, d_iters_out, n_traj, d_only_i32, d_only_u8);
     const long long chunks = 3LL * (rows - n_traj);  // (trajectory, axis, segment) triples
     long long egrid = (chunks + 255) / 256;
     if (egrid > (long long)ctx->num_cus * 16) egrid = (long long)ctx->num_cus * 16;

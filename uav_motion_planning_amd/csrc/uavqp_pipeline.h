@@ -215,9 +215,14 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
         rc = make_length_order(ctx, d_seg_offsets, n, base + o_or, &d_order);
         if (rc != UAVQP_OK) return rc;
     }
-    auto corridor_solve = [&](int warm) {
+    // Re-solves take only the trajectories whose problem changed since their last solve -- durations stretched by the re-allocation
+    // (d_changed) or boxes shrunk by a repair (d_flag): the others would reproduce their coefficients bit for bit.  With the default
+    // cold start (uavqp_settings.corridor_initial_guess = 2: the working set of the position-space dual method, verified by one block
+    // solve) a re-solve is a cold solve; with the other settings it is warm-started from the previous round as before.
+    const bool cold_rounds = ctx->settings.corridor_initial_guess == 2 && (uni > 0 ? uni : mx) - 1 <= 32;
+    auto corridor_solve = [&](int warm, const int32_t* only_i32 = nullptr, const unsigned char* only_u8 = nullptr) {
         return corridor_warm_impl(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_corr_lo, d_corr_hi, d_coeff_out,
-                                  d_status_out, d_iters, d_active, warm, total_segments, d_order);
+                                  d_status_out, d_iters, d_active, cold_rounds ? 0 : warm, total_segments, d_order, only_i32, only_u8);
     };
     auto reallocate = [&]() -> int {      // + count of the trajectories it stretched
         int rc_ = uavqp_time_reallocate_device(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
@@ -237,7 +242,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     // 3. outer loop
     int rounds = 0, still = 0;
     for (int rnd = 0; rnd < P.max_rounds; ++rnd) {
-        rc = corridor_solve(rnd > 0 ? 2 : 0);
+        rc = corridor_solve(rnd > 0 ? 2 : 0, rnd > 0 ? (const int32_t*)d_changed : nullptr);
         if (rc != UAVQP_OK) return rc;
         ++rounds;
         rc = reallocate();
@@ -247,7 +252,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     }
     if (still != 0) {
         // cap reached with durations changed by the last re-allocation: one more solve so that the coefficients match d_times
-        rc = corridor_solve(2);
+        rc = corridor_solve(2, (const int32_t*)d_changed);
         if (rc != UAVQP_OK) return rc;
     }
     // 4. check + repair
@@ -289,13 +294,13 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
             const double shrink = (repairs + 1 == P.repair_rounds) ? 0.0 : 0.5;
             hipLaunchKernelGGL(uavqp::pipe_shrink_kernel, dim3(n < ctx->num_cus * 32 ? n : ctx->num_cus * 32), dim3(64), 0, s, n, uni, d_seg_offsets,
                                d_waypoints, d_corr_lo, d_corr_hi, (const uint8_t*)d_flag, shrink);
-            rc = corridor_solve(2);
+            rc = corridor_solve(2, nullptr, (const unsigned char*)d_flag);
             if (rc != UAVQP_OK) break;
             rc = reallocate();
             if (rc != UAVQP_OK) break;
             still = (int)h_cnt->changed;
             if (still > 0) {
-                rc = corridor_solve(2);
+                rc = corridor_solve(2, (const int32_t*)d_changed);
                 if (rc != UAVQP_OK) break;
             }
             ++repairs;
