@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5], help="2: 4096 x 8-segment snap per GPU (headline); 4: 32768 ragged, sharded; 5: 16384 ragged + cloud corridors + time re-allocation pipeline, sharded")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="2: 4096 x 8-segment snap per GPU (headline); 3: 65536 x 16-segment jerk + corridor boxes per GPU (--rows 2: + K = 2 general rows per segment); 4: 32768 ragged, sharded; 5: 16384 ragged + cloud corridors + time re-allocation pipeline, sharded")
+    ap.add_argument("--rows", type=int, default=0, choices=[0, 2], help="config 3: general inequality rows per segment (2 = mid-segment position sample + velocity limit, SURVEY 8-d 'K = 2 mid-segment samples')")
+    ap.add_argument("--no-time-modes", action="store_true", help="config 2: skip the `time_modes` sub-record (the same block on the other time allocation of SURVEY 8-d)")
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU per step (config 2; default 4096) / in total (config 4; default 32768)")
     ap.add_argument("--segments", type=int, default=8)
     ap.add_argument("--order", type=int, default=4, help="4 = min-snap (7th-order), 3 = min-jerk")
@@ -85,6 +87,23 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
+def usable_cores():
+    """(threads to use, note): the physical cores of the host, capped by the CPU-time quota of this container's cgroup (cpu.max).  The
+    GPU boxes of this pool show 256 logical CPUs to a container that may burn 16 CPUs' worth of time per period: 128 pinned threads
+    then deliver what 16 cores deliver (measured, tools/cpu_scaling_probe.py: linear up to 16 threads, flat beyond) -- the all-cores
+    leg of the CPU baseline runs one thread per core it can actually have."""
+    phys = physical_cores()
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except Exception:
+        pass
+    use = min(phys, quota) if quota else phys
+    return use, f"host: {phys} physical cores, {os.cpu_count()} logical; cgroup cpu.max quota: {quota if quota else 'none'} CPUs; threads used: {use}"
+
+
 def cpu_baseline(batch, r, n_sample):
     """OSQP-faithful CPU restatement (oracle/osqp_port.c) timed on this host's cores: one full setup+solve+cleanup per
     axis, exactly the reference's call pattern (test_minimum_jerk.cpp:75,100,125; minimum_control.cpp:164-190), reference
@@ -105,12 +124,18 @@ def cpu_baseline(batch, r, n_sample):
         dts.append(time.perf_counter() - t0)
         passes += 1
     dt1 = float(np.median(dts))
-    cores = physical_cores()
-    oracle.osqp_solve_batch(*args, threads=cores)   # warm-up: thread pool, page faults
+    cores, cores_note = usable_cores()
+    # all cores: the sample is tiled so that every thread gets >= 512 trajectories (about 0.15 s of work) -- thread creation and pinning
+    # (once per pass, oracle/osqp_port.c) must not be what is measured (32 trajectories per thread gave 10 % efficiency)
+    rep = max(1, -(-cores * 512 // n))
+    n_all = n * rep
+    so_all = (np.arange(n_all + 1, dtype=np.int64) * M).astype(np.int32)
+    args_all = (r, so_all, np.tile(batch["waypoints"][:n], (rep, 1, 1)), np.tile(batch["times"][:n], (rep, 1)), np.tile(batch["bc"][:n], (rep, 1, 1, 1)))
+    oracle.osqp_solve_batch(*args_all, threads=cores)   # warm-up: page faults, allocator arenas
     dtn = []
-    for _ in range(7):
+    for _ in range(5):
         t0 = time.perf_counter()
-        oracle.osqp_solve_batch(*args, threads=cores)
+        oracle.osqp_solve_batch(*args_all, threads=cores)
         dtn.append(time.perf_counter() - t0)
     # second, stronger CPU baseline: the exact KKT solve of the same QPs (oracle/qp_oracle.c, binary128 LU:
     # the checker of the parity tests), one core, a smaller sample
@@ -123,8 +148,49 @@ def cpu_baseline(batch, r, n_sample):
             "sample": f"first {n} trajectories of the same batch (M={M}, r={r}); OSQP-port, reference settings "
                       f"(eps 1e-3, max_iter 1000), 3 x (setup+solve+cleanup) per trajectory; median of {passes} passes of {dt1:.2f} s on 1 core; "
                       f"median {int(np.median(iters))} ADMM iterations, {int((st == 1).sum())}/{n} reported solved",
-            "all_cores": {"value": n / float(np.median(dtn)), "cores": cores, "passes_s": [round(x, 4) for x in dtn],
-                          "note": "physical cores, one trajectory per thread; warm-up pass excluded, median of 7"}}
+            "all_cores": {"value": n_all / float(np.median(dtn)), "cores": cores, "passes_s": [round(x, 4) for x in dtn],
+                          "sample": f"the same {n} trajectories tiled {rep} x = {n_all} per pass ({n_all // cores} per thread)",
+                          "parallel_efficiency": (n_all / float(np.median(dtn))) / (cores * n / dt1),
+                          "host": cores_note,
+                          "note": "one pinned thread per usable core, contiguous shares of the sample; warm-up pass excluded, median of 5"}}
+
+
+def cpu_baseline_corridor(batch, r, lo, hi, rows_np, n_sample):
+    """Config 3's CPU leg: the OSQP port with the corridor rows (and the general rows) appended, reference settings, on one core -- the
+    formulation the reference would hand to OSQP (l < u on the interior-waypoint rows of minimum_control.cpp:118-124).  ADMM at
+    eps 1e-3 does not reach the minimiser the device computes; it is the reference's own accuracy."""
+    from oracle import oracle
+    oracle.build()
+    n = min(n_sample, batch["waypoints"].shape[0])
+    M = batch["M"]
+    so = batch["seg_offsets"][: n + 1]
+    kw = dict(corr_lo=lo[:n], corr_hi=hi[:n])
+    if rows_np:
+        tau, drv, rlo, rhi = rows_np
+        kw.update(rows_per_segment=tau.shape[1], row_tau=tau[: n * M], row_deriv=drv[: n * M], row_lo=rlo[: n * M], row_hi=rhi[: n * M])
+    t0 = time.perf_counter()
+    _, st, iters = oracle.osqp_solve_batch(r, so, batch["waypoints"][:n], batch["times"][:n], batch["bc"][:n], threads=1, **kw)
+    dt1 = time.perf_counter() - t0
+    cores, cores_note = usable_cores()
+    rep = max(1, -(-cores * 64 // n))
+    n_all = n * rep
+    tile = lambda x, k: np.tile(np.asarray(x), (rep,) + (1,) * (np.asarray(x).ndim - 1))
+    so_all = (np.arange(n_all + 1, dtype=np.int64) * M).astype(np.int32)
+    kw_all = {k: (tile(v, 0) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    a_all = (r, so_all, tile(batch["waypoints"][:n], 0), tile(batch["times"][:n], 0), tile(batch["bc"][:n], 0))
+    oracle.osqp_solve_batch(*a_all, threads=cores, **kw_all)
+    dtn = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.osqp_solve_batch(*a_all, threads=cores, **kw_all)
+        dtn.append(time.perf_counter() - t0)
+    return {"value": n / dt1, "unit": "trajectories/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} trajectories of the same batch (M={M}, r={r}) with their corridor rows" + (" and general rows" if rows_np else "")
+                      + f"; OSQP-port, reference settings (eps 1e-3, max_iter 1000), 3 x (setup+solve+cleanup) per trajectory; one pass of {dt1:.2f} s on 1 core; "
+                      f"median {int(np.median(iters))} ADMM iterations, {int((st == 1).sum())}/{n} reported solved",
+            "all_cores": {"value": n_all / float(np.median(dtn)), "cores": cores, "passes_s": [round(x, 4) for x in dtn],
+                          "sample": f"the same {n} trajectories tiled {rep} x", "parallel_efficiency": (n_all / float(np.median(dtn))) / (cores * n / dt1),
+                          "host": cores_note}}
 
 
 def measure_traffic(args):
@@ -145,21 +211,21 @@ def measure_traffic(args):
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="uavqp_pmc_", dir="/tmp")
-            cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                   sys.executable, os.path.abspath(__file__), "--inner", "--steps", "40", "--warmup", "2", "--repeats", "1", "--graph", "0",
-                   "--config", str(args.config), "--batch", str(args.batch), "--segments", str(args.segments), "--order", str(args.order),
-                   "--time-mode", args.time_mode, "--variant", str(args.variant), "--pipelined-streams", "0", "--no-allgather"]
+            pm_steps, pm_warm = (6, 1) if args.config == 3 else (40, 2)
+            cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + _child_cmd(args, ["--steps", str(pm_steps), "--warmup", str(pm_warm)])
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "uavqp::solve" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    # one solve kernel per step (configs 2 / 4: the window sort moves 0.5 MB) or every kernel of the step (config 3: prep,
+                    # dual prelude, solve, emission)
+                    if ("uavqp::" if args.config == 3 else "uavqp::solve") in row["Kernel_Name"] and row["Counter_Name"] == ctr:
                         vals.append(float(row["Counter_Value"]))
             shutil.rmtree(d, ignore_errors=True)
             if not vals:
                 return None
-            out[ctr] = float(np.mean(vals)) * 1024.0
+            out[ctr] = (float(np.sum(vals)) / (pm_steps + pm_warm) if args.config == 3 else float(np.mean(vals))) * 1024.0
         return {"bytes": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "fetch_bytes_corrected": 2.0 * out["FETCH_SIZE"],
                 "write_bytes": out["WRITE_SIZE"]}
     except Exception:
@@ -169,7 +235,7 @@ def measure_traffic(args):
 def _child_cmd(args, extra):
     return [sys.executable, os.path.abspath(__file__), "--inner", "--repeats", "1", "--graph", "0", "--config", str(args.config),
             "--batch", str(args.batch), "--segments", str(args.segments), "--order", str(args.order), "--time-mode", args.time_mode,
-            "--variant", str(args.variant), "--pipelined-streams", "0", "--no-allgather"] + extra
+            "--variant", str(args.variant), "--rows", str(args.rows), "--pipelined-streams", "0", "--no-allgather"] + extra
 
 
 def _short(name):
@@ -286,10 +352,18 @@ def main():
     r = args.order
     K = args.steps
     # ------------------------------------------------------------------ workload: this rank's shard, S distinct buffer sets
-    if args.config == 2:
+    if args.config == 3:
+        # BASELINE configs[2]: 65 536 x 16-segment minimum-jerk, corridor boxes of half-width U(0.3, 0.8) m around every interior waypoint
+        #  replacing the waypoint equalities of minimum_control.cpp:34-42,118-124; --rows 2 adds the "K = 2 mid-segment
+        # samples" as general rows (position sample inside the chord +- 0.25 m, velocity limit 3.5 m/s at mid-segment)
+        r = args.order = 3
+        args.segments = 16
+        args.pipelined_streams = 0
+        args.graph = 0     # (the corridor entry sizes its workspace per call; eager launches, as a planner would call it)
+    if args.config in (2, 3):
         M = args.segments
-        B = args.batch if args.batch > 0 else 4096
-        batch = W.uniform_batch(2, B, M, r, time_mode=args.time_mode, seed=W.SEED0 + 2 + 1000 * rank)
+        B = args.batch if args.batch > 0 else (4096 if args.config == 2 else 65536)
+        batch = W.uniform_batch(args.config, B, M, r, time_mode=args.time_mode, seed=W.SEED0 + args.config + 1000 * rank)
         if args.data == "uniform":
             rng = np.random.default_rng(1)
             batch["waypoints"] = rng.uniform(-2, 2, size=batch["waypoints"].shape)
@@ -305,6 +379,24 @@ def main():
         workload = (f"configs[1]: batch of {B} independent {M}-segment order-{2 * r - 1} (r={r}) 3-axis trajectories per GPU, "
                     f"synthetic A*-like waypoints, time allocation '{args.time_mode}'")
         scaling = "weak"
+        if args.config == 3:
+            c_lo, c_hi = W.corridor_boxes(batch, config_index=3)
+            bytes_local += B * 8 * 2 * 3 * (M - 1)                      # corridor rows (3656 B per trajectory in all)
+            rows_np = None
+            if args.rows:
+                K_ = args.rows
+                wpn = np.asarray(batch["waypoints"])
+                tau = np.full((B * M, K_), 0.5)
+                drv = np.tile(np.array([0, 1], dtype=np.int32), (B * M, 1))
+                mid = 0.5 * (wpn[:, :-1] + wpn[:, 1:]).reshape(B * M, 3)
+                rlo, rhi = np.zeros((B * M, K_, 3)), np.zeros((B * M, K_, 3))
+                rlo[:, 0], rhi[:, 0] = mid - 0.25, mid + 0.25
+                rlo[:, 1], rhi[:, 1] = -3.5, 3.5
+                rows_np = (tau, drv, rlo, rhi)
+                bytes_local += B * M * K_ * (8 + 4 + 2 * 3 * 8)
+            workload = (f"configs[2]: batch of {B} independent {M}-segment minimum-jerk (r=3) 3-axis trajectories per GPU, interior waypoints relaxed to "
+                        f"corridor boxes (half-width U(0.3, 0.8) m)" + (f" + {args.rows} general rows per segment (mid-segment position sample, velocity limit)" if args.rows else "")
+                        + f", time allocation '{args.time_mode}'")
     else:
         n_total = args.batch if args.batch > 0 else (32768 if args.config == 4 else 16384)
         full = W.ragged_batch(args.config, n_total, r)            # identical on every rank (seeded)
@@ -337,11 +429,19 @@ def main():
     S = max(1, min(S, 4096))
     up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     d_so = up(h_so) if h_so is not None else None
+    if args.config == 3:
+        set_bytes += 8 * 2 * np.asarray(c_lo).size + (sum(x.nbytes for x in rows_np) if rows_np else 0)
+        S = args.sets if args.sets > 0 else int(INFINITY_CACHE_BYTES // set_bytes) + 2
     sets = []
     for _ in range(S):
         sets.append(dict(wp=up(np.asarray(shard["waypoints"]).reshape(-1, 3)), T=up(np.asarray(shard["times"]).reshape(-1)),
                          bc=up(shard["bc"]), out=torch.zeros(3 * 2 * r * seg_local, dtype=torch.float64, device=dev)))
+        if args.config == 3:
+            sets[-1].update(lo=up(np.asarray(c_lo).reshape(-1, 3)), hi=up(np.asarray(c_hi).reshape(-1, 3)))
+            if rows_np:
+                sets[-1].update(tau=up(rows_np[0]), drv=up(rows_np[1]), rlo=up(rows_np[2]), rhi=up(rows_np[3]))
     d_st = torch.zeros(max(n_local, 1), dtype=torch.int32, device=dev)
+    d_it = torch.zeros(max(n_local, 1), dtype=torch.int32, device=dev)
 
     def make_slot():
         st_ = torch.cuda.Stream(device=dev)
@@ -368,6 +468,13 @@ def main():
                                            out=pipe_state.get("out"))
             pipe_state["out"] = {k: res[k] for k in ("coeff", "status", "corr_lo", "corr_hi", "first_hit")}
             s["out"], pipe_state["status"], pipe_state["res"] = res["coeff"], res["status"], res
+            return
+        if args.config == 3:
+            if args.rows:
+                c.solve_rows_device(r, n_local, uni, mx, None, s["wp"], s["T"], s["bc"], s["lo"], s["hi"], args.rows, s["tau"], s["drv"], s["rlo"], s["rhi"],
+                                    s["out"], d_st, d_it)
+            else:
+                c.solve_corridor_device(r, n_local, uni, mx, None, s["wp"], s["T"], s["bc"], s["lo"], s["hi"], s["out"], d_st, d_it)
             return
         c.solve_batch_device(r, n_local, uni, mx, d_so, s["wp"], s["T"], s["bc"], s["out"], d_st)
 
@@ -430,10 +537,49 @@ def main():
         dt, dt_evt = float(t[0].item()), float(t[1].item())
     if n_local > 0 and args.config == 5:
         assert float((pipe_state["status"] == U.UAVQP_SOLVED).double().mean().item()) > 0.999, "corridor pipeline left trajectories unsolved"
+    elif n_local > 0 and args.config == 3 and args.rows:
+        # (random rows: a few draws have no feasible point and end as UAVQP_MAX_ITER_REACHED with the minimiser of their last regular working set)
+        assert float((d_st[:n_local] == U.UAVQP_SOLVED).double().mean().item()) > 0.99, "rows solve left trajectories unsolved"
     elif n_local > 0:
         assert int((d_st[:n_local] == U.UAVQP_SOLVED).sum().item()) == n_local, "some trajectories were not solved"
     if args.inner:
         return
+
+    # ------------------------------------------------------------------ config 2: the same block on the OTHER time allocation of SURVEY 8-d
+    # (reference: T_i = 1.0, test_minimum_jerk.cpp:65-71; distance: T_i = max(0.3, |dp| / 2 m/s)) -- same kernel, same bytes, other numbers
+    time_modes = None
+    if args.config == 2 and not args.no_time_modes and args.time_mode in ("reference", "distance") and K > 0:
+        other = "reference" if args.time_mode == "distance" else "distance"
+        ob = W.uniform_batch(2, B, M, r, time_mode=other, seed=W.SEED0 + 2 + 1000 * rank)
+        saved = [(s_["wp"].clone(), s_["T"].clone(), s_["bc"].clone()) for s_ in sets]
+        o_wp, o_T, o_bc = up(np.asarray(ob["waypoints"]).reshape(-1, 3)), up(np.asarray(ob["times"]).reshape(-1)), up(ob["bc"])
+        for s_ in sets:
+            s_["wp"].copy_(o_wp); s_["T"].copy_(o_T); s_["bc"].copy_(o_bc)   # in place: the captured graph reads the same addresses
+        tm_w, tm_e = [], []
+        for _ in range(R):
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            block()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            tm_w.append(time.perf_counter() - t0)
+            fence()
+            tm_e.append(e0.elapsed_time(e1) * 1e-3)
+        assert int((d_st[:n_local] == U.UAVQP_SOLVED).sum().item()) == n_local, "some trajectories were not solved (other time allocation)"
+        for s_, (a_, b_, c_) in zip(sets, saved):
+            s_["wp"].copy_(a_); s_["T"].copy_(b_); s_["bc"].copy_(c_)
+        torch.cuda.synchronize()
+        tw, te = float(np.median(tm_w)), float(np.median(tm_e))
+        if use_dist:
+            t = torch.tensor([tw, te], dtype=torch.float64, device=dev if rccl_ok else torch.device("cpu"))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tw, te = float(t[0].item()), float(t[1].item())
+        mk = lambda w_, e_: {"value": world * n_local * K / w_, "ms_per_step": w_ / K * 1e3, "roofline_frac": bytes_local / (e_ / K) / 1e9 / HBM_PEAK_GBS}
+        time_modes = {args.time_mode: mk(dt, dt_evt), other: mk(tw, te),
+                      "note": "the same K-step block, same buffers and graph, on both time allocations of SURVEY.md 8-d (reference: T_i = 1.0 s, "
+                              "test_minimum_jerk.cpp:65-71; distance: T_i = max(0.3, |dp| / 2 m/s)); `value` of the line is the first"}
 
     # ------------------------------------------------------------------ pipelined sub-record: the same K steps dealt to P streams
     pipelined = None
@@ -538,12 +684,14 @@ def main():
         achieved = bytes_local / per_launch_s / 1e9
         n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 4096
         cpu = cpu_baseline(batch, r, n_cpu) if (n_cpu > 0 and world == 1 and args.config == 2) else None
+        if n_cpu > 0 and world == 1 and args.config == 3:
+            cpu = cpu_baseline_corridor(batch, r, c_lo, c_hi, rows_np, min(n_cpu, 1024))
         traffic = measure_traffic(args) if (world == 1 and not args.no_traffic) else None
         # FP64 roof ("report FP64 FLOP/s next to GB/s") and per-kernel view, from counters / traces of child runs
         fp64 = kernels = None
         if world == 1 and not args.no_fp64:
-            prof_steps = 2 if args.config == 5 else 40
-            trace_steps = 2 if args.config == 5 else 1000   # the trace is cheap: enough launches that the average is the steady state
+            prof_steps = 2 if args.config == 5 else (6 if args.config == 3 else 40)
+            trace_steps = 2 if args.config == 5 else (20 if args.config == 3 else 1000)   # the trace is cheap: enough launches that the average is the steady state
             f64 = measure_fp64(args, prof_steps)
             kt = measure_kernel_times(args, trace_steps)
             if f64 and kt:
@@ -556,11 +704,19 @@ def main():
                                     "fp64_tflops": fl / (v["avg_us"] * 1e-6) / 1e12 if v["avg_us"] > 0 else None,
                                     "fp64_frac_of_vector_peak": fl / (v["avg_us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if v["avg_us"] > 0 else None})
                 dom = kernels[0]
-                fp64 = {"kernel": dom["kernel"], "flops_per_launch": dom["fp64_flops_per_launch"], "achieved": dom["fp64_tflops"],
-                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["fp64_frac_of_vector_peak"],
+                step_flops = sum(k_["fp64_flops_per_launch"] * k_["launches_per_step"] for k_ in kernels)
+                # ONE clock per record: `achieved` / `frac` are the step's FP64 work over the SAME HIP-event time per step that
+                # roofline.achieved uses (this process, this box); the traced figure of the dominant kernel alone (child run under
+                # rocprofv3 on the same box, eager launches) is kept next to it, labelled
+                fp64 = {"kernel": dom["kernel"], "flops_per_step": step_flops, "achieved": step_flops / per_launch_s / 1e12,
+                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_flops / per_launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                        "clock": "HIP events around the timed K-step block / K -- the clock of roofline.achieved",
+                        "dominant_kernel_traced": {"flops_per_launch": dom["fp64_flops_per_launch"], "avg_us": dom["avg_us"], "tflops": dom["fp64_tflops"],
+                                                   "frac": dom["fp64_frac_of_vector_peak"],
+                                                   "clock": "rocprofv3 --kernel-trace average of the child run on this box (eager launches)"},
                         "wave_insts_per_launch": f64.get(dom["kernel"], {}).get("wave_insts_per_launch"),
-                        "note": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 wave-instructions x 64 lanes (FMA = 2 FLOP), per launch of the dominant kernel, "
-                                "over its rocprofv3 average duration; issued lane-slots, idle lanes included"}
+                        "note": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 wave-instructions x 64 lanes (FMA = 2 FLOP) of every uavqp kernel of a step; "
+                                "issued lane-slots, idle lanes included"}
         host_e2e = None
         if world == 1 and args.config == 2 and n_cpu > 0:
             # the same batch from HOST pointers (uavqp_solve_batch_host: staging copies over PCIe, solve, copy back, synchronise):
@@ -576,7 +732,8 @@ def main():
             host_e2e = {"value": n_local / float(np.median(ht)), "unit": "trajectories/s", "ms_per_call": float(np.median(ht)) * 1e3,
                         "bytes_over_the_host_link": int(bytes_local), "note": "pageable host buffers in and out, one call per batch, median of 15"}
         out = {
-            "metric": {2: "trajectories/sec (8-seg 7th-order min-snap, 3-axis)", 4: "trajectories/sec (32768 ragged 4-24-seg min-snap, 3-axis, sharded)",
+            "metric": {2: "trajectories/sec (8-seg 7th-order min-snap, 3-axis)",
+                       3: "trajectories/sec (65536 x 16-seg min-jerk with corridor boxes" + (f" + {args.rows} general rows per segment" if args.rows else "") + ", 3-axis)", 4: "trajectories/sec (32768 ragged 4-24-seg min-snap, 3-axis, sharded)",
                        5: "trajectories/sec (16384 ragged min-snap through the SE(3)-corridor + time re-allocation pipeline, sharded)"}[args.config],
             "value": n_step * K / dt,
             "unit": "trajectories/s",
@@ -589,19 +746,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload, "batch_per_gpu": n_local, "segments": args.segments if args.config == 2 else "4-24", "r": r,
+            "config": {"workload": workload, "batch_per_gpu": n_local, "segments": args.segments if args.config in (2, 3) else "4-24", "r": r,
                        "variant": args.variant, "graph": bool(graph is not None), "buffer_sets": S, "buffer_set_bytes": int(set_bytes),
                        "repeats": R, "parallelism": f"shard{world}", "shard_bounds": bounds if world <= 16 else None},
             "timing": {"block_wall_ms_median": dt * 1e3, "block_event_ms_median": dt_evt * 1e3,
                        "block_wall_ms_p10_p90": [float(np.percentile(wall, 10)) * 1e3, float(np.percentile(wall, 90)) * 1e3],
                        "block_wall_ms_min_max": [float(np.min(wall)) * 1e3, float(np.max(wall)) * 1e3], "repeats": R,
                        "note": "K-step block between barrier + synchronize, repeated; value and ms_per_step from the median wall time (MAX over ranks)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
+            # config 5 is a pipeline of ~20 launches with host synchronisation between rounds: a pipeline-wide HBM fraction says nothing
+            #  -- achieved / frac are null there, the per-kernel table (`kernels`) is the content
+            "roofline": {"bound": "hbm", "achieved": achieved if args.config != 5 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if args.config != 5 else None, "traffic": traffic["bytes"] if traffic else None,
                          "traffic_detail": traffic, "algorithmic_bytes_per_launch": int(bytes_local),
                          "kernel_ms": per_launch_s * 1e3,
                          "kernel_ms_is": ("HIP events on the launch stream around the timed K-step block / K (same clock as value; includes the inter-kernel gap)"
-                                          if args.config != 5 else "one pass of the WHOLE pipeline (about 20 launches, host-synchronised between outer rounds), not one kernel"),
+                                          if args.config not in (3, 5) else "one corridor solve = prep + dual prelude + block solve + emission kernels (HIP events around the K-step block / K)" if args.config == 3 else "one pass of the WHOLE pipeline (about 20 launches, host-synchronised between outer rounds), not one kernel"),
                          "working_set_bytes": int(S * set_bytes),
                          "algorithmic_bytes_per_trajectory": bytes_local / max(n_local, 1),
                          "fp64": fp64},
@@ -611,6 +770,12 @@ def main():
             out["kernels"] = kernels   # per-kernel launches, durations and FP64 rates of one step (config 5: the pipeline's own kernels)
         if host_e2e:
             out["host_pointers"] = host_e2e
+        if time_modes:
+            out["time_modes"] = time_modes
+        if args.config == 3:
+            out["corridor"] = {"iterations_mean": float(d_it[:n_local].double().mean().item()), "iterations_max": int(d_it[:n_local].max().item()),
+                               "solved": int((d_st[:n_local] == U.UAVQP_SOLVED).sum().item()), "rows_per_segment": args.rows,
+                               "note": "block solves per (trajectory, axis) problem after the position-space dual prelude (uavqp_settings.corridor_initial_guess = 2)"}
         if pipelined:
             out["pipelined"] = pipelined
         if gather:

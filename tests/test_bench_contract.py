@@ -57,7 +57,7 @@ def test_bench_defaults_follow_the_contract():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert re.search(r'"--gpus", type=int, default=1', src)
     assert re.search(r'"--steps", type=int, default=\d+', src) and re.search(r'"--warmup", type=int, default=\d+', src)
-    assert re.search(r'"--batch", type=int, default=0', src) and "if args.batch > 0 else 4096" in src and re.search(r'"--segments", type=int, default=8', src)
+    assert re.search(r'"--batch", type=int, default=0', src) and "if args.batch > 0 else (4096 if args.config == 2 else 65536)" in src and re.search(r'"--segments", type=int, default=8', src)
     assert re.search(r'"--config", type=int, default=2', src)      # BASELINE.json configs[1]: the configuration the metric is quoted on
     assert re.search(r'"--order", type=int, default=4', src)
     assert "oracle" not in re.sub(r"def cpu_baseline.*?\n\n\n", "", src, flags=re.S).replace("oracle/osqp_port.c", "")  # oracle only in cpu_baseline
