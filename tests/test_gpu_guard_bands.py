@@ -1,0 +1,324 @@
+"""GPU: memory safety of every C-ABI device entry.
+
+Every input and output of a call is carved out of ONE device allocation with sentinel-filled guard bands in front of and behind it;
+after the call every band must still hold its sentinel (no write outside a buffer), and a second run with DIFFERENT band contents
+(all-ones bit pattern = NaN as a double, -1 as an int32 / then zeros) must give bit-identical outputs (no read outside a buffer
+reaches a result).  Shapes that have bitten before or can: lanes without a problem, single-segment and invalid (zero-segment)
+trajectories, empty batches, trajectories masked out of a re-solve, warm starts 1 / 2 (the round-3 fault: a lane without a problem
+indexing with M = 0 in front of the coefficient buffer -- this test fails on that revision), shard views whose base is in the middle
+of an allocation.  A second test puts every buffer at the very END of its own hipMalloc allocation in a child process: a read or
+write behind a buffer then has a chance to fault instead of landing in a neighbour."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import uav_motion_planning_amd as U  # noqa: E402
+from uav_motion_planning_amd import workloads as W  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+PAD = 4096
+
+
+class Arena:
+    """Buffers carved out of one device allocation, PAD sentinel bytes on both sides of each."""
+
+    def __init__(self, fill, nbytes=96 << 20):
+        import torch
+        self.t = torch
+        self.dev = torch.device("cuda", 0)
+        self.fill = fill
+        self.raw = torch.full((nbytes,), fill, dtype=torch.uint8, device=self.dev)
+        self.off = 0
+        self.bands = []
+
+    def put(self, arr, misalign=0):
+        """Copy `arr` (numpy) in; returns a device view of its dtype / shape.  misalign: extra byte offset (multiple of the item size)."""
+        t = self.t
+        a = np.ascontiguousarray(arr)
+        nb = a.nbytes
+        start = (self.off + PAD + 255) // 256 * 256 + misalign
+        end = start + nb
+        self.bands.append((self.off, start))
+        self.off = end
+        assert self.off + PAD <= self.raw.numel(), "arena too small"
+        view = self.raw[start:end]
+        if nb:
+            view.copy_(t.from_numpy(a.view(np.uint8).reshape(-1)).to(self.dev))
+        td = {np.dtype("float64"): t.float64, np.dtype("int32"): t.int32, np.dtype("int64"): t.int64, np.dtype("uint8"): t.uint8}[a.dtype]
+        return view.view(td).reshape(a.shape) if nb else t.zeros(a.shape, dtype=td, device=self.dev)
+
+    def out(self, shape, dtype=np.float64, misalign=0):
+        return self.put(np.zeros(shape, dtype=dtype), misalign)
+
+    def check(self, what):
+        self.t.cuda.synchronize()
+        self.bands.append((self.off, self.off + PAD))
+        for a, b in self.bands:
+            seg = self.raw[a:b]
+            assert bool((seg == self.fill).all()), f"{what}: guard band [{a}, {b}) was written"
+        self.bands.pop()
+
+
+def _both_fills(run):
+    """run(arena) -> dict of output tensors; executed with NaN-patterned and zero guard bands: bands intact, outputs identical."""
+    res = []
+    for fill in (0xFF, 0x00):
+        ar = Arena(fill)
+        out = run(ar)
+        ar.check(run.__name__)
+        res.append({k: v.detach().cpu().numpy().copy() for k, v in out.items()})
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k], equal_nan=True), f"{run.__name__}: output {k!r} depends on what lies outside the buffers"
+    return res[0]
+
+
+def _ragged_with_edge_cases(r, n, seed):
+    """Ragged batch whose first trajectories have 1, 2, 3 segments and whose LAST has 1 (edge of every array); kino-style roll-outs."""
+    b = W.ragged_batch(4, n, r, m_lo=1, m_hi=24, seed=seed)
+    return b
+
+
+def test_batch_solve_uniform_and_ragged(gpu_ctx):
+    for r, M, n in ((4, 8, 37), (3, 16, 5), (4, 7, 1), (4, 14, 3)):      # partial tiles, specialised and generic shapes
+        b = W.uniform_batch(2, n, M, r, time_mode="distance")
+
+        def run_uniform(ar):
+            wp, T, bc = ar.put(b["waypoints"].reshape(-1, 3), 8), ar.put(b["times"].reshape(-1), 8), ar.put(b["bc"])
+            out, st = ar.out(n * 3 * M * 2 * r), ar.out(n, np.int32)
+            gpu_ctx.solve_batch_device(r, n, M, M, None, wp, T, bc, out, st)
+            return {"out": out, "st": st}
+        got = _both_fills(run_uniform)
+        assert np.all(got["st"] == U.UAVQP_SOLVED)
+    for r in (3, 4):
+        n = 77
+        b = _ragged_with_edge_cases(r, n, 31 + r)
+        so = b["seg_offsets"].copy()
+
+        def run_ragged(ar):
+            d_so, wp, T, bc = ar.put(so), ar.put(b["waypoints"]), ar.put(b["times"]), ar.put(b["bc"])
+            out, st = ar.out(int(so[-1]) * 6 * r), ar.out(n, np.int32)
+            gpu_ctx.solve_batch_device(r, n, 0, 24, d_so, wp, T, bc, out, st)
+            gpu_ctx.solve_batch_device(r, 0, 0, 24, d_so, wp, T, bc, out, st)      # empty batch: nothing is touched
+            return {"out": out, "st": st}
+        got = _both_fills(run_ragged)
+        assert np.all(got["st"] == U.UAVQP_SOLVED)
+
+
+def test_shard_views_with_non_zero_base(gpu_ctx):
+    """The solve of one rank's shard: views of the global arrays that start in the middle of an allocation (what every rank > 0 of
+    the 8-GPU run passes), results written into the middle of the global coefficient buffer."""
+    from uav_motion_planning_amd import distributed as D
+    r, n = 4, 96
+    b = W.ragged_batch(4, n, r, m_lo=1, m_hi=24, seed=5)
+    so = np.asarray(b["seg_offsets"], dtype=np.int64)
+    bounds = D.shard_bounds_ragged(so, 3)
+
+    def run_shards(ar):
+        wp, T, bc = ar.put(b["waypoints"]), ar.put(b["times"]), ar.put(b["bc"])
+        out, st = ar.out(int(so[-1]) * 6 * r), ar.out(n, np.int32)
+        for g in range(3):
+            lo_, hi_ = bounds[g], bounds[g + 1]
+            if hi_ == lo_:
+                continue
+            so_l = ar.put((so[lo_:hi_ + 1] - so[lo_]).astype(np.int32))
+            gpu_ctx.solve_batch_device(r, hi_ - lo_, 0, 24, so_l, wp[so[lo_] + lo_:], T[so[lo_]:], bc[lo_:], out[6 * r * so[lo_]:], st[lo_:])
+        return {"out": out, "st": st}
+    got = _both_fills(run_shards)
+    assert np.all(got["st"] == U.UAVQP_SOLVED)
+    ref, st = gpu_ctx.solve_batch_host(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"])
+    assert np.max(np.abs(got["out"] - ref)) <= 1e-9 * np.max(np.abs(ref))     # (a shard may take another lane layout than the whole batch)
+
+
+@pytest.mark.parametrize("r,guess", [(3, 2), (4, 2), (4, 1), (3, 0)])
+def test_corridor_cold_warm_and_masked(gpu_ctx, r, guess):
+    n = 45      # not a multiple of the 32 problems of a wave, of the 8 / 4 trajectories of a dual-prelude batch
+    b = W.ragged_batch(5, n, r, m_lo=1, m_hi=24, seed=77 + r)
+    so = b["seg_offsets"].copy()
+    lo, hi = W.corridor_boxes(b, config_index=5)
+    nco = int(so[-1]) * 6 * r
+    gpu_ctx.set_settings(corridor_initial_guess=guess)
+    try:
+        def run_corridor(ar):
+            d_so, wp, T, bc = ar.put(so), ar.put(b["waypoints"]), ar.put(b["times"]), ar.put(b["bc"])
+            d_lo, d_hi = ar.put(lo), ar.put(hi)
+            out, st, it, act = ar.out(nco), ar.out(n, np.int32), ar.out(n, np.int32), ar.out((n, 3, 2), np.int64)
+            gpu_ctx.solve_corridor_device(r, n, 0, 24, d_so, wp, T, bc, d_lo, d_hi, out, st, it, act, 0)
+            cold = out.clone()
+            gpu_ctx.solve_corridor_device(r, n, 0, 24, d_so, wp, T, bc, d_lo, d_hi, out, st, it, act, 1)
+            warm1 = out.clone()
+            T.mul_(1.07)
+            gpu_ctx.solve_corridor_device(r, n, 0, 24, d_so, wp, T, bc, d_lo, d_hi, out, st, it, act, 2)   # reads `out` as its starting point
+            gpu_ctx.solve_corridor_device(r, 0, 0, 24, d_so, wp, T, bc, d_lo, d_hi, out, st, it, act, 0)   # empty batch
+            return {"cold": cold, "warm1": warm1, "out": out, "st": st, "it": it, "act": act}
+        got = _both_fills(run_corridor)
+        assert np.all((got["st"] == U.UAVQP_SOLVED) | (got["st"] == U.UAVQP_MAX_ITER_REACHED))
+        assert np.array_equal(got["cold"], got["warm1"])
+
+        M = 16
+        bu = W.uniform_batch(3, 19, M, r, time_mode="distance")
+        lo_u, hi_u = W.corridor_boxes(bu, config_index=3)
+
+        def run_corridor_uniform(ar):
+            wp, T, bc = ar.put(bu["waypoints"].reshape(-1, 3)), ar.put(bu["times"].reshape(-1)), ar.put(bu["bc"])
+            d_lo, d_hi = ar.put(lo_u.reshape(-1, 3)), ar.put(hi_u.reshape(-1, 3))
+            out, st = ar.out(19 * 3 * M * 2 * r), ar.out(19, np.int32)
+            gpu_ctx.solve_corridor_device(r, 19, M, M, None, wp, T, bc, d_lo, d_hi, out, st)
+            return {"out": out, "st": st}
+        got = _both_fills(run_corridor_uniform)
+        assert np.all(got["st"] == U.UAVQP_SOLVED)
+    finally:
+        gpu_ctx.set_settings(corridor_initial_guess=2)
+
+
+def test_corridor_with_invalid_and_degenerate_trajectories(gpu_ctx):
+    """Zero-segment and negative-duration trajectories in the middle and at both ends of the batch: flagged, nothing outside the buffers
+    touched, the valid ones solved as if the others were not there."""
+    r, n = 3, 21
+    b = W.ragged_batch(5, n, r, m_lo=2, m_hi=17, seed=3)
+    so = b["seg_offsets"].copy()
+    T = b["times"].copy()
+    bad = [0, 9, n - 1]
+    for k in bad:
+        T[so[k]] = -1.0
+    lo, hi = W.corridor_boxes(b, config_index=5)
+
+    def run_invalid(ar):
+        d_so, wp, dT, bc, d_lo, d_hi = ar.put(so), ar.put(b["waypoints"]), ar.put(T), ar.put(b["bc"]), ar.put(lo), ar.put(hi)
+        out, st = ar.out(int(so[-1]) * 6 * r), ar.out(n, np.int32)
+        gpu_ctx.solve_corridor_device(r, n, 0, 17, d_so, wp, dT, bc, d_lo, d_hi, out, st)
+        return {"out": out, "st": st}
+    got = _both_fills(run_invalid)
+    assert np.all(got["st"][bad] == U.UAVQP_INVALID_INPUT)
+    good = np.setdiff1d(np.arange(n), bad)
+    assert np.all(got["st"][good] == U.UAVQP_SOLVED)
+    for k in bad:
+        assert np.all(got["out"][6 * r * so[k]:6 * r * so[k + 1]] == 0.0)       # left untouched
+
+
+def test_rows_eval_check_length_realloc_cloud(gpu_ctx):
+    r, n = 4, 29
+    b = W.ragged_batch(4, n, r, m_lo=1, m_hi=12, seed=8)
+    so = b["seg_offsets"].copy()
+    tot = int(so[-1])
+    lo, hi = W.corridor_boxes(b, config_index=5)
+    K = 2
+    wp = np.asarray(b["waypoints"])
+    mid = np.concatenate([0.5 * (wp[so[k] + k:so[k + 1] + k] + wp[so[k] + k + 1:so[k + 1] + k + 1]) for k in range(n)])
+    tau = np.full((tot, K), 0.5)
+    drv = np.tile(np.array([0, 1], dtype=np.int32), (tot, 1))
+    rlo, rhi = np.zeros((tot, K, 3)), np.zeros((tot, K, 3))
+    rlo[:, 0], rhi[:, 0] = mid - 2.0, mid + 2.0
+    rlo[:, 1], rhi[:, 1] = -30.0, 30.0
+    obs = W.pillar_cloud(5, n_pillars=6, resolution=0.4)
+    ns = 17
+
+    def run_aux(ar):
+        d_so, dwp, dT, bc, d_lo, d_hi = ar.put(so), ar.put(wp), ar.put(b["times"]), ar.put(b["bc"]), ar.put(lo), ar.put(hi)
+        d_tau, d_drv, d_rlo, d_rhi = ar.put(tau), ar.put(drv), ar.put(rlo), ar.put(rhi)
+        d_obs = ar.put(obs)
+        out, st, it = ar.out(tot * 6 * r), ar.out(n, np.int32), ar.out(n, np.int32)
+        gpu_ctx.solve_rows_device(r, n, 0, 12, d_so, dwp, dT, bc, d_lo, d_hi, K, d_tau, d_drv, d_rlo, d_rhi, out, st, it)
+        rows_out = out.clone()
+        gpu_ctx.solve_batch_device(r, n, 0, 12, d_so, dwp, dT, bc, out, st)
+        ev = ar.out(n * ns * 9)
+        gpu_ctx.eval_batch_device(r, n, 0, d_so, dT, out, ns, 0.0, 0.21, 7, ev)
+        fh, fl = ar.out(n, np.int32), ar.out(n * ns, np.uint8)
+        gpu_ctx.ellipsoid_check_device(r, n, 0, d_so, dT, out, ns, 0.0, 0.21, d_obs, obs.shape[0], 0.4, 0.1, fh, fl)
+        ln, mv, cnt = ar.out(n), ar.out(n), ar.out(n, np.int32)
+        gpu_ctx.traj_length_device(r, n, 0, d_so, dT, out, 0.05, ln, mv, cnt)
+        c_lo, c_hi, clr = ar.out((tot + n, 3)), ar.out((tot + n, 3)), ar.out(tot + n)
+        gpu_ctx.corridor_from_cloud_device(r, n, 0, d_so, tot + n, dwp, dT, out, d_obs, obs.shape[0], 0.4, 0.1, 0.8, c_lo, c_hi, clr)
+        ch = ar.out(n, np.int32)
+        T2 = ar.put(b["times"])
+        gpu_ctx.time_reallocate_device(r, n, 0, d_so, T2, out, 1.0, 2.0, 8, 1.5, ch)
+        return {"rows": rows_out, "ev": ev, "fh": fh, "fl": fl, "ln": ln, "mv": mv, "cnt": cnt, "c_lo": c_lo, "c_hi": c_hi, "clr": clr, "T2": T2, "ch": ch}
+    _both_fills(run_aux)
+
+
+def test_pipeline_entry(gpu_ctx):
+    r, n = 4, 70
+    b = W.ragged_batch(5, n, r, m_lo=2, m_hi=24, seed=12)
+    so = b["seg_offsets"].copy()
+    tot = int(so[-1])
+    obs = W.pillar_cloud(5, n_pillars=20, resolution=0.3)
+
+    def run_pipeline(ar):
+        d_so, wp, T, bc, d_obs = ar.put(so), ar.put(b["waypoints"]), ar.put(b["times"]), ar.put(b["bc"]), ar.put(obs)
+        out, st = ar.out(tot * 6 * r), ar.out(n, np.int32)
+        c_lo, c_hi, fh = ar.out((tot + n, 3)), ar.out((tot + n, 3)), ar.out(n, np.int32)
+        gpu_ctx.corridor_pipeline_device(r, n, 0, 24, tot, d_so, wp, T, bc, d_obs, obs.shape[0], out, st, c_lo, c_hi, fh, None,
+                                         v_max=3.0, a_max=6.0, repair_rounds=2)
+        return {"out": out, "st": st, "c_lo": c_lo, "c_hi": c_hi, "fh": fh, "T": T}
+    _both_fills(run_pipeline)
+
+
+_CHILD = r'''
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import uav_motion_planning_amd as U
+from uav_motion_planning_amd import workloads as W
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+PAGE = 2 << 20
+
+WHERE = "end"
+
+def at_end(arr):
+    """Device copy of arr that ENDS where its own allocation ends (the allocation is a whole number of 2 MiB pages) -- or, second pass,
+    that STARTS where its allocation starts (the round-3 fault was a read in FRONT of a buffer that happened to start an allocation)."""
+    a = np.ascontiguousarray(arr)
+    nb = max(a.nbytes, 8)
+    size = (nb + PAGE - 1) // PAGE * PAGE
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), size) == 0
+    ptr = p.value + size - (nb + 15) // 16 * 16 if WHERE == "end" else p.value
+    if a.nbytes:
+        assert hip.hipMemcpy(ptr, a.ctypes.data, a.nbytes, 1) == 0
+    return ptr
+
+def back(ptr, shape, dtype):
+    out = np.zeros(shape, dtype=dtype)
+    assert hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0
+    return out
+
+with U.Context(0) as ctx:
+  for WHERE in ("end", "start"):
+    for r in (3, 4):
+        n = 45
+        b = W.ragged_batch(5, n, r, m_lo=1, m_hi=24, seed=77 + r)
+        so = b["seg_offsets"]
+        lo, hi = W.corridor_boxes(b, config_index=5)
+        nco = int(so[-1]) * 6 * r
+        d_so, wp, T, bc, d_lo, d_hi = [at_end(x) for x in (so, b["waypoints"], b["times"], b["bc"], lo, hi)]
+        out, st, it, act = at_end(np.zeros(nco)), at_end(np.zeros(n, np.int32)), at_end(np.zeros(n, np.int32)), at_end(np.zeros((n, 3, 2), np.int64))
+        ctx.solve_batch_device(r, n, 0, 24, d_so, wp, T, bc, out, st)
+        ctx.synchronize()
+        ref, _ = ctx.solve_batch_host(r, so, b["waypoints"], b["times"], b["bc"])
+        assert np.array_equal(back(out, nco, np.float64), ref)
+        for warm in (0, 1, 2):
+            ctx.solve_corridor_device(r, n, 0, 24, d_so, wp, T, bc, d_lo, d_hi, out, st, it, act, warm)
+            ctx.synchronize()
+        s = back(st, n, np.int32)
+        assert np.all((s == U.UAVQP_SOLVED) | (s == U.UAVQP_MAX_ITER_REACHED)), s
+    M, n = 8, 4099
+    b = W.uniform_batch(2, n, M, 4, time_mode="distance")
+    wp, T, bc = at_end(b["waypoints"]), at_end(b["times"]), at_end(b["bc"])
+    out, st = at_end(np.zeros(n * 3 * M * 8)), at_end(np.zeros(n, np.int32))
+    ctx.solve_batch_device(4, n, M, M, None, wp, T, bc, out, st)
+    ctx.synchronize()
+    assert np.all(back(st, n, np.int32) == U.UAVQP_SOLVED)
+print("END-OF-ALLOCATION OK")
+'''
+
+
+def test_buffers_at_the_end_of_their_allocations():
+    """Child process (a fault kills it, not pytest): every buffer ends where its own hipMalloc allocation ends."""
+    p = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "END-OF-ALLOCATION OK" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
