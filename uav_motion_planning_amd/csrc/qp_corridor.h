@@ -56,6 +56,7 @@ struct CorridorArgs {
     unsigned long long* guess;     // [n_traj][3][2] cold start: the closed-form starting set of corridor_prep_kernel (may be null)
     const int32_t* only_i32;       // optional masks of an outer loop (uavqp_pipeline.h): when either is given, only the trajectories with a non-zero
     const unsigned char* only_u8;  // entry in one of them take part; the others keep their coefficients, status, iteration count and working set
+    const int* n_active;           // with a mask: `order` lists only the trajectories that take part, *n_active of them (compact_order_kernel); null: all n_traj
     int guess_closed_form;         // 1: corridor_prep_kernel fills `guess` with the closed-form set; 0: it only zeroes it (corridor_dual_kernel, qp_corridor_dual.h, writes it)
 #ifdef UAVQP_DUAL_DEBUG
     double* dbg;                   // debug build only (tools/corridor_dual_gpu_probe.py): G, unconstrained minimisers, trip counts of the first trajectories
@@ -107,6 +108,51 @@ __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
 __device__ __forceinline__ bool corridor_takes_part(const int32_t* only_i32, const unsigned char* only_u8, int b) {
     if (!only_i32 && !only_u8) return true;
     return (only_i32 && only_i32[b] != 0) || (only_u8 && only_u8[b] != 0);
+}
+// Dealing order of a masked re-solve: the entries of `order` (null: 0, 1, 2, ...) whose trajectory takes part, in the same sequence (the
+// order is by segment count: waves keep trajectories of similar length), and their number.  One workgroup: a block scan over n_traj flags.
+__global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __restrict__ order, int n_traj, const int32_t* __restrict__ only_i32,
+                                                             const unsigned char* __restrict__ only_u8, int32_t* __restrict__ out, int* __restrict__ n_out) {
+    // wave w takes the contiguous slice [w per, (w + 1) per) in sub-chunks of 64 (all loads of a lane in flight together: two round trips
+    // per pass of 16 sub-chunks, not one per element), ranks by ballot; the 16 wave totals are scanned through LDS
+    __shared__ int s_tot[16];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = ((n_traj + 15) / 16 + 63) / 64 * 64, w0 = w * per, w1 = min(w0 + per, n_traj);
+    constexpr int CH = 16;
+    int tot = 0;
+    for (int pass = 0; pass < 2; ++pass) {      // pass 0: count, pass 1: write
+        int base = 0;
+        if (pass == 1) {
+            for (int k = 0; k < w; ++k) base += s_tot[k];
+        }
+        for (int c0 = w0; c0 < w1; c0 += 64 * CH) {
+            int bidx[CH];
+            bool keep[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int i = c0 + 64 * c + lane;
+                bidx[c] = i < w1 ? (order ? order[i] : i) : -1;
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) keep[c] = bidx[c] >= 0 && corridor_takes_part(only_i32, only_u8, bidx[c]);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const unsigned long long m = __ballot(keep[c]);
+                if (pass == 1 && keep[c]) out[base + __popcll(m & ((1ull << lane) - 1ull))] = bidx[c];
+                base += __popcll(m);
+            }
+        }
+        if (pass == 0) {
+            tot = base;
+            if (lane == 0) s_tot[w] = tot;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        int all = 0;
+        for (int k = 0; k < 16; ++k) all += s_tot[k];
+        *n_out = all;
+    }
 }
 __global__ void corridor_reset_kernel(int32_t* status, int32_t* iters, int n, const int32_t* only_i32, const unsigned char* only_u8) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,7 +398,7 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
         }
     };
 
-    const long long total = (long long)a.n_traj * 3;
+    const long long total = (long long)(a.n_active ? *a.n_active : a.n_traj) * 3;
     bool queue_empty = false;
     UAVQP_CT_DECL
 

@@ -86,13 +86,12 @@ constexpr int corridor_dual_lds_doubles(int R, int L, int NRW) {
 // One group of L lanes per trajectory; the block handles 64 / L trajectories at a time, grid-stride over the batch in the dealing
 // order of the solve kernel (a.order, longest first), so that the trajectories of a wave are of similar length.
 template <int R, int L, int NRW>
-__global__ __launch_bounds__(64, (NRW <= 24 ? 2 : 1)) void corridor_dual_kernel(CorridorArgs a, int n_lo, int max_trips_extra) {
+__device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_lo, int max_trips_extra, double* s_all, int block, int n_blocks) {
     constexpr int ND = R - 1, NG = 64 / L, NE = R * (R + 1) / 2, LOG2L = (L == 16) ? 4 : 3;
     constexpr int RS = corridor_dual_slot(R, NRW), CBS = NRW + 2;
     constexpr int O_CB = NRW * RS, O_SC = O_CB + 2 * CBS, GRP = corridor_dual_lds_doubles(R, L, NRW);
     static_assert(NRW % 2 == 0 && NRW <= 2 * L && NRW <= 32, "rows: even, at most two columns per lane, codes are 5 bits");
     static_assert(O_CB % 2 == 0 && GRP % 2 == 0 && RS % 2 == 0, "16-byte aligned rows");
-    __shared__ __attribute__((aligned(16))) double s_all[NG * GRP];
     using Inv = SmallLDL<R>;
     const int lane = threadIdx.x, l = lane & (L - 1), grp = lane >> LOG2L;
     double* const sg = s_all + grp * GRP;
@@ -104,11 +103,12 @@ __global__ __launch_bounds__(64, (NRW <= 24 ? 2 : 1)) void corridor_dual_kernel(
     const int crd[2] = {cidx[0] < NRW ? cidx[0] : NRW, cidx[1] < NRW ? cidx[1] : NRW};   // row of the column buffer a lane reads (NRW: the zero)
     const int crow[2] = {min(cidx[0], NRW - 1), min(cidx[1], NRW - 1)};    // clamped row of G
 
-    const long long n_batches = ((long long)a.n_traj + NG - 1) / NG;
-    for (long long bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
+    const int n_eff = a.n_active ? *a.n_active : a.n_traj;     // (a masked re-solve deals only the trajectories that take part)
+    const long long n_batches = ((long long)n_eff + NG - 1) / NG;
+    for (long long bt = block; bt < n_batches; bt += n_blocks) {
         // ---------------- the group's trajectory ----------------
         const long long bq = bt * NG + grp;
-        const bool have = bq < a.n_traj;
+        const bool have = bq < n_eff;
         const int b = have ? (a.order ? a.order[bq] : (int)bq) : 0;
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
@@ -546,6 +546,26 @@ __global__ __launch_bounds__(64, (NRW <= 24 ? 2 : 1)) void corridor_dual_kernel(
         }
         }
     }
+}
+
+template <int R, int L, int NRW>
+__global__ __launch_bounds__(64, (NRW <= 24 ? 2 : 1)) void corridor_dual_kernel(CorridorArgs a, int n_lo, int max_trips_extra) {
+    __shared__ __attribute__((aligned(16))) double s_all[(64 / L) * corridor_dual_lds_doubles(R, L, NRW)];
+    corridor_dual_body<R, L, NRW>(a, n_lo, max_trips_extra, s_all, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Batches of mixed lengths (up to 25 segments): ONE launch whose first `split` blocks are the 8-lane groups (trajectories of up to 17
+// segments), the others whole DPP rows with 24 tableau rows (18 to 25 segments).  A wave of either shape spends its time in
+// dependent chains (one batch of a ragged config-5 solve per wave: the launch lasts as long as ONE batch), so the two shapes
+// overlap instead of queueing behind each other as two launches.
+constexpr int corridor_dual_mixed_lds(int R) {
+    return 8 * corridor_dual_lds_doubles(R, 8, 16) > 4 * corridor_dual_lds_doubles(R, 16, 24) ? 8 * corridor_dual_lds_doubles(R, 8, 16) : 4 * corridor_dual_lds_doubles(R, 16, 24);
+}
+template <int R>
+__global__ __launch_bounds__(64, 2) void corridor_dual_mixed_kernel(CorridorArgs a, int split, int max_trips_extra) {
+    __shared__ __attribute__((aligned(16))) double s_all[corridor_dual_mixed_lds(R)];
+    if ((int)blockIdx.x < split) corridor_dual_body<R, 8, 16>(a, 1, max_trips_extra, s_all, (int)blockIdx.x, split);
+    else corridor_dual_body<R, 16, 24>(a, 17, max_trips_extra, s_all, (int)blockIdx.x - split, (int)gridDim.x - split);
 }
 
 }  // namespace uavqp

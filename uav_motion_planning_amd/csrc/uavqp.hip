@@ -1380,7 +1380,9 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     const size_t b_state = sizeof(double) * (size_t)ws_knots * F * (size_t)grid * 64;
     const bool guess = gmode != 0;     // cold start from a starting set (closed form: prep kernel; dual method: corridor_dual_kernel)
     const size_t b_guess = guess ? align256(sizeof(unsigned long long) * 6 * (size_t)n_traj) : 0;
-    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state + b_guess);
+    const bool masked = d_only_i32 || d_only_u8;
+    const size_t b_compact = masked ? align256(sizeof(int32_t) * (size_t)n_traj) + 256 : 0;   // compacted dealing order + its length
+    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state + b_guess + b_compact);
     if (rc != UAVQP_OK) return rc;
     a.guess = guess ? (unsigned long long*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order + b_state) : nullptr;
     a.coeff = d_coeff_out;
@@ -1394,6 +1396,14 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     if (deal_by_length) {
         rc = make_length_order(ctx, d_seg_offsets, n_traj, (char*)ctx->ws + b_xsol + b_queue + b_desc, &a.order);
         if (rc != UAVQP_OK) return rc;
+    }
+    a.n_active = nullptr;
+    if (masked) {
+        int32_t* d_compact = (int32_t*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order + b_state + b_guess);
+        int* d_n_active = (int*)((char*)d_compact + align256(sizeof(int32_t) * (size_t)n_traj));
+        hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.order, n_traj, d_only_i32, d_only_u8, d_compact, d_n_active);
+        a.order = d_compact;
+        a.n_active = d_n_active;
     }
 #ifdef UAVQP_DUAL_DEBUG
     {
@@ -1437,8 +1447,21 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
         };
         const int nvar = Mmax - 1;
         const bool mixed = uniform_segments == 0;
-        if (nvar <= 16 || mixed) launch_dual(8, 16, 1);
-        if (nvar > 16) launch_dual(16, nvar <= 24 ? 24 : 32, mixed ? 17 : 1);
+        if (mixed && nvar > 16 && nvar <= 24) {
+            // both shapes in one launch (corridor_dual_mixed_kernel): blocks [0, split) the 8-lane groups, the rest whole rows
+            const int lds_b = 8 * uavqp::corridor_dual_mixed_lds(r);
+            int wpc_d = (160 * 1024) / lds_b;
+            if (wpc_d > 8) wpc_d = 8;
+            const long long cap = (long long)ctx->num_cus * wpc_d;
+            long long g8 = ((long long)n_traj + 7) / 8, g16 = ((long long)n_traj + 3) / 4;
+            if (g8 > cap / 2) g8 = cap / 2;
+            if (g16 > cap - g8) g16 = cap - g8;
+            if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_mixed_kernel<3>), dim3((unsigned)(g8 + g16)), dim3(64), 0, ctx->stream, a, (int)g8, 0);
+            else hipLaunchKernelGGL((uavqp::corridor_dual_mixed_kernel<4>), dim3((unsigned)(g8 + g16)), dim3(64), 0, ctx->stream, a, (int)g8, 0);
+        } else {
+            if (nvar <= 16 || mixed) launch_dual(8, 16, 1);
+            if (nvar > 16) launch_dual(16, nvar <= 24 ? 24 : 32, mixed ? 17 : 1);
+        }
     }
     if (r == 3) {
         if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
