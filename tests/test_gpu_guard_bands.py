@@ -322,3 +322,23 @@ def test_buffers_at_the_end_of_their_allocations():
     """Child process (a fault kills it, not pytest): every buffer ends where its own hipMalloc allocation ends."""
     p = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "END-OF-ALLOCATION OK" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+
+
+def test_pipeline_rejects_a_wrong_segment_total(gpu_ctx):
+    """uavqp_corridor_pipeline_device sizes its workspaces from the caller's total_segments: a value that does not match the CSR
+    offsets on the device is refused before anything is launched."""
+    import torch
+    r, n = 4, 20
+    b = W.ragged_batch(5, n, r, m_lo=2, m_hi=12, seed=2)
+    so = b["seg_offsets"]
+    tot = int(so[-1])
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    obs = W.pillar_cloud(5, n_pillars=4, resolution=0.5)
+    args = (up(so), up(b["waypoints"]), up(b["times"]), up(b["bc"]), up(obs), obs.shape[0], torch.zeros(tot * 6 * r, dtype=torch.float64, device=dev),
+            torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros((tot + n, 3), dtype=torch.float64, device=dev),
+            torch.zeros((tot + n, 3), dtype=torch.float64, device=dev))
+    with pytest.raises(U.UavqpError):
+        gpu_ctx.corridor_pipeline_device(r, n, 0, 12, tot - 3, *args)
+    res = gpu_ctx.corridor_pipeline_device(r, n, 0, 12, tot, *args)
+    assert res["unsolved"] == 0

@@ -295,3 +295,58 @@ def test_python_traj_optimizer_facade_with_rows():
     assert (np.abs(np.abs(v1[seg_solved]) - lim[seg_solved]) < 1e-7).sum() > 10      # the rows bind
     opt.setRows(0)
     assert opt.solve() and np.allclose(vel_mid(opt), v0, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("r,M,K", [(3, 16, 2), (4, 10, 2), (3, 7, 1)])
+def test_pair_and_one_lane_rows_kernels_take_the_same_path(gpu_ctx, r, M, K):
+    """uavqp_settings.rows_lanes_per_problem: the pair kernel (default, qp_rows2.h) and the one-lane kernel kept as its cross-check
+    partner (qp_rows.h) are the same method -- statuses, iteration counts and working sets must be identical problem by problem,
+    coefficients to rounding (the A/B existed only as tools/rows_ab.py and could rot)."""
+    n = 96
+    b = W.uniform_batch(3, n, M, r, time_mode="distance")
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    tau, drv, rlo, rhi = _rows_problem(b, M, K, 0.25, 3.5, n)
+    res = {}
+    try:
+        for lanes in (2, 1):
+            gpu_ctx.set_settings(rows_lanes_per_problem=lanes)
+            res[lanes] = run_rows(gpu_ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, M)
+    finally:
+        gpu_ctx.set_settings(rows_lanes_per_problem=0)
+    assert np.array_equal(res[1][1], res[2][1]) and np.array_equal(res[1][2], res[2][2])
+    ok = res[2][1] == U.UAVQP_SOLVED
+    assert ok.mean() > 0.9 and np.array_equal(res[1][3][ok], res[2][3][ok])
+    assert np.max(np.abs(res[1][0] - res[2][0])) <= 1e-9 * np.max(np.abs(res[2][0]))
+
+
+def test_corridor_tail_shape_changes_the_launch_not_the_result(gpu_ctx):
+    """uavqp_settings.corridor_tail_shape (two waves per CU with twice the sweep state on chip for small batches of long r = 4
+    problems): bit-identical coefficients, statuses, iteration counts and working sets with and without it; with the primal
+    method from its closed-form set, where the solve kernel iterates (the default cold start leaves it one verifying solve)."""
+    import torch
+    r, n = 4, 512
+    b = W.ragged_batch(5, n, r, m_lo=12, m_hi=24)
+    so = b["seg_offsets"]
+    lo, hi = W.corridor_boxes(b, config_index=5)
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_so, d_wp, d_T, d_bc, d_lo, d_hi = up(so), up(b["waypoints"]), up(b["times"]), up(b["bc"]), up(lo), up(hi)
+    res = {}
+    try:
+        for guess in (1, 2):
+            for shape in (1, 0):
+                gpu_ctx.set_settings(corridor_tail_shape=shape, corridor_initial_guess=guess)
+                out = torch.zeros(int(so[-1]) * 6 * r, dtype=torch.float64, device=dev)
+                st = torch.zeros(n, dtype=torch.int32, device=dev)
+                it = torch.zeros(n, dtype=torch.int32, device=dev)
+                act = torch.zeros((n, 3, 2), dtype=torch.int64, device=dev)
+                gpu_ctx.solve_corridor_device(r, n, 0, 24, d_so, d_wp, d_T, d_bc, d_lo, d_hi, out, st, it, act, False)
+                gpu_ctx.synchronize()
+                res[(guess, shape)] = (out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), act.cpu().numpy())
+    finally:
+        gpu_ctx.set_settings(corridor_tail_shape=1, corridor_initial_guess=2)
+    for guess in (1, 2):
+        for k in range(4):
+            assert np.array_equal(res[(guess, 0)][k], res[(guess, 1)][k]), (guess, k)
+    assert np.array_equal(res[(1, 1)][0], res[(2, 1)][0]) and np.array_equal(res[(1, 1)][3], res[(2, 1)][3])
+    assert res[(1, 1)][2].max() > 3 and res[(2, 1)][2].mean() < 1.3

@@ -89,6 +89,11 @@ def test_polynomial_trajectory_packer_fields():
     assert (msg["num_order"], msg["num_segment"], msg["action"], msg["trajectory_id"]) == (5, 4, 1, 7)
     assert msg["coef_x"].size == msg["coef_y"].size == msg["coef_z"].size == m * 2 * r and msg["order"] == [5] * m
     assert list(msg["time"]) == [1.0, 2.0, 0.5, 1.5] and msg["mag_coeff"] == 1.0
+    # round trip through the consumer's unpacking rule (poly_traj_server.cpp:57-81): segment i of axis x is c[x][i][:]
+    segs = A.unpack_like_traj_server(msg)
+    cc = c.reshape(3, m, 2 * r)
+    for i, (cx, cy, cz, t) in enumerate(segs):
+        assert np.array_equal(cx, cc[0, i]) and np.array_equal(cy, cc[1, i]) and np.array_equal(cz, cc[2, i]) and t == msg["time"][i]
     with pytest.raises(U.UavqpError):
         A.pack_polynomial_trajectory(c, [1.0, 0.0, 0.5, 1.5], r)          # a zero duration: the server would walk off the end
     with pytest.raises(ValueError):

@@ -130,12 +130,13 @@ class TrajOptimizer {
         if (params) pp = *params; else uavqp_default_pipeline_params(&pp);
         coef_.assign(static_cast<size_t>(3) * 2 * order_ * seg_offsets_[n_traj_], 0.0);
         status_.assign(n_traj_, 0);
-        lo_.assign(wp_.size(), 0.0);
-        hi_.assign(wp_.size(), 0.0);
+        // (the pipeline's boxes go to their own members: lo_ / hi_ are what setCorridor() installed and what a later plain solve() keys on -- ADVICE r3)
+        pipe_lo_.assign(wp_.size(), 0.0);
+        pipe_hi_.assign(wp_.size(), 0.0);
         first_hit_.assign(n_traj_, pp.check_samples);
         pipe_result_ = uavqp_pipeline_result{};
         const int rc = uavqp_corridor_pipeline_host(ctx_, order_, n_traj_, 0, 0, seg_offsets_.data(), wp_.data(), T_.data(), bc_.data(), obstacles, n_obs,
-                                                    &pp, coef_.data(), status_.data(), lo_.data(), hi_.data(), first_hit_.data(), &pipe_result_);
+                                                    &pp, coef_.data(), status_.data(), pipe_lo_.data(), pipe_hi_.data(), first_hit_.data(), &pipe_result_);
         if (rc != UAVQP_OK) {
             std::cout << "solver solve failed! (" << uavqp_last_error() << ")" << std::endl;
             return false;
@@ -143,8 +144,8 @@ class TrajOptimizer {
         return pipe_result_.unsolved == 0;
     }
     const std::vector<double>& timeAllocation() const { return T_; }
-    const std::vector<double>& corridorLo() const { return lo_; }
-    const std::vector<double>& corridorHi() const { return hi_; }
+    const std::vector<double>& corridorLo() const { return pipe_lo_; }   // boxes of the last solvePipeline() (setCorridor()'s own are untouched)
+    const std::vector<double>& corridorHi() const { return pipe_hi_; }
     const std::vector<int32_t>& firstHit() const { return first_hit_; }
     const uavqp_pipeline_result& pipelineResult() const { return pipe_result_; }
 
@@ -272,7 +273,7 @@ class TrajOptimizer {
     uavqp_settings settings_{};
     uavqp_ctx* ctx_ = nullptr;
     std::vector<int32_t> seg_offsets_, status_;
-    std::vector<double> wp_, T_, bc_, coef_, lo_, hi_, row_tau_, row_lo_, row_hi_;
+    std::vector<double> wp_, T_, bc_, coef_, lo_, hi_, pipe_lo_, pipe_hi_, row_tau_, row_lo_, row_hi_;
     std::vector<int32_t> row_deriv_, first_hit_;
     int rows_k_ = 0;
     uavqp_pipeline_result pipe_result_{};

@@ -17,7 +17,7 @@
 //     across the pair with order-independent tie rules (largest violation / smallest step, then kind, then index), so which lane
 //     sees a constraint never matters;
 //   * validation and the permanent (equality) masks come from rows_prep_kernel, one lane per problem, off the solver's path.
-// Checked against qp_rows.h's kernel (uavqp_settings.rows_kernel = 1) and the exact-rational fixtures incl. working sets.
+// Checked against qp_rows.h's kernel (uavqp_settings.rows_lanes_per_problem = 1; tests/test_gpu_rows.py::test_pair_and_one_lane_rows_kernels_take_the_same_path) and the exact-rational fixtures incl. working sets.
 #pragma once
 #include "qp_rows.h"
 

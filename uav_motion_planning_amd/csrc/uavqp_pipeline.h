@@ -180,6 +180,18 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     UAVQP_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int n = n_traj, uni = uniform_segments, mx = uni > 0 ? uni : max_segments;
+    if (uni == 0) {
+        // every workspace below is sized from the caller's total_segments: check it against the last CSR offset on the device before
+        // anything is launched (4 bytes through the pinned page, one synchronisation in a call that has one per round anyway -- ADVICE r3)
+        if (!ctx->h_pipe) { const int rc0 = ensure_pipe_ws(ctx, 256); if (rc0 != UAVQP_OK) return rc0; }
+        int32_t* h_last = (int32_t*)ctx->h_pipe;
+        UAVQP_HIP(hipMemcpyAsync(h_last, d_seg_offsets + n_traj, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        UAVQP_HIP(hipStreamSynchronize(s));
+        if (*h_last != total_segments) {
+            g_last_error = "uavqp_corridor_pipeline_device: total_segments does not match seg_offsets[n_traj]";
+            return UAVQP_ERR_INVALID_ARG;
+        }
+    }
     const int n_rows = total_segments + n_traj;
     const bool checking = P.check_samples > 0;
 
