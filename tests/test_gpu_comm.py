@@ -2,6 +2,8 @@
 the real N = 2, 4, 8 through bench.py): uavqp_comm_unique_id / uavqp_comm_create on the ctx, uavqp_allgather_coeffs and
 _status in place and out of place behind a solve on the ctx stream, uavqp_comm_destroy; and distributed.solve_sharded with
 that communicator on device tensors (views in, results written straight into the full output)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,7 @@ from uav_motion_planning_amd import distributed as D
 from uav_motion_planning_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_single_rank_communicator_and_sharded_solve(oracle):
@@ -71,3 +74,25 @@ def test_cpp_traj_optimizer_sharded_path_from_cpp():
     assert cp.returncode == 0, cp.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "OK" in run.stdout, run.stdout + run.stderr
+
+
+@pytest.mark.parametrize("config", [2, 4, 5])
+def test_bench_exchange_leg_goes_through_the_ctx_communicator(config):
+    """The situation on the driver's 8-GPU node, as far as one GPU can rehearse it: bench.py under
+    torch.distributed with the nccl backend (= RCCL) AND the library's own communicator (uavqp_comm_create) in the same process --
+    two RCCL communicators side by side.  The exchange leg must go through uavqp_allgather_coeffs, not fall back to torch's
+    all-gather, and must leave this rank's shard intact.  (World size 1: RCCL refuses two ranks on one device.)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + config), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("UAVQP_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--gpus", "1", "--config", str(config), "--steps", "3", "--warmup", "1",
+           "--cpu-sample", "0", "--no-traffic", "--no-fp64", "--pipelined-streams", "0", "--no-time-modes"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    g = d["allgather"]
+    assert g["through"].startswith("uavqp_allgather_coeffs (RCCL, ctx communicator)"), g["through"]
+    assert g["own_shard_intact"] is True and g["ms"] > 0 and d["n_gpus"] == 1 and d["value"] > 0
