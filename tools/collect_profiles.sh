@@ -3,22 +3,26 @@
 # The bench line, the rocprofv3 --kernel-trace --stats summary of the SAME command, the PMC counters of the headline kernel, the
 # other configs (bench.py --config 4 / 5 with their per-kernel tables, tools/bench_configs.py) with kernel stats and HBM traffic,
 # the A/B of the two general-rows kernels, the per-wave timeline of the headline kernel.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python $R/bench.py > $O/bench4096.json 2> $O/bench4096.err
 python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-traffic --no-fp64 > $O/bench4096_steps20.json 2>> $O/bench4096.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof4096 -o b -- python $R/bench.py --cpu-sample 0 --no-traffic --no-fp64 --pipelined-streams 0 > $O/bench4096_under_prof.json 2>> $O/bench4096.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof4096 -o b -- python $R/bench.py --cpu-sample 0 --no-traffic --no-fp64 --pipelined-streams 0 > $O/bench4096_under_prof.json 2>> $O/bench4096.err
 cp $(find $O/prof4096 -name "*kernel_stats.csv" | head -1) $O/bench4096_kernel_stats.csv
 for B in 65536 1048576; do
   python $R/bench.py --batch $B --steps 50 --cpu-sample 0 --pipelined-streams 0 > $O/bench_$B.json 2>> $O/bench4096.err
 done
-python $R/bench.py --config 4 --steps 50 --cpu-sample 0 > $O/bench_config4.json 2>> $O/bench4096.err
-python $R/bench.py --config 5 --steps 10 --cpu-sample 0 > $O/bench_config5.json 2>> $O/bench4096.err
+timeout 600 python $R/bench.py --config 3 --steps 10 --warmup 3 --cpu-sample 512 > $O/bench_config3.json 2>> $O/bench4096.err
+timeout 600 python $R/bench.py --config 3 --rows 2 --steps 3 --warmup 1 --cpu-sample 0 > $O/bench_config3_rows2.json 2>> $O/bench4096.err
+timeout 600 python $R/bench.py --config 4 --steps 50 --cpu-sample 0 > $O/bench_config4.json 2>> $O/bench4096.err
+timeout 600 python $R/bench.py --config 5 --steps 10 --cpu-sample 0 > $O/bench_config5.json 2>> $O/bench4096.err
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_config3 -o c3 -- python $R/bench.py --config 3 --steps 10 --warmup 3 --inner --repeats 1 --cpu-sample 0 > /dev/null 2>> $O/bench4096.err )
+cp $(find $O/prof_config3 -name "*kernel_stats.csv" | head -1) $O/bench_config3_kernel_stats.csv
 python $R/tools/bench_configs.py > $O/other_configs.jsonl 2> $O/other_configs.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_configs -o c -- python $R/tools/bench_configs.py > /dev/null 2>> $O/other_configs.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_configs -o c -- python $R/tools/bench_configs.py > /dev/null 2>> $O/other_configs.err
 cp $(find $O/prof_configs -name "*kernel_stats.csv" | head -1) $O/other_configs_kernel_stats.csv
 $R/tools/pmc_configs.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_configs.txt $O/pmc_other_configs.txt
 $R/tools/pmc.sh s4k "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" -- --no-traffic --pipelined-streams 0 --graph 0 --steps 50 --repeats 1 > $O/pmc_bench4096.txt 2>&1

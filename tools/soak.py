@@ -23,6 +23,7 @@ def main():
     rng = np.random.default_rng(seed)
     ctx = U.Context(0)
     worst_eq = worst_stat = 0.0
+    it_sum = it_n = it_max = 0
     for draw in range(n_draws):
         r = int(rng.choice([3, 4]))
         ragged = bool(rng.integers(0, 2))
@@ -63,6 +64,7 @@ def main():
             lo, hi = wp - h, wp + h
             gc, stc, itc = ctx.solve_corridor_batch_host(r, so if not uni else None, b["waypoints"], b["times"], b["bc"], lo, hi, uniform_segments=uni)
             assert np.all(stc == U.UAVQP_SOLVED), ("corridor status", draw, np.unique(stc))
+            it_sum += int(itc.sum()); it_n += int(itc.size); it_max = max(it_max, int(itc.max()))
             for k in sub[:8]:
                 s0, s1 = int(so[k]), int(so[k + 1])
                 M = s1 - s0
@@ -84,7 +86,8 @@ def main():
                             l_, h_ = lo[s0 + k + 1 + i, ax], hi[s0 + k + 1 + i, ax]
                             print("  knot %2d  width %.3e  p-lo %.3e  hi-p %.3e  nu %.6e" % (i + 1, h_ - l_, Ax[row] - l_, h_ - Ax[row], nu[row]))
                         return 1
-    print("soak ok: %d draws, seed %d, worst equality rel err %.2e, worst corridor stationarity %.2e" % (n_draws, seed, worst_eq, worst_stat))
+    print("soak ok: %d draws, seed %d, worst equality rel err %.2e, worst corridor stationarity %.2e; corridor block solves per trajectory after the "
+          "dual prelude: mean %.3f max %d" % (n_draws, seed, worst_eq, worst_stat, it_sum / max(it_n, 1), it_max))
     return 0
 
 
