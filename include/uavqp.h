@@ -111,12 +111,16 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *   generic_lanes_per_traj 0 auto, 1 = one lane per trajectory, 2 = a lane pair per trajectory (two-sided elimination),
  *                          3 = one lane per (trajectory, axis)
  *   generic_waves_per_cu   0 auto, > 0: resident waves per CU of the generic kernel
- *   corridor_pdas_rounds   block-pivoting rounds before the single-pivot active-set phase of a COLD corridor solve (default 3)
+ *   corridor_pdas_rounds   block-pivoting rounds before the single-pivot active-set phase of a COLD corridor solve (default 3; not
+ *                          used with corridor_initial_guess = 2, whose starting set only has to be verified)
  *   corridor_pdas_rounds_warm  the same for a warm-started one (default 0: measured on config 5's outer loop, block rounds from
  *                          the carried working set only disturb it -- largest iteration counts 57 / 54 / 37 / 27 with 3 rounds, 41 / 43 /
  *                          22 / 12 with none and the previous positions as the starting point)
- *   corridor_initial_guess 1 (default): a cold corridor solve starts from the knots whose boxes the end-state polynomial misses
- *                          (closed form) instead of the empty working set; 0: empty set.  Same result.
+ *   corridor_initial_guess working set a COLD corridor solve starts from.  2 (default): the set a dual active-set method in position space ends
+ *                          with (qp_corridor_dual.h, DESIGN.md section 5.13: inverse Hessian of the knot positions once per trajectory,
+ *                          Goldfarb-Idnani on a swept tableau) -- the exact block solve then verifies it, one solve per problem instead of
+ *                          ~12; trajectories of up to 33 segments, longer batches fall back to 1.  1: the knots whose boxes the end-state
+ *                          polynomial misses (closed form, section 5.4).  0: the empty set.  Same result to the last bit whichever is used.
  *   rows_lanes_per_problem uavqp_solve_rows_batch_*: 0 auto / 2 = a lane pair per (trajectory, axis) problem with the sweep state in LDS
  *                          (default), 1 = one lane per problem, state in an HBM workspace (the round-2 kernel, kept for A/B).  Same result.
  *   corridor_tail_shape    1 (default): small batches of long r = 4 corridor problems run two waves per CU with twice the sweep state on
