@@ -764,7 +764,7 @@ struct uavqp_ctx {
         }                                                                                        \
     } while (0)
 
-extern "C" const char* uavqp_version(void) { return "uavqp 0.3.0 (gfx950, float64)"; }
+extern "C" const char* uavqp_version(void) { return "uavqp 0.4.0 (gfx950, float64)"; }
 
 extern "C" void uavqp_default_settings(uavqp_settings* out) {
     if (!out) return;
