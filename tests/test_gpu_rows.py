@@ -309,10 +309,11 @@ def test_pair_and_one_lane_rows_kernels_take_the_same_path(gpu_ctx, r, M, K):
     res = {}
     try:
         for lanes in (2, 1):
-            gpu_ctx.set_settings(rows_lanes_per_problem=lanes)
+            # (the starting set of qp_rows_dual.h exists for the pair kernel only: both from the box set here)
+            gpu_ctx.set_settings(rows_lanes_per_problem=lanes, corridor_initial_guess=1)
             res[lanes] = run_rows(gpu_ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, M)
     finally:
-        gpu_ctx.set_settings(rows_lanes_per_problem=0)
+        gpu_ctx.set_settings(rows_lanes_per_problem=0, corridor_initial_guess=2)
     assert np.array_equal(res[1][1], res[2][1]) and np.array_equal(res[1][2], res[2][2])
     ok = res[2][1] == U.UAVQP_SOLVED
     assert ok.mean() > 0.9 and np.array_equal(res[1][3][ok], res[2][3][ok])
@@ -350,3 +351,52 @@ def test_corridor_tail_shape_changes_the_launch_not_the_result(gpu_ctx):
             assert np.array_equal(res[(guess, 0)][k], res[(guess, 1)][k]), (guess, k)
     assert np.array_equal(res[(1, 1)][0], res[(2, 1)][0]) and np.array_equal(res[(1, 1)][3], res[(2, 1)][3])
     assert res[(1, 1)][2].max() > 3 and res[(2, 1)][2].mean() < 1.3
+
+
+@pytest.mark.parametrize("r,M,K,ragged", [(3, 16, 2, False), (4, 10, 2, False), (3, 20, 1, False), (4, 12, 2, True), (3, 20, 2, False)])
+def test_rows_prelude_changes_iterations_not_results(gpu_ctx, r, M, K, ragged):
+    """uavqp_settings.corridor_initial_guess = 2 also gives the general-rows solve its starting set (qp_rows_dual.h: the dual method of
+    the corridor prelude on a time grid refined by a knot at every row; it solves a RELAXATION -- an inserted knot whose row is active
+    may break the higher derivatives -- so the set is a good guess, not the answer): statuses and working sets identical, coefficients to
+    rounding, far fewer block solves where it applies ((M - 1) + K M <= 48 constraints; the last case is beyond that: same counts)."""
+    n = 64
+    if ragged:
+        b = W.ragged_batch(5, n, r, m_lo=2, m_hi=M, seed=77)
+        so = np.asarray(b["seg_offsets"])
+        tot = int(so[-1])
+        wp = np.asarray(b["waypoints"])
+        mid = np.concatenate([0.5 * (wp[so[k] + k:so[k + 1] + k] + wp[so[k] + k + 1:so[k + 1] + k + 1]) for k in range(n)])
+        uni = 0
+    else:
+        b = W.uniform_batch(3, n, M, r, time_mode="distance")
+        tot = n * M
+        mid = 0.5 * (b["waypoints"][:, :-1] + b["waypoints"][:, 1:]).reshape(tot, 3)
+        uni = M
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    rng = np.random.default_rng(3)
+    tau = np.tile(np.array([0.5, 0.5])[:K], (tot, 1))
+    tau[rng.random(tot) < 0.3, 0] = 0.3                      # some segments with two different times (two inserted knots)
+    drv = np.tile(np.array([0, 1])[:K], (tot, 1))
+    drv[rng.random(tot) < 0.1, K - 1] = -1                     # some unused slots
+    rlo, rhi = np.zeros((tot, K, 3)), np.zeros((tot, K, 3))
+    rlo[:, 0], rhi[:, 0] = mid - 0.25, mid + 0.25
+    if K == 2:
+        rlo[:, 1], rhi[:, 1] = -3.5, 3.5
+    res = {}
+    try:
+        for guess in (2, 1):
+            gpu_ctx.set_settings(corridor_initial_guess=guess)
+            res[guess] = run_rows(gpu_ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, uni)
+    finally:
+        gpu_ctx.set_settings(corridor_initial_guess=2)
+    assert np.array_equal(res[1][1], res[2][1])
+    ok = res[2][1] == U.UAVQP_SOLVED
+    assert ok.mean() > 0.8
+    assert np.array_equal(res[1][3][ok], res[2][3][ok])
+    so_ = np.asarray(b["seg_offsets"])
+    co = np.repeat(ok, np.diff(so_) * 6 * r)
+    assert np.max(np.abs(res[1][0][co] - res[2][0][co])) <= 1e-9 * np.max(np.abs(res[1][0][co]))
+    if (M - 1) + K * M <= 48:
+        assert res[2][2][ok].mean() < 0.75 * res[1][2][ok].mean(), (res[2][2][ok].mean(), res[1][2][ok].mean())
+    else:
+        assert np.array_equal(res[1][2], res[2][2])

@@ -33,7 +33,7 @@ def case(tag, r, n, M=None, K=2, boxes=True, timing=True):
     d_tau, d_drv, d_rlo, d_rhi = up(tau), up(drv), up(rlo), up(rhi)
     res = {}
     for mode in (1, 2):
-        ctx.set_settings(rows_lanes_per_problem=mode)
+        ctx.set_settings(rows_lanes_per_problem=mode, corridor_initial_guess=1)   # (A/B of the two kernels from the same start: the box set)
         out = torch.zeros(tot * 6 * r, dtype=torch.float64, device=dev)
         st = torch.zeros(n, dtype=torch.int32, device=dev); it = torch.zeros(n, dtype=torch.int32, device=dev)
         act = torch.zeros(n * 3 * (2 + 2 * K), dtype=torch.int64, device=dev)
@@ -51,7 +51,7 @@ def case(tag, r, n, M=None, K=2, boxes=True, timing=True):
                       "iters_mean": [float(a["it"].mean()), float(c["it"].mean())], "iters_max": [int(a["it"].max()), int(c["it"].max())],
                       "iters_equal_frac": float((a["it"] == c["it"]).mean()), "working_sets_equal_frac(solved)": float(np.all(a["act"] == c["act"], axis=(1, 2))[solved].mean()) if solved.any() else None,
                       "max_coef_diff_rel(solved)": float(err[solved].max() / scale) if solved.any() else None}), flush=True)
-    ctx.set_settings(rows_lanes_per_problem=0)
+    ctx.set_settings(rows_lanes_per_problem=0, corridor_initial_guess=2)
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536

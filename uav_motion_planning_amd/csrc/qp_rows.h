@@ -49,6 +49,7 @@ struct RowsArgs {
     double* ws;                 // [wave][knot 1..M][F][lane]
     unsigned long long* active; // [n_traj][3][2 + 2 K]: knot boxes (active, upper), then per row slot (active, upper); may be null
     const unsigned long long* warm;   // [n_traj][3][2]: initial working set of the knot boxes (the box-only solution's: uavqp.hip), may be null
+    const unsigned long long* warm_rows;   // [n_traj][3][2 K]: initial working set of the rows, (active, upper) per slot (qp_rows_dual.h; pair kernel only), may be null
     unsigned int* queue;              // work counter, zeroed before the launch
 };
 

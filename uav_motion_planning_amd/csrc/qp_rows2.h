@@ -224,6 +224,16 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                                 pin |= w0;
                                 upper = a.warm[(size_t)gn * 2 + 1] & w0;
                             }
+                            if (a.warm_rows) {
+                                // rows of the starting set (qp_rows_dual.h): like the boxes above they enter with multiplier 0 -- a wrong guess
+                                // leaves again with a zero-length step, a right one is confirmed by the first solve
+#pragma unroll
+                                for (int j = 0; j < K; ++j) {
+                                    const unsigned long long w = a.warm_rows[(size_t)gn * 2 * K + 2 * j] & rused[j] & ~req[j];
+                                    ract[j] |= w;
+                                    rup[j] = a.warm_rows[(size_t)gn * 2 * K + 2 * j + 1] & w;
+                                }
+                            }
                             it = 0; capped = false; tpend = 1.0; ppin = 0ull; new_kind = -1; new_idx = -1;
                         }
                     }

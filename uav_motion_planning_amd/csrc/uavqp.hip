@@ -693,6 +693,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 #include "qp_corridor_dual.h"
 #include "qp_rows.h"
 #include "qp_rows2.h"
+#include "qp_rows_dual.h"
 #include "obstacle_grid.h"
 
 namespace uavqp {
@@ -733,6 +734,8 @@ struct uavqp_ctx {
     double* ws = nullptr;
     size_t ws_bytes = 0;
     uavqp::Comm comm;         // RCCL communicator of the multi-GPU entry points (uavqp_comm_create)
+    void* rows_warm2 = nullptr;      // rows part of the starting set of the general-rows solve + the "box phase needed" flags (qp_rows_dual.h)
+    size_t rows_warm2_bytes = 0;
     void* dbg_queue = nullptr;  // (debug builds) where the last corridor solve kept its work counter
     void* dbg_dual = nullptr;   // (UAVQP_DUAL_DEBUG builds) dump area of corridor_dual_kernel
     void* dbg_guess = nullptr;  // (UAVQP_DUAL_DEBUG builds) the starting sets of the last cold corridor solve
@@ -880,6 +883,7 @@ extern "C" int uavqp_destroy(uavqp_ctx* ctx) {
     if (ctx->dummy) (void)hipFree(ctx->dummy);
     if (ctx->h_axis) (void)hipHostFree(ctx->h_axis);
     if (ctx->rows_warm) (void)hipFree(ctx->rows_warm);
+    if (ctx->rows_warm2) (void)hipFree(ctx->rows_warm2);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_pipe) (void)hipFree(ctx->d_pipe);
     if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
@@ -1530,6 +1534,9 @@ extern "C" int uavqp_debug_generic2_stamps(uavqp_ctx* ctx, long long* out9) {
 }
 #endif
 
+#ifdef UAVQP_DUAL_DEBUG
+static double* g_rows_dbg = nullptr;   // dump area of rows_dual_kernel (tools/rows_dual_gpu_probe.py)
+#endif
 static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                            const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
                            const double* d_bc, const double* d_corr_lo, const double* d_corr_hi, int rows_per_segment,
@@ -1560,7 +1567,13 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     // constraint per block solve (BASELINE config 3 with K = 2 rows: 34 -> 25 iterations mean, 36 -> 30 ms; uavqp_settings.warm_start = 0
     // starts from the empty set).
     const bool warm = d_corr_lo != nullptr && ctx->settings.warm_start != 0;
-    if (warm) {
+    const int K_ = rows_per_segment;
+    // Round 4: the starting set of boxes AND rows from the position-space dual method on the refined time grid (qp_rows_dual.h: a row is a
+    // bound on a component of a knot inserted at its time); trajectories it does not take (rows at tau = 0, too many constraints) go
+    // through the box phase as before.  uavqp_settings.corridor_initial_guess != 2 or warm_start = 0 switch it off.
+    const bool prelude = ctx->settings.corridor_initial_guess == 2 && ctx->settings.warm_start != 0 && ctx->settings.rows_lanes_per_problem != 1 &&
+                         Mmax >= 2 && (Mmax - 1) + K_ * Mmax <= 48;
+    if (warm || prelude) {
         if ((size_t)n_traj * 6 > ctx->rows_warm_count) {
             UAVQP_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->rows_warm) UAVQP_HIP(hipFree(ctx->rows_warm));
@@ -1569,10 +1582,60 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
             UAVQP_HIP(hipMalloc((void**)&ctx->rows_warm, sizeof(uint64_t) * (size_t)n_traj * 6));
             ctx->rows_warm_count = (size_t)n_traj * 6;
         }
+    }
+    unsigned long long* d_warm_rows = nullptr;
+    unsigned char* d_need_phase1 = nullptr;
+    if (prelude) {
+        const size_t need = sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_ + align256((size_t)n_traj);
+        if (need > ctx->rows_warm2_bytes) {
+            UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->rows_warm2) UAVQP_HIP(hipFree(ctx->rows_warm2));
+            ctx->rows_warm2 = nullptr;
+            ctx->rows_warm2_bytes = 0;
+            UAVQP_HIP(hipMalloc((void**)&ctx->rows_warm2, need));
+            ctx->rows_warm2_bytes = need;
+        }
+        d_warm_rows = (unsigned long long*)ctx->rows_warm2;
+        d_need_phase1 = (unsigned char*)ctx->rows_warm2 + sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_;
+        UAVQP_HIP(hipMemsetAsync(ctx->rows_warm2, 0, need, ctx->stream));
+        UAVQP_HIP(hipMemsetAsync(ctx->rows_warm, 0, sizeof(uint64_t) * (size_t)n_traj * 6, ctx->stream));
+        uavqp::RowsDualArgs da{};
+        da.r.n_traj = n_traj; da.r.uniform = uniform_segments; da.r.max_segments = Mmax;
+        da.r.seg_offsets = d_seg_offsets; da.r.waypoints = d_waypoints; da.r.times = d_times; da.r.bc = d_bc;
+        da.r.corr_lo = d_corr_lo; da.r.corr_hi = d_corr_hi; da.r.row_tau = d_row_tau; da.r.row_deriv = d_row_deriv; da.r.row_lo = d_row_lo; da.r.row_hi = d_row_hi;
+        da.order = nullptr;
+        da.warm_box = (unsigned long long*)ctx->rows_warm; da.warm_rows = d_warm_rows; da.need_phase1 = d_need_phase1;
+#ifdef UAVQP_DUAL_DEBUG
+        {
+            if (!g_rows_dbg) { UAVQP_HIP(hipMalloc(&g_rows_dbg, 64 * 2048 * sizeof(double))); }   // (the size uavqp_debug_corridor_dual copies)
+            UAVQP_HIP(hipMemsetAsync(g_rows_dbg, 0, 64 * 2048 * sizeof(double), ctx->stream));
+            da.dbg = g_rows_dbg;
+        }
+#endif
+        const long long nb = ((long long)n_traj + 1) / 2;
+        const long long dgrid = nb < (long long)ctx->num_cus * 4 ? nb : (long long)ctx->num_cus * 4;
+        if (r == 3 && K_ == 1) hipLaunchKernelGGL((uavqp::rows_dual_kernel<3, 1>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
+        else if (r == 3) hipLaunchKernelGGL((uavqp::rows_dual_kernel<3, 2>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
+        else if (K_ == 1) hipLaunchKernelGGL((uavqp::rows_dual_kernel<4, 1>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
+        else hipLaunchKernelGGL((uavqp::rows_dual_kernel<4, 2>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
+    }
+    if (warm) {
+        // (with the prelude: only for the trajectories it did not take)
         const int rc1 = corridor_warm_impl(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times,
-                                           d_bc, d_corr_lo, d_corr_hi, d_coeff_out, d_status_out, nullptr, ctx->rows_warm, 0, rows - n_traj);
+                                           d_bc, d_corr_lo, d_corr_hi, d_coeff_out, d_status_out, nullptr, ctx->rows_warm, 0, rows - n_traj, nullptr,
+                                           nullptr, d_need_phase1);
         if (rc1 != UAVQP_OK) return rc1;
     }
+#ifdef UAVQP_DUAL_DEBUG
+    if (prelude) {   // (after the box phase, which points these at its own dump)
+        static unsigned long long* s_box = nullptr;
+        static size_t s_box_n = 0;
+        if (s_box_n < (size_t)n_traj * 6) { if (s_box) (void)hipFree(s_box); UAVQP_HIP(hipMalloc((void**)&s_box, sizeof(uint64_t) * (size_t)n_traj * 6)); s_box_n = (size_t)n_traj * 6; }
+        UAVQP_HIP(hipMemcpyAsync(s_box, ctx->rows_warm, sizeof(uint64_t) * (size_t)n_traj * 6, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->dbg_guess = s_box;
+        ctx->dbg_dual = g_rows_dbg;
+    }
+#endif
     const int K = rows_per_segment, Bk = r + K;
     uavqp::RowsArgs a;
     a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax;
@@ -1580,7 +1643,8 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.row_tau = d_row_tau; a.row_deriv = d_row_deriv; a.row_lo = d_row_lo; a.row_hi = d_row_hi;
     a.status = d_status_out; a.iters = d_iters_out; a.active = (unsigned long long*)d_active_out;
-    a.warm = warm ? (const unsigned long long*)ctx->rows_warm : nullptr;
+    a.warm = (warm || prelude) ? (const unsigned long long*)ctx->rows_warm : nullptr;
+    a.warm_rows = prelude ? (const unsigned long long*)d_warm_rows : nullptr;
     const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
     const bool pair_kernel = ctx->settings.rows_lanes_per_problem != 1;
     int rc;
