@@ -51,30 +51,52 @@ with U.Context(0) as ctx:
 print("rows solve: iterations mean %.2f max %d with the prelude; %.2f / %d from the box set; statuses equal %s; coefficients equal to %.1e; working sets equal %s" % (
     res[2][2].mean(), res[2][2].max(), res[1][2].mean(), res[1][2].max(), np.array_equal(res[2][1], res[1][1]),
     np.max(np.abs(res[2][0] - res[1][0])) / np.max(np.abs(res[1][0])), np.array_equal(res[2][3], res[1][3])))
+def hermite_functional(r, T, tau, d):
+    """g_l, g_r with p^(d)(tau T) = g_l' x_start + g_r' x_end for the degree-(2r-1) polynomial matching derivatives 0..r-1 at both ends."""
+    import math
+    nc = 2 * r
+    A = np.zeros((nc, nc))
+    for k in range(r):
+        A[k, k] = math.factorial(k)                                   # p^(k)(0)
+        for j in range(k, nc):
+            A[r + k, j] = math.factorial(j) / math.factorial(j - k) * T ** (j - k)   # p^(k)(T)
+    row = np.zeros(nc)
+    t = tau * T
+    for j in range(d, nc):
+        row[j] = math.factorial(j) / math.factorial(j - d) * t ** (j - d)
+    g = np.linalg.solve(A.T, row)
+    return g[:r], g[r:]
+
+
 if have_dbg:
     print("box part of the starting set == box part of the final set for %d / %d problems" % (int(np.sum(np.all(box == res[2][3][:, :, :2], axis=2))), 3 * n))
     for k in range(min(n, 2)):
         T = b["times"][k]
-        T2 = np.repeat(T, 2) * 0.5
-        H = hessian(r, T2)
-        M2 = 2 * M
-        I = np.arange(r, M2 * r)
-        Bd = np.r_[np.arange(r), np.arange(M2 * r, (M2 + 1) * r)]
+        H = hessian(r, T)
+        I = np.arange(r, M * r)
+        Bd = np.r_[np.arange(r), np.arange(M * r, (M + 1) * r)]
         Hi = np.linalg.inv(H[np.ix_(I, I)])
-        NC = int(dump[k, 2304 + 640]); nref = int(dump[k, 2304 + 641])
+        NC = int(dump[k, 2304 + 640])
         cd = dump[k, 2304 + 576: 2304 + 576 + NC].astype(np.int64)
-        knot, comp = cd & 255, (cd >> 8) & 15
-        idx = (knot - 1) * r + comp
-        Gref = Hi[np.ix_(idx, idx)]
+        kL, kind, seg = cd & 255, (cd >> 8) & 15, (cd >> 12) & 255
+        C = np.zeros((NC, (M + 1) * r))                               # functionals over ALL knots 0..M
+        for i in range(NC):
+            if kind[i] == 0:
+                C[i, kL[i] * r] = 1.0
+            else:
+                gl, gr = hermite_functional(r, T[seg[i]], tau[k * M + seg[i], kind[i] - 1], int(drv[k * M + seg[i], kind[i] - 1]))
+                C[i, seg[i] * r:(seg[i] + 1) * r] = gl
+                C[i, (seg[i] + 1) * r:(seg[i] + 2) * r] = gr
+        Ci = C[:, I]
+        Gref = Ci @ Hi @ Ci.T
         G = dump[k, :2304].reshape(48, 48)[:NC, :NC]
-        print(f"traj {k}: NC {NC} refined interior knots {nref}; max |G - Gref| / max |Gref| = {np.max(np.abs(G - Gref)) / np.max(np.abs(Gref)):.2e}")
+        print(f"traj {k}: NC {NC}; max |G - Gref| / max |Gref| = {np.max(np.abs(G - Gref)) / np.max(np.abs(Gref)):.2e}; asymmetry {np.max(np.abs(G - G.T)):.1e}")
         for ax in range(3):
             x0 = np.r_[wp[k, 0, ax], b["bc"][k, 0, :, ax]]; xM = np.r_[wp[k, M, ax], b["bc"][k, 1, :, ax]]
             g = -(H[np.ix_(I, Bd)] @ np.r_[x0, xM])
-            yref = (Hi @ g)[idx]
+            yref = Ci @ (Hi @ g)
             y0 = dump[k, 2304 + 192 * ax: 2304 + 192 * ax + NC]
             trips = dump[k, 2304 + 192 * ax + 48]
             mk = [hex(int(v)) for v in dump[k, 2304 + 700 + 8 * ax: 2304 + 700 + 8 * ax + 2 + 2 * K]]
-            print(f"   axis {ax}: prelude set {mk}")
-            print(f"   axis {ax}: y0 err {np.max(np.abs(y0 - yref)) / (1 + np.max(np.abs(yref))):.2e} trips {trips:.0f}  start box {int(box[k, ax, 0]):#x}/{int(box[k, ax, 1]):#x}"
-                  f"  final {[hex(int(v)) for v in res[2][3][k, ax]]}  rows-kernel iterations {res[2][2][k]} (box start: {res[1][2][k]})")
+            print(f"   axis {ax}: y0 err {np.max(np.abs(y0 - yref)) / (1 + np.max(np.abs(yref))):.2e} trips {trips:.0f}  prelude set {mk}")
+            print(f"           final set   {[hex(int(v)) for v in res[2][3][k, ax]]}  rows-kernel iterations {res[2][2][k]} (box start: {res[1][2][k]})")

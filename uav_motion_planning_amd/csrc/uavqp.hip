@@ -1612,8 +1612,10 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
             da.dbg = g_rows_dbg;
         }
 #endif
-        const long long nb = ((long long)n_traj + 1) / 2;
-        const long long dgrid = nb < (long long)ctx->num_cus * 4 ? nb : (long long)ctx->num_cus * 4;
+        // one trajectory per wave; waves per CU by the LDS of a block (two per SIMD at most: 256 registers)
+        int wpc_r = (160 * 1024) / (8 * uavqp::rows_dual_lds_doubles(r));
+        if (wpc_r > 8) wpc_r = 8;
+        const long long dgrid = (long long)n_traj < (long long)ctx->num_cus * wpc_r ? (long long)n_traj : (long long)ctx->num_cus * wpc_r;
         if (r == 3 && K_ == 1) hipLaunchKernelGGL((uavqp::rows_dual_kernel<3, 1>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
         else if (r == 3) hipLaunchKernelGGL((uavqp::rows_dual_kernel<3, 2>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
         else if (K_ == 1) hipLaunchKernelGGL((uavqp::rows_dual_kernel<4, 1>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
