@@ -356,9 +356,10 @@ def test_corridor_tail_shape_changes_the_launch_not_the_result(gpu_ctx):
 @pytest.mark.parametrize("r,M,K,ragged", [(3, 16, 2, False), (4, 10, 2, False), (3, 20, 1, False), (4, 12, 2, True), (3, 20, 2, False)])
 def test_rows_prelude_changes_iterations_not_results(gpu_ctx, r, M, K, ragged):
     """uavqp_settings.corridor_initial_guess = 2 also gives the general-rows solve its starting set (qp_rows_dual.h: the dual method of
-    the corridor prelude on a time grid refined by a knot at every row; it solves a RELAXATION -- an inserted knot whose row is active
-    may break the higher derivatives -- so the set is a good guess, not the answer): statuses and working sets identical, coefficients to
-    rounding, far fewer block solves where it applies ((M - 1) + K M <= 48 constraints; the last case is beyond that: same counts)."""
+    the corridor prelude on the dense matrix G_ij = c_i' H^-1 c_j of ALL constraints -- boxes and rows as two-knot functionals, the rows
+    QP itself): statuses and working sets identical, coefficients to rounding, and where it applies ((M - 1) + used rows <= 48
+    constraints) barely more than the one verifying block solve per problem; the last case is beyond that: same counts as from the box
+    set.  Segments with two different row times, unused slots and rows at tau = 0 are mixed in."""
     n = 64
     if ragged:
         b = W.ragged_batch(5, n, r, m_lo=2, m_hi=M, seed=77)
@@ -375,7 +376,9 @@ def test_rows_prelude_changes_iterations_not_results(gpu_ctx, r, M, K, ragged):
     lo, hi = W.corridor_boxes(b, config_index=3)
     rng = np.random.default_rng(3)
     tau = np.tile(np.array([0.5, 0.5])[:K], (tot, 1))
-    tau[rng.random(tot) < 0.3, 0] = 0.3                      # some segments with two different times (two inserted knots)
+    tau[rng.random(tot) < 0.3, 0] = 0.3                      # some segments with two different row times
+    if K == 2:
+        tau[rng.random(tot) < 0.05, 1] = 0.0                   # a velocity row AT a knot (tau = 0, d = 1)
     drv = np.tile(np.array([0, 1])[:K], (tot, 1))
     drv[rng.random(tot) < 0.1, K - 1] = -1                     # some unused slots
     rlo, rhi = np.zeros((tot, K, 3)), np.zeros((tot, K, 3))
@@ -389,14 +392,17 @@ def test_rows_prelude_changes_iterations_not_results(gpu_ctx, r, M, K, ragged):
             res[guess] = run_rows(gpu_ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, uni)
     finally:
         gpu_ctx.set_settings(corridor_initial_guess=2)
-    assert np.array_equal(res[1][1], res[2][1])
-    ok = res[2][1] == U.UAVQP_SOLVED
+    # (a degenerate vertex -- as many active constraints as free variables -- can end the dual method from the box set as "capped" where the
+    # verified starting set is accepted: seen on a 2-segment snap trajectory; never the other way round)
+    assert np.all((res[2][1] == res[1][1]) | ((res[2][1] == U.UAVQP_SOLVED) & (res[1][1] == U.UAVQP_MAX_ITER_REACHED)))
+    assert int((res[2][1] != res[1][1]).sum()) <= 1
+    ok = (res[2][1] == U.UAVQP_SOLVED) & (res[1][1] == U.UAVQP_SOLVED)
     assert ok.mean() > 0.8
     assert np.array_equal(res[1][3][ok], res[2][3][ok])
     so_ = np.asarray(b["seg_offsets"])
     co = np.repeat(ok, np.diff(so_) * 6 * r)
     assert np.max(np.abs(res[1][0][co] - res[2][0][co])) <= 1e-9 * np.max(np.abs(res[1][0][co]))
     if (M - 1) + K * M <= 48:
-        assert res[2][2][ok].mean() < 0.75 * res[1][2][ok].mean(), (res[2][2][ok].mean(), res[1][2][ok].mean())
+        assert res[2][2][ok].mean() < 1.5 and res[2][2][ok].mean() < 0.3 * res[1][2][ok].mean(), (res[2][2][ok].mean(), res[1][2][ok].mean())
     else:
         assert np.array_equal(res[1][2], res[2][2])

@@ -28,6 +28,7 @@ struct RowsDualArgs {
     unsigned long long* warm_box;    // [problem][2]: (active, upper) of the knot boxes, bit k = interior knot k -- written for handled trajectories
     unsigned long long* warm_rows;   // [problem][2 K]: (active, upper) per row slot, bit s = segment s -- zeroed by the host, written for handled ones
     unsigned char* need_phase1;      // [n_traj]: 1 = not handled here
+    const double* gfun;              // [segment][K][2 R]: g_l, g_r of every row (rows_gfun_kernel, launched before this kernel)
 #ifdef UAVQP_DUAL_DEBUG
     double* dbg;
 #endif
@@ -120,9 +121,9 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                 if (d >= 0) {
                     segok = segok && d < R && tau >= 0.0 && tau < 1.0 && !(tau == 0.0 && d == 0);
                     double gl[R], gr[R];
+                    const double* const gf = aa.gfun + ((size_t)(s0 + lane) * K + j) * 2 * R;     // (zeros for an invalid row: the trajectory is not handled then)
 #pragma unroll
-                    for (int q = 0; q < R; ++q) { gl[q] = 0.0; gr[q] = 0.0; }
-                    if (segok) row_functional<R>(Tseg, tau, d, gl, gr);
+                    for (int q = 0; q < R; ++q) { gl[q] = gf[q]; gr[q] = gf[R + q]; }
                     // (compile-time slot index: the first used row goes to position 0)
                     if (nrow == 0) {
 #pragma unroll

@@ -1585,8 +1585,11 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     }
     unsigned long long* d_warm_rows = nullptr;
     unsigned char* d_need_phase1 = nullptr;
+    double* d_gfun_pre = nullptr;
     if (prelude) {
-        const size_t need = sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_ + align256((size_t)n_traj);
+        const size_t b_wr = align256(sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_), b_np = align256((size_t)n_traj);
+        const size_t b_gf = align256(sizeof(double) * (size_t)(rows - n_traj) * K_ * 2 * r);     // row functionals: made here, used by the prelude AND the rows kernel
+        const size_t need = b_wr + b_np + b_gf;
         if (need > ctx->rows_warm2_bytes) {
             UAVQP_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->rows_warm2) UAVQP_HIP(hipFree(ctx->rows_warm2));
@@ -1596,15 +1599,29 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
             ctx->rows_warm2_bytes = need;
         }
         d_warm_rows = (unsigned long long*)ctx->rows_warm2;
-        d_need_phase1 = (unsigned char*)ctx->rows_warm2 + sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_;
-        UAVQP_HIP(hipMemsetAsync(ctx->rows_warm2, 0, need, ctx->stream));
+        d_need_phase1 = (unsigned char*)ctx->rows_warm2 + b_wr;
+        d_gfun_pre = (double*)((char*)ctx->rows_warm2 + b_wr + b_np);
+        UAVQP_HIP(hipMemsetAsync(ctx->rows_warm2, 0, b_wr + b_np, ctx->stream));
+        {
+            uavqp::Rows2Args ga{};
+            ga.r.row_tau = d_row_tau; ga.r.row_deriv = d_row_deriv; ga.r.times = d_times;
+            ga.gfun = d_gfun_pre;
+            const long long total_seg_ = rows - n_traj;
+            long long gg = (total_seg_ * K_ + 255) / 256;
+            if (gg > (long long)ctx->num_cus * 16) gg = (long long)ctx->num_cus * 16;
+            if (gg < 1) gg = 1;
+            if (r == 3 && K_ == 1) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<3, 1>), dim3((unsigned)gg), dim3(256), 0, ctx->stream, ga, total_seg_);
+            else if (r == 3) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<3, 2>), dim3((unsigned)gg), dim3(256), 0, ctx->stream, ga, total_seg_);
+            else if (K_ == 1) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<4, 1>), dim3((unsigned)gg), dim3(256), 0, ctx->stream, ga, total_seg_);
+            else hipLaunchKernelGGL((uavqp::rows_gfun_kernel<4, 2>), dim3((unsigned)gg), dim3(256), 0, ctx->stream, ga, total_seg_);
+        }
         UAVQP_HIP(hipMemsetAsync(ctx->rows_warm, 0, sizeof(uint64_t) * (size_t)n_traj * 6, ctx->stream));
         uavqp::RowsDualArgs da{};
         da.r.n_traj = n_traj; da.r.uniform = uniform_segments; da.r.max_segments = Mmax;
         da.r.seg_offsets = d_seg_offsets; da.r.waypoints = d_waypoints; da.r.times = d_times; da.r.bc = d_bc;
         da.r.corr_lo = d_corr_lo; da.r.corr_hi = d_corr_hi; da.r.row_tau = d_row_tau; da.r.row_deriv = d_row_deriv; da.r.row_lo = d_row_lo; da.r.row_hi = d_row_hi;
         da.order = nullptr;
-        da.warm_box = (unsigned long long*)ctx->rows_warm; da.warm_rows = d_warm_rows; da.need_phase1 = d_need_phase1;
+        da.warm_box = (unsigned long long*)ctx->rows_warm; da.warm_rows = d_warm_rows; da.need_phase1 = d_need_phase1; da.gfun = d_gfun_pre;
 #ifdef UAVQP_DUAL_DEBUG
         {
             if (!g_rows_dbg) { UAVQP_HIP(hipMalloc(&g_rows_dbg, 64 * 2048 * sizeof(double))); }   // (the size uavqp_debug_corridor_dual copies)
@@ -1666,7 +1683,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         const size_t b_state = align256(sizeof(double) * (size_t)ws_knots * Fp * (size_t)grid * 64);
         const size_t b_lam = align256(sizeof(double) * (size_t)kown * 2 * NCN * (size_t)grid * 64);
         const long long total_seg = rows - n_traj;
-        const size_t b_gfun = align256(sizeof(double) * (size_t)total_seg * K * 2 * r);
+        const size_t b_gfun = d_gfun_pre ? 0 : align256(sizeof(double) * (size_t)total_seg * K * 2 * r);
         rc = ensure_ws(ctx, b_xsol + 256 + b_desc + b_order + b_state + b_lam + b_gfun);
         if (rc != UAVQP_OK) return rc;
         char* p = (char*)ctx->ws;
@@ -1691,7 +1708,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         p += b_order;
         a.ws = (double*)p; p += b_state;
         aa.lam = (double*)p; p += b_lam;
-        aa.gfun = (double*)p;
+        aa.gfun = d_gfun_pre ? d_gfun_pre : (double*)p;
         aa.ws_knots = ws_knots;
         aa.lam_knots = kown;
         UAVQP_HIP(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
@@ -1706,7 +1723,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
 #define UAVQP_ROWS2(RR, KK)                                                                                                                  \
     do {                                                                                                                                     \
         hipLaunchKernelGGL((uavqp::rows_prep_kernel<RR, KK>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);                       \
-        hipLaunchKernelGGL((uavqp::rows_gfun_kernel<RR, KK>), dim3((unsigned)ggrid), dim3(256), 0, ctx->stream, aa, total_seg);           \
+        if (!d_gfun_pre) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<RR, KK>), dim3((unsigned)ggrid), dim3(256), 0, ctx->stream, aa, total_seg); \
         if (ws_knots > 0) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);  \
         else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);             \
     } while (0)
