@@ -33,6 +33,8 @@
 
 namespace uavqp {
 
+constexpr int corridor_gcache_stride = 24 * 24 + 2 * 32 * 4;   // G of up to 24 rows, then the two vector families of up to 32 columns (r <= 4)
+
 struct CorridorArgs {
     int n_traj, uniform, max_segments, max_iter, pdas_rounds;
     const int32_t* seg_offsets;
@@ -57,6 +59,12 @@ struct CorridorArgs {
     const int32_t* only_i32;       // optional masks of an outer loop (uavqp_pipeline.h): when either is given, only the trajectories with a non-zero
     const unsigned char* only_u8;  // entry in one of them take part; the others keep their coefficients, status, iteration count and working set
     const int* n_active;           // with a mask: `order` lists only the trajectories that take part, *n_active of them (compact_order_kernel); null: all n_traj
+    // G of the dual prelude across the solves of an outer loop whose durations only change by ONE factor per trajectory (the time
+    // re-allocation): [H^-1]_{(i,a),(j,b)}(s T) = s^(2r-1-a-b) [H^-1]_{(i,a),(j,b)}(T).  mode 1: build as usual and store; 2: load and rescale
+    // by gscale[b] (the factor since the store) instead of running the chain; 0: off
+    double* gcache;                // [n_traj][corridor_gcache_stride]
+    const double* gscale;          // [n_traj]
+    int gcache_mode;
     int guess_closed_form;         // 1: corridor_prep_kernel fills `guess` with the closed-form set; 0: it only zeroes it (corridor_dual_kernel, qp_corridor_dual.h, writes it)
 #ifdef UAVQP_DUAL_DEBUG
     double* dbg;                   // debug build only (tools/corridor_dual_gpu_probe.py): G, unconstrained minimisers, trip counts of the first trajectories
@@ -100,6 +108,10 @@ struct FullBlocks {
     __device__ __forceinline__ double B00(int i, int c) const { return ((i + c) & 1) ? -B11[i][c] : B11[i][c]; }
 };
 
+__global__ void fill_f64_kernel(double* p, int n, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

@@ -134,6 +134,8 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
         kmax = __builtin_amdgcn_readfirstlane(kmax);
+        const bool reuse = a.gcache_mode == 2;            // G from the cache of an earlier solve of the same outer loop: no chain
+        const int kch = reuse ? 0 : kmax;
         lds_publish();
 
         // ---------------- forward: block LDL' chain, replicated in the lanes of the group ----------------
@@ -142,7 +144,7 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
         Inv lprev;
         LDLPack<R>::zero(lprev);
 #pragma unroll 1
-        for (int k = 1; k <= kmax; ++k) {
+        for (int k = 1; k <= kch; ++k) {
             const bool vk = k <= n;
             FullBlocks<R> sb;
             sb.build(ldT(min(k, M - 1)));
@@ -217,7 +219,7 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
             lprev = ldl;
             sa = sb;
         }
-        if (l == 0) {   // E of the last chain knot: nothing behind it
+        if (l == 0 && !reuse) {   // E of the last chain knot: nothing behind it
             double* const rec = ES(kmax);
 #pragma unroll
             for (int i = 0; i < R * R; ++i) rec[NE + i] = 0.0;
@@ -233,7 +235,7 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
             for (int c = 0; c < R; ++c) { Zk1[i][c] = 0.0; Zkn[i][c] = 0.0; }
         }
 #pragma unroll 1
-        for (int k = kmax; k >= 1; --k) {
+        for (int k = kch; k >= 1; --k) {
             double Si[R][R], E[R][R];
             {
                 const double* const rec = ES(k);
@@ -319,6 +321,41 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
             }
         lds_publish();
         // cv[sl] = Z_{1,j} e_0, wv[sl] = e_0' Z_{j,n} of the owned columns
+        if (a.gcache_mode != 0 && solve_any) {
+            // G and the two vector families across the solves of an outer loop (CorridorArgs::gcache): store after a build, or load and
+            // rescale instead of one -- entry ((i, a), (j, b)) of H^-1 scales by s^(2R-1-a-b) when every duration is multiplied by s
+            double* const gc = a.gcache + (size_t)b * corridor_gcache_stride;
+            if (!reuse) {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+                    if (cidx[sl] < NRW) {
+                        const double* const row = GR(cidx[sl]);
+                        for (int i = 0; i < NRW; i += 2) *reinterpret_cast<double2_a*>(gc + cidx[sl] * NRW + i) = *reinterpret_cast<const double2_a*>(row + i);
+#pragma unroll
+                        for (int q = 0; q < R; ++q) { gc[NRW * NRW + cidx[sl] * 2 * R + q] = cv[sl][q]; gc[NRW * NRW + cidx[sl] * 2 * R + R + q] = wv[sl][q]; }
+                    }
+            } else {
+                const double sc = a.gscale[b];
+                double pw[R];                          // pw[q] = s^(2R-1-q)
+                pw[R - 1] = sc;
+#pragma unroll
+                for (int e = 1; e < R; ++e) pw[R - 1] *= sc;     // s^R
+#pragma unroll
+                for (int q = R - 2; q >= 0; --q) pw[q] = pw[q + 1] * sc;
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+                    if (cidx[sl] < NRW) {
+                        double* const row = GR(cidx[sl]);
+                        for (int i = 0; i < NRW; i += 2) {
+                            const double2 t = *reinterpret_cast<const double2_a*>(gc + cidx[sl] * NRW + i);
+                            *reinterpret_cast<double2_a*>(row + i) = make_double2(t.x * pw[0], t.y * pw[0]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < R; ++q) { cv[sl][q] = gc[NRW * NRW + cidx[sl] * 2 * R + q] * pw[q]; wv[sl][q] = gc[NRW * NRW + cidx[sl] * 2 * R + R + q] * pw[q]; }
+                    }
+            }
+            lds_publish();
+        }
         const int nrows = __builtin_amdgcn_readfirstlane(min(NRW, (kmax + 1) & ~1));   // tableau rows the wave touches (even)
 #ifdef UAVQP_DUAL_DEBUG
         // per trajectory (dealing position bq < 64): [0, 1024) G row-major [32][32];  [1024 + 96 ax + 32 what + col]: what 0 = p_unc, 1 = trips, 2 = p at the end

@@ -624,6 +624,7 @@ struct ReallocArgs {
     double v_max, a_max, max_stretch;
     double dead_band, overshoot;  // uavqp_settings.realloc_dead_band / realloc_overshoot
     int32_t* changed;
+    double* scale_acc;            // optional [n_traj]: multiplied by the factor applied (the pipeline's record of how far a trajectory was stretched)
 };
 
 template <int R>
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
             const double s = fmin(a.overshoot * ratio, a.max_stretch);
             for (int i = sub; i < M; i += LPT) a.times[s0 + i] *= s;
             ch = M;
+            if (a.scale_acc && sub == 0) a.scale_acc[b] *= s;
         }
         if (a.changed && sub == 0) a.changed[b] = ch;
     }
@@ -1327,7 +1329,8 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
                               const double* d_bc, const double* d_corr_lo, const double* d_corr_hi,
                               double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
                               uint64_t* d_active_set, int warm_start, long long total_segments, const int32_t* d_order_ready = nullptr,
-                              const int32_t* d_only_i32 = nullptr, const unsigned char* d_only_u8 = nullptr) {
+                              const int32_t* d_only_i32 = nullptr, const unsigned char* d_only_u8 = nullptr,
+                              double* d_gcache = nullptr, const double* d_gscale = nullptr, int gcache_mode = 0) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
     if (n_traj == 0) return UAVQP_OK;
     if (!d_waypoints || !d_times || !d_bc || !d_corr_lo || !d_corr_hi || !d_coeff_out || !d_status_out) return UAVQP_ERR_INVALID_ARG;
@@ -1346,6 +1349,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     a.pdas_rounds = warm_start ? ctx->settings.corridor_pdas_rounds_warm : (dual ? 0 : ctx->settings.corridor_pdas_rounds);
     a.guess_closed_form = (gmode != 0 && !dual) ? 1 : 0;
     a.only_i32 = d_only_i32; a.only_u8 = d_only_u8;
+    a.gcache = d_gcache; a.gscale = d_gscale; a.gcache_mode = (d_gcache && Mmax - 1 <= 24) ? gcache_mode : 0;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.coeff = d_coeff_out; a.status = d_status_out; a.iters = d_iters_out;
     // Persistent single-wave workgroups, one per SIMD (the sweep state of a lane pair lives in LDS: 4 x 40 KiB per CU),
@@ -1921,9 +1925,17 @@ extern "C" int uavqp_solve_rows_batch_host(uavqp_ctx* ctx, int r, int n_traj, in
     return UAVQP_OK;
 }
 
+static int time_reallocate_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                double* d_times, const double* d_coeff, double v_max, double a_max,
+                                int samples_per_seg, double max_stretch, int32_t* d_changed_out, double* d_scale_acc);
 extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
                                             double* d_times, const double* d_coeff, double v_max, double a_max,
                                             int samples_per_seg, double max_stretch, int32_t* d_changed_out) {
+    return time_reallocate_impl(ctx, r, n_traj, uniform_segments, d_seg_offsets, d_times, d_coeff, v_max, a_max, samples_per_seg, max_stretch, d_changed_out, nullptr);
+}
+static int time_reallocate_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                double* d_times, const double* d_coeff, double v_max, double a_max,
+                                int samples_per_seg, double max_stretch, int32_t* d_changed_out, double* d_scale_acc) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0 || !(v_max > 0.0) || !(a_max > 0.0) ||
         samples_per_seg < 1 || !(max_stretch > 1.0))
         return UAVQP_ERR_INVALID_ARG;
@@ -1933,7 +1945,7 @@ extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, i
     uavqp::ReallocArgs a;
     a.n_traj = n_traj; a.uniform = uniform_segments; a.samples = samples_per_seg;
     a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.v_max = v_max; a.a_max = a_max;
-    a.max_stretch = max_stretch; a.changed = d_changed_out;
+    a.max_stretch = max_stretch; a.changed = d_changed_out; a.scale_acc = d_scale_acc;
     a.dead_band = ctx->settings.realloc_dead_band; a.overshoot = ctx->settings.realloc_overshoot;
     long long grid_ll = ((long long)n_traj * 8 + 63) / 64;  // 8 lanes per trajectory
     if (grid_ll > (long long)ctx->num_cus * 32) grid_ll = (long long)ctx->num_cus * 32;

@@ -200,7 +200,11 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     const size_t o_as = o_fh + align256(sizeof(int32_t) * (size_t)n), o_rm = o_as + align256(sizeof(uint64_t) * 6 * (size_t)n);
     const size_t o_fl = o_rm + align256((size_t)n), o_or = o_fl + align256((size_t)n);
     const bool deal_by_length = uni == 0 && n >= 64 && ctx->settings.ragged_window_sort;
-    const size_t need = o_or + (deal_by_length ? length_order_bytes(n) : 0);
+    // G of the dual prelude across the rounds (the re-allocation multiplies all durations of a trajectory by one factor: G only rescales)
+    const bool g_across = ctx->settings.corridor_initial_guess == 2 && mx - 1 <= 24 && mx >= 2;
+    const size_t o_sc = o_or + (deal_by_length ? length_order_bytes(n) : 0);
+    const size_t o_gc = o_sc + (g_across ? align256(sizeof(double) * (size_t)n) : 0);
+    const size_t need = o_gc + (g_across ? align256(sizeof(double) * (size_t)n * uavqp::corridor_gcache_stride) : 0);
     int rc = ensure_pipe_ws(ctx, need);
     if (rc != UAVQP_OK) return rc;
     char* base = (char*)ctx->d_pipe;
@@ -209,6 +213,9 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     int32_t* d_changed = (int32_t*)(base + o_ch);
     int32_t* d_fh = d_first_hit ? d_first_hit : (int32_t*)(base + o_fh);
     uint64_t* d_active = (uint64_t*)(base + o_as);
+    double* d_scale = g_across ? (double*)(base + o_sc) : nullptr;     // factor by which every trajectory was stretched since its G was stored
+    double* d_gcache = g_across ? (double*)(base + o_gc) : nullptr;
+    int solves_done = 0;
     uint8_t* d_roomy = (uint8_t*)(base + o_rm);
     uint8_t* d_flag = (uint8_t*)(base + o_fl);
     uavqp::PipeCounters* h_cnt = (uavqp::PipeCounters*)ctx->h_pipe;
@@ -233,18 +240,23 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     // solve) a re-solve is a cold solve; with the other settings it is warm-started from the previous round as before.
     const bool cold_rounds = ctx->settings.corridor_initial_guess == 2 && (uni > 0 ? uni : mx) - 1 <= 32;
     auto corridor_solve = [&](int warm, const int32_t* only_i32 = nullptr, const unsigned char* only_u8 = nullptr) {
+        // first solve: every trajectory takes part, its G is stored; later solves load it and rescale by the stretch since then
+        const int gmode = (g_across && cold_rounds) ? (solves_done == 0 ? 1 : 2) : 0;
+        ++solves_done;
         return corridor_warm_impl(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_corr_lo, d_corr_hi, d_coeff_out,
-                                  d_status_out, d_iters, d_active, cold_rounds ? 0 : warm, total_segments, d_order, only_i32, only_u8);
+                                  d_status_out, d_iters, d_active, cold_rounds ? 0 : warm, total_segments, d_order, only_i32, only_u8,
+                                  d_gcache, d_scale, gmode);
     };
     auto reallocate = [&]() -> int {      // + count of the trajectories it stretched
-        int rc_ = uavqp_time_reallocate_device(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
-                                               P.max_stretch, d_changed);
+        int rc_ = time_reallocate_impl(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
+                                       P.max_stretch, d_changed, d_scale);
         if (rc_ != UAVQP_OK) return rc_;
         hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
         hipLaunchKernelGGL(uavqp::pipe_count_kernel, dim3(cgrid), dim3(256), 0, s, (const int32_t*)d_changed, (const int32_t*)nullptr, n, d_cnt);
         return read_counters();
     };
 
+    if (d_scale) hipLaunchKernelGGL(uavqp::fill_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_scale, n, 1.0);
     // 1. the reference's equality problem, 2. boxes from the cloud with the attitude of that solve
     rc = uavqp_solve_batch_device(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_coeff_out, d_status_out);
     if (rc != UAVQP_OK) return rc;
