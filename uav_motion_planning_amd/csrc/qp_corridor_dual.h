@@ -33,6 +33,18 @@
 
 namespace uavqp {
 
+// v_max_f64 / v_min_f64 as they are: fmax() / fmin() first quiet a possible signalling NaN of each operand (one extra v_max_f64 x, x
+// per operand and call -- a fifth of the selection and ratio-test instructions of a trip); the values here are never NaN-sensitive
+__device__ __forceinline__ double raw_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double raw_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -43,18 +55,18 @@ __device__ __forceinline__ double dpp_f64(double v) {
 // butterfly over the L lanes of a group (quad swaps, half-row mirror, row mirror): every lane ends with the result
 template <int L>
 __device__ __forceinline__ double group_max(double v) {
-    v = __builtin_fmax(v, dpp_f64<0xB1>(v));
-    v = __builtin_fmax(v, dpp_f64<0x4E>(v));
-    v = __builtin_fmax(v, dpp_f64<0x141>(v));
-    if (L == 16) v = __builtin_fmax(v, dpp_f64<0x140>(v));
+    v = raw_max(v, dpp_f64<0xB1>(v));
+    v = raw_max(v, dpp_f64<0x4E>(v));
+    v = raw_max(v, dpp_f64<0x141>(v));
+    if (L == 16) v = raw_max(v, dpp_f64<0x140>(v));
     return v;
 }
 template <int L>
 __device__ __forceinline__ double group_min(double v) {
-    v = __builtin_fmin(v, dpp_f64<0xB1>(v));
-    v = __builtin_fmin(v, dpp_f64<0x4E>(v));
-    v = __builtin_fmin(v, dpp_f64<0x141>(v));
-    if (L == 16) v = __builtin_fmin(v, dpp_f64<0x140>(v));
+    v = raw_min(v, dpp_f64<0xB1>(v));
+    v = raw_min(v, dpp_f64<0x4E>(v));
+    v = raw_min(v, dpp_f64<0x141>(v));
+    if (L == 16) v = raw_min(v, dpp_f64<0x140>(v));
     return v;
 }
 // a non-negative double with a 6-bit code in its low mantissa bits (order-preserving up to 64 ulp)
@@ -458,11 +470,11 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
                     const double below = lo[sl] - y[sl], above = y[sl] - hi[sl];
-                    const double v = fmax(below, above);
+                    const double v = raw_max(below, above);
                     const bool cand = valid[sl] && !inW[sl] && v > tol[sl] && dg[sl] > 0.0;
-                    const double kv = fmax(fmin(v * v * __builtin_amdgcn_rcp(dg[sl]), 1e299), eqb[sl]);
+                    const double kv = raw_max(raw_min(v * v * __builtin_amdgcn_rcp(dg[sl]), 1e299), eqb[sl]);
                     const double pk = pack_code(kv, (below > above ? 32 : 0) | cidx[sl]);
-                    key = fmax(key, cand ? pk : 0.0);
+                    key = raw_max(key, cand ? pk : 0.0);
                 }
                 key = group_max<L>(key);
                 if (!done && q < 0) {
@@ -501,8 +513,8 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
                 const bool blocks = sw[sl] * d[sl] > 0.0;
-                const double ratio = fmin(fmax(-y[sl] * rcp1(d[sl]), 0.0), 1e299);
-                rmin = fmin(rmin, blocks ? pack_code(ratio, cidx[sl]) : 1e300);
+                const double ratio = raw_min(raw_max(-y[sl] * rcp1(d[sl]), 0.0), 1e299);
+                rmin = raw_min(rmin, blocks ? pack_code(ratio, cidx[sl]) : 1e300);
             }
             rmin = group_min<L>(rmin);
             const bool partial = go && rmin < t1;

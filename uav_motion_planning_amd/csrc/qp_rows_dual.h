@@ -35,18 +35,18 @@ struct RowsDualArgs {
 };
 
 __device__ __forceinline__ double group_max32(double v) {
-    v = __builtin_fmax(v, dpp_f64<0xB1>(v));
-    v = __builtin_fmax(v, dpp_f64<0x4E>(v));
-    v = __builtin_fmax(v, dpp_f64<0x141>(v));
-    v = __builtin_fmax(v, dpp_f64<0x140>(v));
-    return __builtin_fmax(v, __shfl_xor(v, 16, 64));
+    v = raw_max(v, dpp_f64<0xB1>(v));
+    v = raw_max(v, dpp_f64<0x4E>(v));
+    v = raw_max(v, dpp_f64<0x141>(v));
+    v = raw_max(v, dpp_f64<0x140>(v));
+    return raw_max(v, __shfl_xor(v, 16, 64));
 }
 __device__ __forceinline__ double group_min32(double v) {
-    v = __builtin_fmin(v, dpp_f64<0xB1>(v));
-    v = __builtin_fmin(v, dpp_f64<0x4E>(v));
-    v = __builtin_fmin(v, dpp_f64<0x141>(v));
-    v = __builtin_fmin(v, dpp_f64<0x140>(v));
-    return __builtin_fmin(v, __shfl_xor(v, 16, 64));
+    v = raw_min(v, dpp_f64<0xB1>(v));
+    v = raw_min(v, dpp_f64<0x4E>(v));
+    v = raw_min(v, dpp_f64<0x141>(v));
+    v = raw_min(v, dpp_f64<0x140>(v));
+    return raw_min(v, __shfl_xor(v, 16, 64));
 }
 __device__ __forceinline__ double pack_code7(double v, int code) {
     return __longlong_as_double((__double_as_longlong(v) & ~127ll) | (long long)code);
@@ -56,20 +56,20 @@ __device__ __forceinline__ int code7_of(double v) { return (int)(__double_as_lon
 constexpr int rows_dual_lds_doubles(int R) { return 48 * 48 + 48 * 2 * R + 50 + 34 + 8 + 8 + 64; }   // G / chain records, functionals, column buffer, durations, scalars, masks, int tables
 
 __device__ __forceinline__ double wave_max64(double v) {
-    v = __builtin_fmax(v, dpp_f64<0xB1>(v));
-    v = __builtin_fmax(v, dpp_f64<0x4E>(v));
-    v = __builtin_fmax(v, dpp_f64<0x141>(v));
-    v = __builtin_fmax(v, dpp_f64<0x140>(v));
-    v = __builtin_fmax(v, __shfl_xor(v, 16, 64));
-    return __builtin_fmax(v, __shfl_xor(v, 32, 64));
+    v = raw_max(v, dpp_f64<0xB1>(v));
+    v = raw_max(v, dpp_f64<0x4E>(v));
+    v = raw_max(v, dpp_f64<0x141>(v));
+    v = raw_max(v, dpp_f64<0x140>(v));
+    v = raw_max(v, __shfl_xor(v, 16, 64));
+    return raw_max(v, __shfl_xor(v, 32, 64));
 }
 __device__ __forceinline__ double wave_min64(double v) {
-    v = __builtin_fmin(v, dpp_f64<0xB1>(v));
-    v = __builtin_fmin(v, dpp_f64<0x4E>(v));
-    v = __builtin_fmin(v, dpp_f64<0x141>(v));
-    v = __builtin_fmin(v, dpp_f64<0x140>(v));
-    v = __builtin_fmin(v, __shfl_xor(v, 16, 64));
-    return __builtin_fmin(v, __shfl_xor(v, 32, 64));
+    v = raw_min(v, dpp_f64<0xB1>(v));
+    v = raw_min(v, dpp_f64<0x4E>(v));
+    v = raw_min(v, dpp_f64<0x141>(v));
+    v = raw_min(v, dpp_f64<0x140>(v));
+    v = raw_min(v, __shfl_xor(v, 16, 64));
+    return raw_min(v, __shfl_xor(v, 32, 64));
 }
 
 template <int R, int K>
@@ -458,9 +458,9 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                 lds_publish();
                 // entering constraint: steepest dual ascent, violation^2 / T_qq
                 const double below = lo - y, above = y - hi;
-                const double viol = fmax(below, above);
+                const double viol = raw_max(below, above);
                 const bool cand = vc && !inW && viol > tol && dg > 0.0;
-                const double kv = fmax(fmin(viol * viol * __builtin_amdgcn_rcp(dg), 1e299), eqb);
+                const double kv = raw_max(raw_min(viol * viol * __builtin_amdgcn_rcp(dg), 1e299), eqb);
                 const double key = wave_max64(cand ? pack_code7(kv, (below > above ? 64 : 0) | c) : 0.0);
                 if (!(key > 1e-300) || trips >= max_trips) break;
                 const int cd = code7_of(key);
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                     const double d = sdir * CB[crd];
                     const double t1 = SC[0];
                     const bool blocks = sw * d > 0.0;
-                    const double ratio = fmin(fmax(-y * rcp1(d), 0.0), 1e299);
+                    const double ratio = raw_min(raw_max(-y * rcp1(d), 0.0), 1e299);
                     const double rmin = wave_min64(blocks ? pack_code7(ratio, c) : 1e300);
                     const bool partial = rmin < t1;
                     const double t = partial ? rmin : t1;
