@@ -69,6 +69,10 @@ def hermite_functional(r, T, tau, d):
 
 
 if have_dbg:
+    names = ["prologue", "forward chain", "backward + G", "axis set-up", "selection", "direction + ratio", "sweep", "hand-over"]
+    st = dump[:16, 3100:3109]
+    print("cycles per section (mean over the waves of the first 16 trajectories, %d trajectories in flight): " % n
+          + ", ".join("%s %.0f" % (nm, v) for nm, v in zip(names, st[:, :8].mean(axis=0))) + "; trips %.1f; total %.0f" % (st[:, 8].mean(), st[:, :8].sum(axis=1).mean()))
     print("box part of the starting set == box part of the final set for %d / %d problems" % (int(np.sum(np.all(box == res[2][3][:, :, :2], axis=2))), 3 * n))
     for k in range(min(n, 2)):
         T = b["times"][k]

@@ -48,8 +48,8 @@ __device__ __forceinline__ double raw_min(double a, double b) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);      // (every control used here reads a valid lane: no `old` value to keep, no copy)
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 // butterfly over the L lanes of a group (quad swaps, half-row mirror, row mirror): every lane ends with the result

@@ -34,65 +34,123 @@ struct RowsDualArgs {
 #endif
 };
 
-__device__ __forceinline__ double group_max32(double v) {
-    v = raw_max(v, dpp_f64<0xB1>(v));
-    v = raw_max(v, dpp_f64<0x4E>(v));
-    v = raw_max(v, dpp_f64<0x141>(v));
-    v = raw_max(v, dpp_f64<0x140>(v));
-    return raw_max(v, __shfl_xor(v, 16, 64));
-}
-__device__ __forceinline__ double group_min32(double v) {
-    v = raw_min(v, dpp_f64<0xB1>(v));
-    v = raw_min(v, dpp_f64<0x4E>(v));
-    v = raw_min(v, dpp_f64<0x141>(v));
-    v = raw_min(v, dpp_f64<0x140>(v));
-    return raw_min(v, __shfl_xor(v, 16, 64));
-}
 __device__ __forceinline__ double pack_code7(double v, int code) {
     return __longlong_as_double((__double_as_longlong(v) & ~127ll) | (long long)code);
 }
 __device__ __forceinline__ int code7_of(double v) { return (int)(__double_as_longlong(v) & 127ll); }
 
-constexpr int rows_dual_lds_doubles(int R) { return 48 * 48 + 48 * 2 * R + 50 + 34 + 8 + 8 + 64; }   // G / chain records, functionals, column buffer, durations, scalars, masks, int tables
+// debug build: cycles per section of the wave that solves one of the first 16 trajectories -> dbg[3100 + k]
+// (k: 0 prologue, 1 forward chain, 2 backward pass + G, 3 per-axis set-up, 4 selection, 5 direction + ratio test, 6 sweep, 7 hand-over; 8 = trips)
+#ifdef UAVQP_DUAL_DEBUG
+#define RD_T_DECL long long rd_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long rd_t = __builtin_readcyclecounter();
+#define RD_T(k) do { const long long n_ = __builtin_readcyclecounter(); rd_acc[k] += n_ - rd_t; rd_t = n_; } while (0)
+#else
+#define RD_T_DECL
+#define RD_T(k) do {} while (0)
+#endif
 
-__device__ __forceinline__ double wave_max64(double v) {
-    v = raw_max(v, dpp_f64<0xB1>(v));
-    v = raw_max(v, dpp_f64<0x4E>(v));
-    v = raw_max(v, dpp_f64<0x141>(v));
-    v = raw_max(v, dpp_f64<0x140>(v));
-    v = raw_max(v, __shfl_xor(v, 16, 64));
-    return raw_max(v, __shfl_xor(v, 32, 64));
+constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 + 48 * 2 * R + 34 + 8 + 64; }   // G / chain records (row stride 49), functionals, durations, masks, int tables
+
+typedef double v16d __attribute__((ext_vector_type(16)));
+// lane `src` (wave-uniform) of a double
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// x = [r0 r1 r2 r3] (the four DPP rows of a wave) -> a = [r0 r0 r0 r0], b = [r1 ...], c = [r2 ...]: v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second
+__device__ __forceinline__ void row_replicas32(unsigned x, unsigned& a, unsigned& b, unsigned& c) {
+    const auto p = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // [r0 r0 r2 r2], [r1 r1 r3 r3]
+    const auto u = __builtin_amdgcn_permlane32_swap(p[0], p[0], false, false); // [r0 r0 r0 r0], [r2 r2 r2 r2]
+    const auto w = __builtin_amdgcn_permlane32_swap(p[1], p[1], false, false); // [r1 r1 r1 r1], [r3 ...]
+    a = u[0]; c = u[1]; b = w[0];
+}
+__device__ __forceinline__ void row_replicas(double x, double& a, double& b, double& c) {
+    unsigned al, bl, cl, ah, bh, ch;
+    row_replicas32((unsigned)__double2loint(x), al, bl, cl);
+    row_replicas32((unsigned)__double2hiint(x), ah, bh, ch);
+    a = __hiloint2double((int)ah, (int)al); b = __hiloint2double((int)bh, (int)bl); c = __hiloint2double((int)ch, (int)cl);
+}
+// maximum / minimum over the wave, every lane ends with it, no LDS: DPP inside the rows, permlane swaps across them
+__device__ __forceinline__ void cross_rows(double v, double& p, double& q) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    p = __hiloint2double((int)h[0], (int)l[0]); q = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ void cross_halves(double v, double& p, double& q) {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    p = __hiloint2double((int)h[0], (int)l[0]); q = __hiloint2double((int)h[1], (int)l[1]);
+}
+// acc += (lane I of the own DPP row of t) * ns, one instruction (v_fmac_f64 takes DPP row_newbcast on gfx90a and later)
+// (a VGPR written by the VALU must be two wait states old before a DPP operand reads it, and the compiler's hazard recogniser does not
+// look into the string: the first instruction of a run carries its own s_nop)
+template <int I, bool FIRST = false>
+__device__ __forceinline__ double fmac_rowbcast(double acc, double t, double ns) {
+    if (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(ns), "n"(I));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(ns), "n"(I));
+    return acc;
+}
+// row kq (wave-uniform) of a column held as three 16-row vectors
+__device__ __forceinline__ double pick_row(const v16d A0, const v16d A1, const v16d A2, int kq) {
+    const int e = kq & 15;
+    const double x0 = A0[e], x1 = A1[e], x2 = A2[e];
+    return kq < 16 ? x0 : (kq < 32 ? x1 : x2);
+}
+__device__ __forceinline__ void sweep16(v16d& A, double t, double ns) {
+    A[0] = fmac_rowbcast<0, true>(A[0], t, ns);   A[1] = fmac_rowbcast<1>(A[1], t, ns);   A[2] = fmac_rowbcast<2>(A[2], t, ns);   A[3] = fmac_rowbcast<3>(A[3], t, ns);
+    A[4] = fmac_rowbcast<4>(A[4], t, ns);   A[5] = fmac_rowbcast<5>(A[5], t, ns);   A[6] = fmac_rowbcast<6>(A[6], t, ns);   A[7] = fmac_rowbcast<7>(A[7], t, ns);
+    A[8] = fmac_rowbcast<8>(A[8], t, ns);   A[9] = fmac_rowbcast<9>(A[9], t, ns);   A[10] = fmac_rowbcast<10>(A[10], t, ns); A[11] = fmac_rowbcast<11>(A[11], t, ns);
+    A[12] = fmac_rowbcast<12>(A[12], t, ns); A[13] = fmac_rowbcast<13>(A[13], t, ns); A[14] = fmac_rowbcast<14>(A[14], t, ns); A[15] = fmac_rowbcast<15>(A[15], t, ns);
+}
+
+// maximum of a 32-bit key over the wave (the entering constraint: a float's bits with the column in the low mantissa bits)
+template <int CTRL>
+__device__ __forceinline__ unsigned umax_dpp(unsigned v) {
+    return max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = umax_dpp<0xB1>(v);
+    v = umax_dpp<0x4E>(v);
+    v = umax_dpp<0x141>(v);
+    v = umax_dpp<0x140>(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = max(r[0], r[1]);
+    const auto h = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return max(h[0], h[1]);
 }
 __device__ __forceinline__ double wave_min64(double v) {
     v = raw_min(v, dpp_f64<0xB1>(v));
     v = raw_min(v, dpp_f64<0x4E>(v));
     v = raw_min(v, dpp_f64<0x141>(v));
     v = raw_min(v, dpp_f64<0x140>(v));
-    v = raw_min(v, __shfl_xor(v, 16, 64));
-    return raw_min(v, __shfl_xor(v, 32, 64));
+    double p, q;
+    cross_rows(v, p, q);
+    v = raw_min(p, q);
+    cross_halves(v, p, q);
+    return raw_min(p, q);
 }
 
 template <int R, int K>
 __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int max_trips_extra) {
     const RowsArgs& a = aa.r;
-    constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, RS = 48;
-    constexpr int O_GF = NRW * RS, O_CB = O_GF + NRW * 2 * R, O_TB = O_CB + 50, O_SC = O_TB + 34, O_MK = O_SC + 8, O_IT = O_MK + 8;
+    // (row stride 49 doubles: lane c writes the mirror entry G[c][i] into ROW c -- with a stride of 48 the 48 lanes hit two bank pairs, a
+    // 24-way conflict per write; with 49 it is two-way -- and reads its column G[.][c] from consecutive addresses)
+    constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, RS = 49;
+    constexpr int O_GF = NRW * RS, O_TB = O_GF + NRW * 2 * R, O_MK = O_TB + 34, O_IT = O_MK + 8;
     static_assert(NE + R * R <= RS, "a chain record fits a slot");
-    static_assert(O_GF % 2 == 0 && O_CB % 2 == 0 && O_TB % 2 == 0 && O_IT % 2 == 0, "16-byte aligned rows");
+    static_assert(O_GF % 2 == 0 && O_TB % 2 == 0 && O_IT % 2 == 0, "8-byte tables on even offsets");
     __shared__ __attribute__((aligned(16))) double sg[rows_dual_lds_doubles(R)];
     using Inv = SmallLDL<R>;
     const int lane = threadIdx.x, c = lane;
     double* const GF = sg + O_GF;      // [48][2 R]: g_l, g_r of every constraint (a box: e_0, 0)
-    double* const CB = sg + O_CB;      // [50]: the pivot's column; element 48 is a constant zero
     double* const TB = sg + O_TB;      // [33]: durations
-    double* const SC = sg + O_SC;
     unsigned long long* const MK = reinterpret_cast<unsigned long long*>(sg + O_MK);
     int* const KT = reinterpret_cast<int*>(sg + O_IT);       // [34] per knot: first constraint that sits there | count << 8
     int* const CD = KT + 34;                                   // [48] per constraint: left knot | kind << 8 (0 box, 1 + slot) | segment << 12
     int* const CNT = CD + 48;                                  // [33] rows per segment
     auto ES = [&](int k) -> double* { return sg + (k - 1) * RS; };
     auto GR = [&](int i) -> double* { return sg + i * RS; };
-    const int crd = c < NRW ? c : NRW, crow = min(c, NRW - 1);
+    const int crow = min(c, NRW - 1);
 
     for (long long bq = blockIdx.x; bq < a.n_traj; bq += gridDim.x) {
         const int b = aa.order ? aa.order[bq] : (int)bq;
@@ -103,6 +161,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         const bool shape_ok = M >= 2 && M <= 32 && (a.uniform > 0 || M <= a.max_segments);
         if (!shape_ok) { if (lane == 0) aa.need_phase1[b] = 1; continue; }
         const int n = M - 1;
+        RD_T_DECL
         lds_publish();
         // ---------------- lane s prepares segment s: the functionals of its rows ----------------
         const bool myseg = lane < M;
@@ -170,11 +229,10 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         }
         lds_publish();
 
+        RD_T(0);
         // ---------------- forward: block LDL' chain (one trajectory per wave: every lane computes it, lane 0 stores the records) ----------------
-        FullBlocks<R> sa, seg0, segl;
+        FullBlocks<R> sa;
         sa.build(TB[0]);
-        seg0 = sa;
-        segl.build(TB[M - 1]);
         Inv lprev;
         LDLPack<R>::zero(lprev);
 #pragma unroll 1
@@ -247,6 +305,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             sa = sb;
         }
         lds_publish();
+        RD_T(1);
 
         // ---------------- backward: z_c = H^-1 c_c at and above its knots, the entries of G that do not sit behind it ----------------
         const bool vc = c < NC;
@@ -262,24 +321,51 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
 #pragma unroll
             for (int q = 0; q < R; ++q) { Zk1[i][q] = 0.0; Zkn[i][q] = 0.0; Ek[i][q] = 0.0; }
         }
-#pragma unroll 1
-        for (int k = n; k >= 1; --k) {
-            double Si[R][R], Em[R][R];      // S_k^-1, E_{k-1}
+        // One knot of the backward pass.  Its LDS operands -- the chain record (S_k^-1, E_{k-1}), the knot's constraint table entry and the
+        // functionals of its first K + 1 constraints -- are loaded one knot ahead (two register sets, the loop below alternates between
+        // them): this phase is issue-bound (the 3 x 3 recursions are the same in every lane), and every exposed LDS round trip -- the compiler
+        // cannot move a load above the G rows written just before it -- was ~10 % on top.
+        constexpr bool PF = R == 3;     // (r = 4: the second register set does not fit beside the 4 x 4 recursions)
+        struct KnotOps {
+            double Si[NE], Em[R][R];
+            int kt;
+        };
+        auto load_ops = [&](int k, KnotOps& o) __attribute__((always_inline)) {
+            const double* const rec = ES(k);
+#pragma unroll
+            for (int f = 0; f < NE; ++f) o.Si[f] = rec[f];
+            const double* const recm = ES(k >= 2 ? k - 1 : 1);
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int q = 0; q < R; ++q) o.Em[i][q] = k >= 2 ? recm[NE + i * R + q] : 0.0;
+            o.kt = KT[k];
+        };
+        auto knot = [&](int k, const KnotOps& o, KnotOps& nx) __attribute__((always_inline)) {
+            if (PF && k >= 2) load_ops(k - 1, nx);
+            const int kt = __builtin_amdgcn_readfirstlane(o.kt);
+            const int cf = kt & 255, cnt = (kt >> 8) & 255;
+            int cdv[K + 1];
+            double gfv[K + 1][2 * R];
+#pragma unroll
+            for (int t = 0; t <= K; ++t) {
+                const int i = min(cf + t, NRW - 1);
+                cdv[t] = CD[i];
+#pragma unroll
+                for (int p = 0; p < 2 * R; p += 2) {
+                    const double2 g2 = *reinterpret_cast<const double2_a*>(GF + i * 2 * R + p);
+                    gfv[t][p] = g2.x; gfv[t][p + 1] = g2.y;
+                }
+            }
+            lds_publish();      // (everything this knot and the record of the next read is on its way before rows of G are written over older slots)
+            double Si[R][R];
             {
-                const double* const rec = ES(k);
                 int f = 0;
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q <= i; ++q) { Si[i][q] = rec[f]; Si[q][i] = Si[i][q]; ++f; }
-                const double* const recm = ES(k >= 2 ? k - 1 : 1);
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int q = 0; q < R; ++q) Em[i][q] = k >= 2 ? recm[NE + i * R + q] : 0.0;
+                    for (int q = 0; q <= i; ++q) { Si[i][q] = o.Si[f]; Si[q][i] = o.Si[f]; ++f; }
             }
-            const int kt = KT[k];
-            lds_publish();
             double P[R][R], Zkk[R][R];
 #pragma unroll
             for (int i = 0; i < R; ++i)
@@ -324,7 +410,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             for (int i = 0; i < R; ++i) {
                 double t = gRc[i];
 #pragma unroll
-                for (int p = 0; p < R; ++p) t -= Em[p][i] * gLc[p];      // g_r - E_{k-1}' g_l   (E_0 = 0: a row of segment 0 has no variable on its left)
+                for (int p = 0; p < R; ++p) t -= o.Em[p][i] * gLc[p];      // g_r - E_{k-1}' g_l   (E_0 = 0: a row of segment 0 has no variable on its left)
                 inj1[i] = dR * t;
                 inj2[i] = dL * gLc[i];
                 wg[i] = dR * gRc[i] + dL * gLc[i];
@@ -341,15 +427,28 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                 wv[i] = w;
             }
             // entries of G: constraints that sit at knot k against every column that does not sit in front of them
-            const int cf = kt & 255, cnt = (kt >> 8) & 255;
-            for (int t = 0; t < cnt; ++t) {
+#pragma unroll
+            for (int t = 0; t <= K; ++t) {
+                if (t < cnt) {
+                    const int i = cf + t;
+                    const int kLi = cdv[t] & 255;
+                    double val = 0.0;
+#pragma unroll
+                    for (int p = 0; p < R; ++p) val += kLi == k ? (gfv[t][p] * vn[p] + gfv[t][R + p] * v[p]) : gfv[t][R + p] * vn[p];   // (kLi = 0 at k = 1: only its right knot is a variable)
+                    if (vc && kLi <= kLc) {
+                        GR(i)[c] = val;
+                        GR(c)[i] = val;
+                    }
+                }
+            }
+            for (int t = K + 1; t < cnt; ++t) {      // (knot 1 also hosts the rows of segment 0)
                 const int i = cf + t;
                 const int kLi = CD[i] & 255;
                 double val = 0.0;
 #pragma unroll
                 for (int p = 0; p < R; ++p) {
                     const double ga = GF[i * 2 * R + p], gb = GF[i * 2 * R + R + p];
-                    val += kLi == k ? (ga * vn[p] + gb * v[p]) : gb * vn[p];      // (kLi = 0 at k = 1: only its right knot is a variable)
+                    val += kLi == k ? (ga * vn[p] + gb * v[p]) : gb * vn[p];
                 }
                 if (vc && kLi <= kLc) {
                     GR(i)[c] = val;
@@ -360,7 +459,23 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             for (int i = 0; i < R; ++i) {
                 v[i] = vn[i];
 #pragma unroll
-                for (int q = 0; q < R; ++q) { Zk1[i][q] = Zkk[i][q]; Ek[i][q] = Em[i][q]; }
+                for (int q = 0; q < R; ++q) { Zk1[i][q] = Zkk[i][q]; Ek[i][q] = o.Em[i][q]; }
+            }
+        };
+        if constexpr (PF) {
+            KnotOps oa, ob;
+            load_ops(n, oa);
+#pragma unroll 1
+            for (int k = n; k >= 1; k -= 2) {
+                knot(k, oa, ob);
+                if (k >= 2) knot(k - 1, ob, oa);
+            }
+        } else {
+#pragma unroll 1
+            for (int k = n; k >= 1; --k) {
+                KnotOps oa;
+                load_ops(k, oa);
+                knot(k, oa, oa);
             }
         }
         // rows and columns beyond the constraints hold what the chain records left there: they must be neutral in the sweeps
@@ -369,12 +484,15 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
 #pragma unroll 1
             for (int i = c >= NC ? 0 : NC; i < NRW; ++i) row[i] = 0.0;
         }
-        if (lane == 0) { CB[NRW] = 0.0; CB[NRW + 1] = 0.0; }
         lds_publish();
+        RD_T(2);
 
         // ---------------- per axis: unconstrained value and bounds of this lane's constraint ----------------
         double y0[3], lo3[3], hi3[3];
         {
+            FullBlocks<R> seg0, segl;
+            seg0.build(TB[0]);
+            segl.build(TB[M - 1]);
             const int kind = (cdc >> 8) & 15, seg = (cdc >> 12) & 255;
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
@@ -429,7 +547,16 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
 #endif
 
         // ---------------- the three axes: the dual method, every branch wave-uniform ----------------
-        double A[NRW];
+        // The tableau column of this lane: three 16-row register vectors (contiguous registers: a row picked by a wave-uniform run-time
+        // index is one s_set_gpr_idx move).  The tableau stays symmetric under the sweeps, so everything a trip needs of the pivot's
+        // COLUMN is the pivot's ROW entry every lane already holds -- no column travels through LDS:
+        //   * direction d_c = T[q][c] and pivot-row entry t_c = T[k][c]: own_row(q), own_row(k);
+        //   * the sweep's u_i = T[i][k] = t_i of lane i: three replicas of t (columns 0-15 / 16-31 / 32-47 copied into all four DPP
+        //     rows by two permlane swaps each) feed v_fmac_f64 ... row_newbcast:i -- ONE instruction per tableau row and lane.
+        // (first version: the owner wrote its column to LDS, 24 ds_write_b128 + 24 broadcast ds_read_b128 per trip and wave; with 7
+        // waves per CU the LDS pipe was ~45 % busy and a trip cost 4.5 k cycles: tools/rows_dual_gpu_probe.py stamps)
+        v16d A0, A1, A2;
+#define own_row(kq) pick_row(A0, A1, A2, (kq))
         const int max_trips = 4 * NC + 16 + max_trips_extra;
 #pragma unroll 1
         for (int axis = 0; axis < 3; ++axis) {
@@ -442,86 +569,79 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             bool inW = false;
             lds_publish();
             {
-                const double* const row = GR(crow);
+                const double* const col = sg + crow;     // column c of G (lanes 48..63 carry a copy of column 47: nothing ever reads them)
 #pragma unroll
-                for (int i = 0; i < NRW; i += 2) {
-                    const double2 tt = *reinterpret_cast<const double2_a*>(row + i);
-                    A[i] = tt.x;
-                    A[i + 1] = tt.y;
+                for (int i = 0; i < 16; ++i) {
+                    A0[i] = col[i * RS];
+                    A1[i] = col[(16 + i) * RS];
+                    A2[i] = col[(32 + i) * RS];
                 }
             }
 #ifdef UAVQP_DUAL_DEBUG
             if (dbg && vc) dbg[2304 + 192 * axis + c] = y;
 #endif
             int trips = 0;
+            RD_T(3);
             for (;;) {
-                lds_publish();
                 // entering constraint: steepest dual ascent, violation^2 / T_qq
                 const double below = lo - y, above = y - hi;
                 const double viol = raw_max(below, above);
                 const bool cand = vc && !inW && viol > tol && dg > 0.0;
-                const double kv = raw_max(raw_min(viol * viol * __builtin_amdgcn_rcp(dg), 1e299), eqb);
-                const double key = wave_max64(cand ? pack_code7(kv, (below > above ? 64 : 0) | c) : 0.0);
-                if (!(key > 1e-300) || trips >= max_trips) break;
-                const int cd = code7_of(key);
-                const int q = __builtin_amdgcn_readfirstlane(cd & 63);
+                // (the choice among the violated constraints is a heuristic: ranked in single precision, 17 bits of it, equality rows first)
+                const float kf = eqb != 0.0 ? 3.0e38f : (float)raw_min(viol * viol * __builtin_amdgcn_rcp(dg), 1e38);
+                const unsigned key = wave_umax(cand ? ((__float_as_uint(kf) & ~127u) | (unsigned)((below > above ? 64 : 0) | c)) : 0u);
+                const int cd = __builtin_amdgcn_readfirstlane((int)key);
+                if (cd < 128 || trips >= max_trips) break;
+                const int q = cd & 63;
                 const double sdir = (cd & 64) ? 1.0 : -1.0;
                 double muq = 0.0;
+                RD_T(4);
                 // the constraint moves towards its bound until it reaches it (it enters) -- each time a multiplier of the working set would
                 // change sign first, that constraint leaves and the move goes on
+                double aq = own_row(q);
                 for (;;) {
-                    lds_publish();
-                    if (c == q) {
-#pragma unroll
-                        for (int i = 0; i < NRW; i += 2) *reinterpret_cast<double2_a*>(CB + i) = make_double2(A[i], A[i + 1]);
-                        const double pv = rcp1(dg);
-                        CB[q] = dg;
-                        SC[0] = ((sdir > 0.0 ? lo : hi) - y) * sdir * pv;
-                        SC[1] = pv;
-                    }
-                    lds_publish();
-                    const double d = sdir * CB[crd];
-                    const double t1 = SC[0];
+                    const double d = sdir * (c == q ? dg : aq);
+                    const double pvl = rcp1(dg);
+                    const double t1 = readlane_f64(((sdir > 0.0 ? lo : hi) - y) * sdir * pvl, q);
                     const bool blocks = sw * d > 0.0;
                     const double ratio = raw_min(raw_max(-y * rcp1(d), 0.0), 1e299);
                     const double rmin = wave_min64(blocks ? pack_code7(ratio, c) : 1e300);
-                    const bool partial = rmin < t1;
+                    const bool partial = __builtin_amdgcn_readfirstlane((int)(rmin < t1)) != 0;
                     const double t = partial ? rmin : t1;
-                    const int kp = __builtin_amdgcn_readfirstlane(partial ? (code7_of(rmin) & 63) : q);
+                    const int kp = partial ? (__builtin_amdgcn_readfirstlane(code7_of(rmin)) & 63) : q;
                     y = fma(t, d, y);
                     muq = fma(sdir, t, muq);
-                    if (partial) {
-                        lds_publish();
-                        if (c == kp) {
-#pragma unroll
-                            for (int i = 0; i < NRW; i += 2) *reinterpret_cast<double2_a*>(CB + i) = make_double2(A[i], A[i + 1]);
-                            SC[1] = rcp1(dg);
-                        }
-                    }
-                    if (c == kp) CB[kp] = dg - (partial ? -1.0 : 1.0);
-                    lds_publish();
+                    RD_T(5);
+                    // sweep on the pivot kp: the constraint q enters (full step) or the blocking one leaves (partial step)
+                    const bool pc = c == kp;
+                    const double ak = partial ? own_row(kp) : aq;
+                    const double tc = pc ? dg - (partial ? -1.0 : 1.0) : ak;      // (entering: T_qq > 0; leaving: -[G_WW^-1]_kk < 0)
+                    const double piv = readlane_f64(pvl, kp);
+                    const double sc = tc * piv;                                    // (pivot column: (t_k - sign) / t_k = 1 - 1 / |t_k|, by the patch)
+                    const double dn = fma(-tc, sc, dg);
+                    dg = pc ? -piv : dn;
+                    const double yb = sw < 0.0 ? hi : lo;
+                    y = pc ? (partial ? yb : -muq) : y;
+                    sw = pc ? ((partial || eqb != 0.0) ? 0.0 : sdir) : sw;
+                    inW = pc ? !partial : inW;
                     {
-                        const double piv = SC[1];
-                        const double tc = CB[crd];
-                        const bool pc = c == kp;
-                        const double s = tc * piv;
-                        const double dn = fma(-tc, s, dg);
-                        dg = pc ? -piv : dn;
-                        const double yb = sw < 0.0 ? hi : lo;
-                        y = pc ? (partial ? yb : -muq) : y;
-                        sw = pc ? ((partial || eqb != 0.0) ? 0.0 : sdir) : sw;
-                        inW = pc ? !partial : inW;
-#pragma unroll
-                        for (int i = 0; i < NRW; i += 2) {   // (all 48 rows: rows beyond the constraints are zero in every column -- a guard on the row count compiled to 96 selects)
-                            const double2 u = *reinterpret_cast<const double2_a*>(CB + i);
-                            A[i] = fma(-u.x, s, A[i]);
-                            A[i + 1] = fma(-u.y, s, A[i + 1]);
-                        }
+                        double ta, tb, tcc;
+                        row_replicas(tc, ta, tb, tcc);
+                        const double ns = -sc;
+                        sweep16(A0, ta, ns);
+                        sweep16(A1, tb, ns);
+                        sweep16(A2, tcc, ns);
                     }
                     ++trips;
+                    RD_T(6);
                     if (!partial || trips >= max_trips) break;
+                    aq = own_row(q);
                 }
             }
+            RD_T(4);
+#ifdef UAVQP_DUAL_DEBUG
+            rd_acc[8] += trips;
+#endif
             // ---- hand the working set of this axis over in the rows kernel's layout: boxes by interior knot, rows by slot and segment
             lds_publish();
             if (lane < 2 + 2 * K) MK[lane] = 0ull;
@@ -545,7 +665,11 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
 #pragma unroll
                 for (int j = 0; j < 2 * K; ++j) aa.warm_rows[2 * K * prob + j] = MK[2 + j];
             }
+            RD_T(7);
         }
+#ifdef UAVQP_DUAL_DEBUG
+        if (dbg && lane == 0) for (int k_ = 0; k_ < 9; ++k_) dbg[3100 + k_] = (double)rd_acc[k_];
+#endif
     }
 }
 
