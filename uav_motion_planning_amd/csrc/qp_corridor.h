@@ -65,6 +65,8 @@ struct CorridorArgs {
     double* gcache;                // [n_traj][corridor_gcache_stride]
     const double* gscale;          // [n_traj]
     int gcache_mode;
+    int fused_emit;                // 1: corridor_solve_kernel writes the polynomials itself when a problem is done (and corridor_prep_kernel those of the
+                                   // one-segment trajectories); 0: it leaves the Hermite solution in xsol for corridor_emit_kernel (the rows solvers' path)
     int guess_closed_form;         // 1: corridor_prep_kernel fills `guess` with the closed-form set; 0: it only zeroes it (corridor_dual_kernel, qp_corridor_dual.h, writes it)
 #ifdef UAVQP_DUAL_DEBUG
     double* dbg;                   // debug build only (tools/corridor_dual_gpu_probe.py): G, unconstrained minimisers, trip counts of the first trajectories
@@ -297,8 +299,20 @@ __global__ __launch_bounds__(256) void corridor_prep_kernel(CorridorArgs a) {
             g_up &= g_act;
         }
         if (!ok) atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
-        // no interior knot (M = 1): nothing to solve, the emission kernel builds the segment from the boundary data
+        // no interior knot (M = 1): nothing to solve, the segment follows from the boundary data (here, or in the emission kernel)
         if (ok && M == 1 && a.active) { a.active[2 * q] = 0ull; a.active[2 * q + 1] = 0ull; }
+        if (ok && M == 1 && a.fused_emit) {   // (validity of a one-segment trajectory is its duration: the same verdict on all three axes)
+            const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+            double ys[ND], ye[ND], c1[NC];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) { ys[d] = bc[d * 3]; ye[d] = bc[(ND + d) * 3]; }
+            const double Tk = T[0];
+            segment_coeffs_det<R>(a.waypoints[base3], ys, a.waypoints[base3 + 3], ye, Tk, fast_rcp(Tk), c1);
+            if (!((fabs(c1[NC - 1]) < INFINITY) && (fabs(c1[R]) < INFINITY))) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+            double* o = a.coeff + ((size_t)3 * s0 + ax) * NC;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) o[j] = c1[j];
+        }
         a.desc[q] = (ok && M >= 2) ? (eq | 1ull) : 0ull;
         if (a.guess) {
             a.guess[2 * q] = (ok && M >= 2) ? g_act : 0ull;
@@ -461,7 +475,10 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                         const long long gn = 3LL * bn + ax;
                         // everything a new problem needs is fetched by INDEPENDENT loads (one round trip); validation and
                         // the equality rows come ready-made from corridor_prep_kernel
-                        const unsigned long long dsc = a.desc[gn];
+                        unsigned long long dsc = a.desc[gn];
+                        // (a trajectory with an invalid axis is left untouched as a whole: with the emission in this kernel its other axes must not be solved)
+                        const int32_t st_in = a.fused_emit ? a.status[bn] : (int32_t)UAVQP_SOLVED;
+                        if (st_in == (int32_t)UAVQP_INVALID_INPUT) dsc = 0ull;
                         int sn, Mn;
                         if (a.uniform > 0) { Mn = a.uniform; sn = bn * Mn; } else { sn = a.seg_offsets[bn]; Mn = a.seg_offsets[bn + 1] - sn; }
                         unsigned long long wpin = 0ull, wupper = 0ull;
@@ -956,25 +973,85 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
 #endif
         // ================= a finished pair hands over its Hermite solution and frees its slot =================
         if (__ballot(done) != 0ull) {
-            for (int s = 0; s < mmax; ++s) {   // slot s = own knot m - s
-                const int j = mm - s;
-                if (done && j >= 1 && (s > 0 || !isR)) {  // the meeting knot is written by the L lane
-                    const int kk = korig(j);
-                    double xs[R], zs;
-                    if (in_lds(s)) {
+            if (!a.fused_emit) {
+                for (int s = 0; s < mmax; ++s) {   // slot s = own knot m - s
+                    const int j = mm - s;
+                    if (done && j >= 1 && (s > 0 || !isR)) {  // the meeting knot is written by the L lane
+                        const int kk = korig(j);
+                        double xs[R], zs;
+                        if (in_lds(s)) {
 #pragma unroll
-                        for (int q = 0; q < R; ++q) xs[q] = L(s, F_X + q);
-                        zs = L(s, F_Z);
-                    } else {
+                            for (int q = 0; q < R; ++q) xs[q] = L(s, F_X + q);
+                            zs = L(s, F_Z);
+                        } else {
 #pragma unroll
-                        for (int q = 0; q < R; ++q) xs[q] = G(s, F_X + q);
-                        zs = G(s, F_Z);
+                            for (int q = 0; q < R; ++q) xs[q] = G(s, F_X + q);
+                            zs = G(s, F_Z);
+                        }
+                        if (bit(pin, kk)) xs[0] = zs;  // pinned positions: exact bound value
+                        double* o = a.xsol + (base3 + 3LL * kk) * R;
+#pragma unroll
+                        for (int q = 0; q < R; ++q) o[q] = (isR && (q & 1)) ? -xs[q] : xs[q];  // back to the original frame
                     }
-                    if (bit(pin, kk)) xs[0] = zs;  // pinned positions: exact bound value
-                    double* o = a.xsol + (base3 + 3LL * kk) * R;
-#pragma unroll
-                    for (int q = 0; q < R; ++q) o[q] = (isR && (q & 1)) ? -xs[q] : xs[q];  // back to the original frame
                 }
+            } else {
+                // The polynomials of the own segments, straight from the sweep state: own segment j joins own knots j and j + 1 -- walking the
+                // slots from the meeting knot outwards, the previous slot is the segment's other end; own knot 0 is the boundary knot (x0).  The
+                // same segment_coeffs on the same numbers corridor_emit_kernel would read back from xsol (Hermite data in the ORIGINAL frame:
+                // the reversed lane flips the odd derivatives and swaps the ends), so the coefficients are bit-identical to the two-kernel
+                // path; what is saved is the round trip of the Hermite solution through HBM and a launch (round 4: 55 us of config 3's 530).
+                constexpr int NC = 2 * R;
+                const bool al16 = (reinterpret_cast<uintptr_t>(a.coeff) & 15u) == 0;
+                double xn[R];
+#pragma unroll
+                for (int q = 0; q < R; ++q) xn[q] = 0.0;
+                bool finite = true;
+                for (int s = 0; s <= mmax; ++s) {
+                    const int j = mm - s;
+                    double xo[R];
+#pragma unroll
+                    for (int q = 0; q < R; ++q) xo[q] = x0[q];
+                    if (s < mmax) {
+                        const int kk = korig(j);
+                        double xs[R], zs;
+                        if (in_lds(s)) {
+#pragma unroll
+                            for (int q = 0; q < R; ++q) xs[q] = L(s, F_X + q);
+                            zs = L(s, F_Z);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < R; ++q) xs[q] = G(s, F_X + q);
+                            zs = G(s, F_Z);
+                        }
+                        if (bit(pin, kk)) xs[0] = zs;  // pinned positions: exact bound value
+                        if (j >= 1) {
+#pragma unroll
+                            for (int q = 0; q < R; ++q) xo[q] = xs[q];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 1; q < R; q += 2) xo[q] = isR ? -xo[q] : xo[q];     // back to the original frame
+                    if (done && j >= 0 && s >= 1) {
+                        const int seg = isR ? M - 1 - j : j;                          // original segment of own segment j
+                        double ys[ND], ye[ND], c[NC];
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) { ys[d] = isR ? xn[d + 1] : xo[d + 1]; ye[d] = isR ? xo[d + 1] : xn[d + 1]; }
+                        const double Tk = TT[seg];
+                        segment_coeffs_det<R>(isR ? xn[0] : xo[0], ys, isR ? xo[0] : xn[0], ye, Tk, fast_rcp(Tk), c);
+                        finite = finite && (fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY);
+                        double* o = a.coeff + ((size_t)3 * s0 + (size_t)axis * M + seg) * NC;
+                        if (al16) {
+#pragma unroll
+                            for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(o + q) = make_double2(c[q], c[q + 1]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < NC; ++q) o[q] = c[q];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < R; ++q) xn[q] = xo[q];
+                }
+                if (done && !finite) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
             }
             if (done && !isR) {
                 if (final_pass) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
@@ -1058,7 +1135,7 @@ __global__ __launch_bounds__(256) void corridor_emit_kernel(CorridorArgs a, long
                     for (int d = 0; d < ND; ++d) ye[d] = x[d + 1];
                 }
                 const double Tk = a.times[s0 + k];
-                segment_coeffs<R>(p0, ys, p1, ye, Tk, fast_rcp(Tk), c);
+                segment_coeffs_det<R>(p0, ys, p1, ye, Tk, fast_rcp(Tk), c);
                 if (!((fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY))) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
             }
         }

@@ -265,6 +265,50 @@ __device__ __forceinline__ void segment_coeffs(double p0, const double (&ys)[R -
     }
 }
 
+// The same arithmetic with every fused multiply-add spelled out and contraction off: the result does not depend on the code the function
+// is inlined into.  The corridor path emits from three places (corridor_prep_kernel: one-segment trajectories, corridor_solve_kernel in
+// its template variants, corridor_emit_kernel behind the rows solvers) and their polynomials must agree to the bit for the same Hermite data.
+template <int R>
+__device__ __forceinline__ void segment_coeffs_det(double p0, const double (&ys)[R - 1], double p1,
+                                                   const double (&ye)[R - 1], double T, double it,
+                                                   double (&c)[2 * R]) {
+#pragma clang fp contract(off)
+    double tp[R];  // T^d
+    tp[0] = 1.0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) tp[d] = tp[d - 1] * T;
+    double s0[R], s1[R];
+    s0[0] = 0.0;
+    s1[0] = p1 - p0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) {
+        s0[d] = tp[d] * ys[d - 1];
+        s1[d] = tp[d] * ye[d - 1];
+    }
+    double e[R];
+#pragma unroll
+    for (int d = 0; d < R; ++d) {
+        double acc = s1[d];
+#pragma unroll
+        for (int k = (d > 1 ? d : 1); k < R; ++k) acc = fma(-s0[k], inv_fact(k - d), acc);
+        e[d] = acc;
+    }
+    c[0] = p0;
+#pragma unroll
+    for (int d = 1; d < R; ++d) c[d] = ys[d - 1] * inv_fact(d);
+    double ipw = 1.0;
+#pragma unroll
+    for (int d = 0; d < R; ++d) ipw *= it;  // T^-R
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        double q = Tab<R>::K(j, 0) * e[0];
+#pragma unroll
+        for (int d = 1; d < R; ++d) q = fma(Tab<R>::K(j, d), e[d], q);
+        c[R + j] = q * ipw;
+        ipw *= it;
+    }
+}
+
 // segment_coeffs with the inverse powers of the duration supplied (ip[j] = T^-j, from SegBlocks::build): no reciprocal, no power chain.
 template <int R>
 __device__ __forceinline__ void segment_coeffs_ip(double p0, const double (&ys)[R - 1], double p1, const double (&ye)[R - 1], double T,

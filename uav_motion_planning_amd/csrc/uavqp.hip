@@ -1348,6 +1348,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     const bool dual = gmode == 2 && Mmax >= 2 && Mmax - 1 <= 32;
     a.pdas_rounds = warm_start ? ctx->settings.corridor_pdas_rounds_warm : (dual ? 0 : ctx->settings.corridor_pdas_rounds);
     a.guess_closed_form = (gmode != 0 && !dual) ? 1 : 0;
+    a.fused_emit = 1;      // the solve kernel writes the polynomials itself (corridor_emit_kernel: only behind the rows solvers)
     a.only_i32 = d_only_i32; a.only_u8 = d_only_u8;
     a.gcache = d_gcache; a.gscale = d_gscale; a.gcache_mode = (d_gcache && Mmax - 1 <= 24) ? gcache_mode : 0;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
@@ -1428,9 +1429,6 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
 #endif
     UAVQP_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(uavqp::corridor_reset_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, d_iters_out, n_traj, d_only_i32, d_only_u8);
-    const long long chunks = 3LL * (rows - n_traj);  // (trajectory, axis, segment) triples
-    long long egrid = (chunks + 255) / 256;
-    if (egrid > (long long)ctx->num_cus * 16) egrid = (long long)ctx->num_cus * 16;
     {
         long long pgrid = (pairs + 255) / 256;
         if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
@@ -1474,14 +1472,12 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     if (r == 3) {
         if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<3, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
-        if (chunks > 0) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<3>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, a, chunks);
     } else {
         if (tail_shape) {
             if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, true, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, false, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
         } else if (ws_knots > 0) hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL((uavqp::corridor_solve_kernel<4, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
-        if (chunks > 0) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<4>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, a, chunks);
     }
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
