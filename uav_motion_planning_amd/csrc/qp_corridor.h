@@ -65,6 +65,7 @@ struct CorridorArgs {
     double* gcache;                // [n_traj][corridor_gcache_stride]
     const double* gscale;          // [n_traj]
     int gcache_mode;
+    int prep_in_dual;              // 1: no corridor_reset_kernel / corridor_prep_kernel launch: the dual prelude validates, resets and describes what it visits
     int fused_emit;                // 1: corridor_solve_kernel writes the polynomials itself when a problem is done (and corridor_prep_kernel those of the
                                    // one-segment trajectories); 0: it leaves the Hermite solution in xsol for corridor_emit_kernel (the rows solvers' path)
     int guess_closed_form;         // 1: corridor_prep_kernel fills `guess` with the closed-form set; 0: it only zeroes it (corridor_dual_kernel, qp_corridor_dual.h, writes it)
@@ -1002,6 +1003,68 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                 // path; what is saved is the round trip of the Hermite solution through HBM and a launch (round 4: 55 us of config 3's 530).
                 constexpr int NC = 2 * R;
                 const bool al16 = (reinterpret_cast<uintptr_t>(a.coeff) & 15u) == 0;
+                // Whole wave done at once, uniform batch, every slot on chip (the one-iteration case the dual prelude makes the rule): the
+                // coefficients go through LDS -- over the sweep records nobody needs any more, [pair][segment][2 R] -- and leave as linear
+                // 16-byte-per-lane stores, whole lines.  (Straight from the lanes, a store instruction is 64 scattered 16-byte pieces: measured
+                // +45 us on config 3's solve kernel for 151 MB of output.)
+                const bool whole = a.uniform > 0 && al16 && mmax <= NT && __ballot(act && !done) == 0ull;
+                if (whole) {
+                    const int Mu = a.uniform;
+                    double X[NT + 1][R];
+#pragma unroll
+                    for (int s = 0; s <= NT; ++s) {
+                        const int j = mm - s;
+#pragma unroll
+                        for (int q = 0; q < R; ++q) X[s][q] = x0[q];
+                        if (s < NT && s < mmax) {
+                            double xs[R];
+#pragma unroll
+                            for (int q = 0; q < R; ++q) xs[q] = L(s, F_X + q);
+                            const double zs = L(s, F_Z);
+                            if (bit(pin, korig(j))) xs[0] = zs;
+                            if (j >= 1) {
+#pragma unroll
+                                for (int q = 0; q < R; ++q) X[s][q] = xs[q];
+                            }
+                        }
+#pragma unroll
+                        for (int q = 1; q < R; q += 2) X[s][q] = isR ? -X[s][q] : X[s][q];
+                    }
+                    wave_lds_sync();
+                    bool finite = true;
+                    double* const stage = s_rec + (size_t)(lane >> 1) * Mu * NC;
+#pragma unroll
+                    for (int s = 1; s <= NT; ++s) {
+                        const int j = mm - s;
+                        if (s <= mmax && done && j >= 0) {
+                            const int seg = isR ? M - 1 - j : j;
+                            double ys[ND], ye[ND], c[NC];
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) { ys[d] = isR ? X[s - 1][d + 1] : X[s][d + 1]; ye[d] = isR ? X[s][d + 1] : X[s - 1][d + 1]; }
+                            const double Tk = TT[seg];
+                            segment_coeffs_det<R>(isR ? X[s - 1][0] : X[s][0], ys, isR ? X[s][0] : X[s - 1][0], ye, Tk, fast_rcp(Tk), c);
+                            finite = finite && (fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY);
+#pragma unroll
+                            for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(stage + seg * NC + q) = make_double2(c[q], c[q + 1]);
+                        }
+                    }
+                    if (done && !finite) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+                    wave_lds_sync();
+                    const int PP = Mu * R;                                   // 16-byte pieces per problem
+                    const unsigned inv = 0xFFFFFFFFu / (unsigned)PP + 1u;    // t / PP = (t * inv) >> 32 for t < 2^16
+                    const int gi = done ? (int)g : -1;
+                    for (int t0 = 0; t0 < 32 * PP; t0 += 64) {
+                        const int t = t0 + lane;
+                        const int pr = (int)(((unsigned long long)(unsigned)t * inv) >> 32);
+                        const int gp = __shfl(gi, 2 * (pr < 32 ? pr : 31), 64);
+                        if (pr < 32 && gp >= 0) {
+                            const int off = t - pr * PP;
+                            const double2 v = *reinterpret_cast<const double2*>(s_rec + 2 * (size_t)t);
+                            *reinterpret_cast<double2*>(a.coeff + (size_t)gp * Mu * NC + 2 * off) = v;
+                        }
+                    }
+                    wave_lds_sync();
+                } else {
                 double xn[R];
 #pragma unroll
                 for (int q = 0; q < R; ++q) xn[q] = 0.0;
@@ -1052,6 +1115,7 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
                     for (int q = 0; q < R; ++q) xn[q] = xo[q];
                 }
                 if (done && !finite) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+                }
             }
             if (done && !isR) {
                 if (final_pass) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);

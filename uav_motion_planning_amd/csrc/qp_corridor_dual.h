@@ -98,7 +98,7 @@ constexpr int corridor_dual_lds_doubles(int R, int L, int NRW) {
 // One group of L lanes per trajectory; the block handles 64 / L trajectories at a time, grid-stride over the batch in the dealing
 // order of the solve kernel (a.order, longest first), so that the trajectories of a wave are of similar length.
 template <int R, int L, int NRW>
-__device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_lo, int max_trips_extra, double* s_all, int block, int n_blocks) {
+__device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_lo, int max_trips_extra, bool last, double* s_all, int block, int n_blocks) {
     constexpr int ND = R - 1, NG = 64 / L, NE = R * (R + 1) / 2, LOG2L = (L == 16) ? 4 : 3;
     constexpr int RS = corridor_dual_slot(R, NRW), CBS = NRW + 2;
     constexpr int O_CB = NRW * RS, O_SC = O_CB + 2 * CBS, GRP = corridor_dual_lds_doubles(R, L, NRW);
@@ -124,11 +124,64 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
         const int b = have ? (a.order ? a.order[bq] : (int)bq) : 0;
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        // a.prep_in_dual: no corridor_reset_kernel / corridor_prep_kernel ran -- this kernel also validates the trajectories it visits (every
+        // trajectory of the dealing order is `mine` for exactly one launch shape: by n_lo and NRW, the last shape also takes what is longer
+        // than any tableau, which can only be an invalid segment count), resets status and iteration count, writes the problem descriptors
+        // and emits the one-segment trajectories; the boxes are checked where the axes' loads bring them in anyway
+        const bool prep = a.prep_in_dual != 0;
+        const bool mine = have && (n_lo <= 1 || M - 1 >= n_lo) && (last || M - 1 <= NRW);
+        const bool shape_ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;
+        const bool fits = shape_ok && M >= 2 && M - 1 <= NRW && M - 1 >= n_lo;
+        const unsigned long long gmask = ((L == 16) ? 0xFFFFull : 0xFFull) << (grp * L);
         unsigned long long dsc[3];
+        bool solve_any;
+        bool t_ok = true;
+        if (prep) {
+            // durations: every lane checks the ones it is about to stage (indices 0..NRW cover M <= NRW + 1 segments)
+            const double* const TTp = a.times + s0;
+            bool bad = false;
+            if (mine && shape_ok && M - 1 <= NRW) {
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) dsc[ax] = have ? a.desc[3LL * b + ax] : 0ull;
-        // (a batch of mixed lengths is covered by two launches: this one takes the trajectories with n_lo <= M - 1 <= NRW interior knots)
-        const bool solve_any = ((dsc[0] | dsc[1] | dsc[2]) & 1ull) && M >= 2 && M - 1 <= NRW && M - 1 >= n_lo;
+                for (int sl = 0; sl < 2; ++sl)
+                    if (cidx[sl] < M && cidx[sl] < NRW) { const double t = TTp[cidx[sl]]; bad = bad || !((t > 0.0) && (t < INFINITY)); }
+                if (l == 0 && NRW < M) { const double t = TTp[NRW]; bad = bad || !((t > 0.0) && (t < INFINITY)); }
+            }
+            t_ok = (__ballot(bad) & gmask) == 0ull;
+            solve_any = mine && fits && t_ok;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) dsc[ax] = solve_any ? 1ull : 0ull;      // (the equality rows and the box check follow below)
+            if (mine && !solve_any) {
+                // nothing to solve here: an invalid trajectory (left untouched), or a single segment (M = 1: its polynomial follows from the boundary data)
+                const bool valid1 = shape_ok && t_ok && M == 1;
+                if (l == 0) {
+                    a.status[b] = (shape_ok && t_ok) ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
+                    if (a.iters) a.iters[b] = 0;
+                }
+                if (l < 3) {
+                    a.desc[3LL * b + l] = 0ull;
+                    if (valid1 && a.active) { a.active[2 * (3LL * b + l)] = 0ull; a.active[2 * (3LL * b + l) + 1] = 0ull; }
+                    if (valid1) {
+                        constexpr int NC = 2 * R;
+                        const long long base3 = 3LL * ((long long)s0 + b) + l;
+                        const double* bc = a.bc + (size_t)b * 2 * ND * 3 + l;
+                        double ys[ND], ye[ND], c1[NC];
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) { ys[d] = bc[d * 3]; ye[d] = bc[(ND + d) * 3]; }
+                        const double Tk = TTp[0];
+                        segment_coeffs_det<R>(a.waypoints[base3], ys, a.waypoints[base3 + 3], ye, Tk, fast_rcp(Tk), c1);
+                        if (!((fabs(c1[NC - 1]) < INFINITY) && (fabs(c1[R]) < INFINITY))) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+                        double* o = a.coeff + ((size_t)3 * s0 + l) * NC;
+#pragma unroll
+                        for (int j = 0; j < NC; ++j) o[j] = c1[j];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) dsc[ax] = have ? a.desc[3LL * b + ax] : 0ull;
+            // (a batch of mixed lengths is covered by two launches: this one takes the trajectories with n_lo <= M - 1 <= NRW interior knots)
+            solve_any = ((dsc[0] | dsc[1] | dsc[2]) & 1ull) && M >= 2 && M - 1 <= NRW && M - 1 >= n_lo;
+        }
         if (__ballot(solve_any) == 0ull) continue;
         if (!solve_any) M = 2;                       // (keeps every index below in range; nothing is written for this group)
         const int n = M - 1;                         // variables = interior knots 1..n
@@ -388,7 +441,7 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
             segl.build(ldT(M - 1));
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-                const bool on = solve_any && (dsc[ax] & 1ull);
+                const bool on = solve_any && (dsc[ax] & 1ull);      // (prep: provisionally every axis; the box check follows the loads)
                 const long long base3 = 3LL * ((long long)s0 + b) + ax;
                 const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
                 double x0[R], xM[R], r1[R], rn[R];
@@ -416,6 +469,28 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
                     y0[ax][sl] = vc ? v : 0.0;
                 }
             }
+        }
+        if (prep) {
+            // box check and equality rows of the three axes from the bounds just loaded: lo <= hi at every interior knot or the trajectory is
+            // invalid as a whole (left untouched, like corridor_prep_kernel + the status test of the solve kernel's refill would leave it)
+            bool bad = false;
+            unsigned long long eqm[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const bool v0 = solve_any && cidx[0] < n, v1 = solve_any && cidx[1] < n;
+                bad = bad || (v0 && !(lo3[ax][0] <= hi3[ax][0])) || (v1 && !(lo3[ax][1] <= hi3[ax][1]));
+                const unsigned long long e0 = __ballot(v0 && lo3[ax][0] == hi3[ax][0]), e1 = __ballot(v1 && lo3[ax][1] == hi3[ax][1]);
+                const unsigned long long gm = (L == 16) ? 0xFFFFull : 0xFFull;
+                eqm[ax] = (((e0 >> (grp * L)) & gm) << 1) | (((e1 >> (grp * L)) & gm) << (1 + L));
+            }
+            const bool box_ok = (__ballot(bad) & gmask) == 0ull;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) dsc[ax] = (solve_any && box_ok) ? (eqm[ax] | 1ull) : 0ull;
+            if (solve_any && l == 0) {
+                a.status[b] = box_ok ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
+                if (a.iters) a.iters[b] = 0;
+            }
+            if (solve_any && l < 3) a.desc[3LL * b + l] = l == 0 ? dsc[0] : (l == 1 ? dsc[1] : dsc[2]);
         }
         lds_publish();
         if (l == 0) { CB[NRW] = 0.0; CB[NRW + 1] = 0.0; CB[CBS + NRW] = 0.0; CB[CBS + NRW + 1] = 0.0; }
@@ -598,9 +673,9 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
 }
 
 template <int R, int L, int NRW>
-__global__ __launch_bounds__(64, (NRW <= 24 ? 2 : 1)) void corridor_dual_kernel(CorridorArgs a, int n_lo, int max_trips_extra) {
+__global__ __launch_bounds__(64, (NRW <= 24 ? 2 : 1)) void corridor_dual_kernel(CorridorArgs a, int n_lo, int max_trips_extra, int last) {
     __shared__ __attribute__((aligned(16))) double s_all[(64 / L) * corridor_dual_lds_doubles(R, L, NRW)];
-    corridor_dual_body<R, L, NRW>(a, n_lo, max_trips_extra, s_all, (int)blockIdx.x, (int)gridDim.x);
+    corridor_dual_body<R, L, NRW>(a, n_lo, max_trips_extra, last != 0, s_all, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Batches of mixed lengths (up to 25 segments): ONE launch whose first `split` blocks are the 8-lane groups (trajectories of up to 17
@@ -613,8 +688,8 @@ constexpr int corridor_dual_mixed_lds(int R) {
 template <int R>
 __global__ __launch_bounds__(64, 2) void corridor_dual_mixed_kernel(CorridorArgs a, int split, int max_trips_extra) {
     __shared__ __attribute__((aligned(16))) double s_all[corridor_dual_mixed_lds(R)];
-    if ((int)blockIdx.x < split) corridor_dual_body<R, 8, 16>(a, 1, max_trips_extra, s_all, (int)blockIdx.x, split);
-    else corridor_dual_body<R, 16, 24>(a, 17, max_trips_extra, s_all, (int)blockIdx.x - split, (int)gridDim.x - split);
+    if ((int)blockIdx.x < split) corridor_dual_body<R, 8, 16>(a, 1, max_trips_extra, false, s_all, (int)blockIdx.x, split);
+    else corridor_dual_body<R, 16, 24>(a, 17, max_trips_extra, true, s_all, (int)blockIdx.x - split, (int)gridDim.x - split);
 }
 
 }  // namespace uavqp

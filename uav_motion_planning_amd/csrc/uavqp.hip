@@ -1428,8 +1428,11 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     a.stamps = (long long*)((char*)a.queue + 64);   // debug build: section cycles of wave 0, read back by uavqp_debug_corridor_stamps
 #endif
     UAVQP_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(uavqp::corridor_reset_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, d_iters_out, n_traj, d_only_i32, d_only_u8);
-    {
+    // with the dual prelude in front, resetting, validating and describing the problems is its business (one launch less, and the inputs are
+    // not read a third time); otherwise corridor_reset_kernel + corridor_prep_kernel
+    a.prep_in_dual = dual ? 1 : 0;
+    if (!a.prep_in_dual) {
+        hipLaunchKernelGGL(uavqp::corridor_reset_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, d_iters_out, n_traj, d_only_i32, d_only_u8);
         long long pgrid = (pairs + 255) / 256;
         if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
         if (r == 3) hipLaunchKernelGGL(uavqp::corridor_prep_kernel<3>, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
@@ -1438,7 +1441,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     if (dual) {
         // groups of 8 lanes (two tableau columns each) for the trajectories of up to 17 segments, whole DPP rows for the longer ones: a batch
         // of mixed lengths gets both launches, each skipping (per wave: the dealing order is by length) what the other one takes
-        auto launch_dual = [&](int L, int NRW, int n_lo) {
+        auto launch_dual = [&](int L, int NRW, int n_lo, int last) {
             const long long nb = ((long long)n_traj + 64 / L - 1) / (64 / L);
             const int lds_b = 8 * (64 / L) * uavqp::corridor_dual_lds_doubles(r, L, NRW);
             int wpc_d = (160 * 1024) / lds_b;
@@ -1446,7 +1449,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
             if (wpc_d > wmax) wpc_d = wmax;
             if (wpc_d < 1) wpc_d = 1;
             const long long dgrid = nb < (long long)ctx->num_cus * wpc_d ? nb : (long long)ctx->num_cus * wpc_d;
-#define UAVQP_DUAL_LAUNCH(R_, L_, N_) hipLaunchKernelGGL((uavqp::corridor_dual_kernel<R_, L_, N_>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, a, n_lo, 0)
+#define UAVQP_DUAL_LAUNCH(R_, L_, N_) hipLaunchKernelGGL((uavqp::corridor_dual_kernel<R_, L_, N_>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, a, n_lo, 0, last)
             if (r == 3) { if (NRW == 16) UAVQP_DUAL_LAUNCH(3, 8, 16); else if (NRW == 24) UAVQP_DUAL_LAUNCH(3, 16, 24); else UAVQP_DUAL_LAUNCH(3, 16, 32); }
             else { if (NRW == 16) UAVQP_DUAL_LAUNCH(4, 8, 16); else if (NRW == 24) UAVQP_DUAL_LAUNCH(4, 16, 24); else UAVQP_DUAL_LAUNCH(4, 16, 32); }
 #undef UAVQP_DUAL_LAUNCH
@@ -1465,8 +1468,9 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
             if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_mixed_kernel<3>), dim3((unsigned)(g8 + g16)), dim3(64), 0, ctx->stream, a, (int)g8, 0);
             else hipLaunchKernelGGL((uavqp::corridor_dual_mixed_kernel<4>), dim3((unsigned)(g8 + g16)), dim3(64), 0, ctx->stream, a, (int)g8, 0);
         } else {
-            if (nvar <= 16 || mixed) launch_dual(8, 16, 1);
-            if (nvar > 16) launch_dual(16, nvar <= 24 ? 24 : 32, mixed ? 17 : 1);
+            // (`last`: the launch that also takes -- as invalid -- whatever is longer than any tableau)
+            if (nvar <= 16 || mixed) launch_dual(8, 16, 1, nvar <= 16 ? 1 : 0);
+            if (nvar > 16) launch_dual(16, nvar <= 24 ? 24 : 32, mixed ? 17 : 1, 1);
         }
     }
     if (r == 3) {
