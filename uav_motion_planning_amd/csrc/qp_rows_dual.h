@@ -49,7 +49,7 @@ __device__ __forceinline__ int code7_of(double v) { return (int)(__double_as_lon
 #define RD_T(k) do {} while (0)
 #endif
 
-constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 + 48 * 2 * R + 34 + 8 + 64; }   // G / chain records (row stride 49), functionals, durations, masks, int tables
+constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 / 2 + 32 * (R * (R + 1) / 2 + R * R + (R & 1)) + 48 * 2 * R + 34 + 8 + 64; }   // G (lower triangle), chain records, functionals, durations, masks, int tables
 
 typedef double v16d __attribute__((ext_vector_type(16)));
 // lane `src` (wave-uniform) of a double
@@ -133,12 +133,12 @@ __device__ __forceinline__ double wave_min64(double v) {
 template <int R, int K>
 __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int max_trips_extra) {
     const RowsArgs& a = aa.r;
-    // (row stride 49 doubles: lane c writes the mirror entry G[c][i] into ROW c -- with a stride of 48 the 48 lanes hit two bank pairs, a
-    // 24-way conflict per write; with 49 it is two-way -- and reads its column G[.][c] from consecutive addresses)
-    constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, RS = 49;
-    constexpr int O_GF = NRW * RS, O_TB = O_GF + NRW * 2 * R, O_MK = O_TB + 34, O_IT = O_MK + 8;
-    static_assert(NE + R * R <= RS, "a chain record fits a slot");
-    static_assert(O_GF % 2 == 0 && O_TB % 2 == 0 && O_IT % 2 == 0, "8-byte tables on even offsets");
+    // G is symmetric: only its lower triangle is kept (entry (i, c) at max (max + 1) / 2 + min; 9.4 KB instead of 18.8), next to the chain
+    // records -- 16.4 KB per wave in all, so that the register file (256 VGPRs: two waves per SIMD), not LDS, sets the 8 waves per CU.
+    // (First version: full rows with the records aliased underneath, 22 KB: 7 waves per CU, one SIMD of four with a single wave.)
+    constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, RS = NE + R * R + (R & 1);
+    constexpr int O_ER = NRW * (NRW + 1) / 2, O_GF = O_ER + 32 * RS, O_TB = O_GF + NRW * 2 * R, O_MK = O_TB + 34, O_IT = O_MK + 8;
+    static_assert(O_ER % 2 == 0 && O_GF % 2 == 0 && O_TB % 2 == 0 && O_IT % 2 == 0, "16-byte functionals, 8-byte tables on even offsets");
     __shared__ __attribute__((aligned(16))) double sg[rows_dual_lds_doubles(R)];
     using Inv = SmallLDL<R>;
     const int lane = threadIdx.x, c = lane;
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
     int* const KT = reinterpret_cast<int*>(sg + O_IT);       // [34] per knot: first constraint that sits there | count << 8
     int* const CD = KT + 34;                                   // [48] per constraint: left knot | kind << 8 (0 box, 1 + slot) | segment << 12
     int* const CNT = CD + 48;                                  // [33] rows per segment
-    auto ES = [&](int k) -> double* { return sg + (k - 1) * RS; };
-    auto GR = [&](int i) -> double* { return sg + i * RS; };
+    auto ES = [&](int k) -> double* { return sg + O_ER + (k - 1) * RS; };      // chain record of knot k = 1..31
+    auto GP = [&](int i, int j) -> double& { const int hi = max(i, j), lo = min(i, j); return sg[hi * (hi + 1) / 2 + lo]; };
     const int crow = min(c, NRW - 1);
 
     for (long long bq = blockIdx.x; bq < a.n_traj; bq += gridDim.x) {
@@ -436,8 +436,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
 #pragma unroll
                     for (int p = 0; p < R; ++p) val += kLi == k ? (gfv[t][p] * vn[p] + gfv[t][R + p] * v[p]) : gfv[t][R + p] * vn[p];   // (kLi = 0 at k = 1: only its right knot is a variable)
                     if (vc && kLi <= kLc) {
-                        GR(i)[c] = val;
-                        GR(c)[i] = val;
+                        GP(i, c) = val;
                     }
                 }
             }
@@ -451,8 +450,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                     val += kLi == k ? (ga * vn[p] + gb * v[p]) : gb * vn[p];
                 }
                 if (vc && kLi <= kLc) {
-                    GR(i)[c] = val;
-                    GR(c)[i] = val;
+                    GP(i, c) = val;
                 }
             }
 #pragma unroll
@@ -478,11 +476,10 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                 knot(k, oa, oa);
             }
         }
-        // rows and columns beyond the constraints hold what the chain records left there: they must be neutral in the sweeps
+        // rows and columns beyond the constraints must be neutral in the sweeps
         if (c < NRW) {
-            double* const row = GR(c);
 #pragma unroll 1
-            for (int i = c >= NC ? 0 : NC; i < NRW; ++i) row[i] = 0.0;
+            for (int i = max(NC, c); i < NRW; ++i) sg[i * (i + 1) / 2 + c] = 0.0;
         }
         lds_publish();
         RD_T(2);
@@ -539,7 +536,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         double* const dbg = (aa.dbg && bq < 16) ? aa.dbg + bq * 4096 : nullptr;
         if (dbg) {
             if (vc) {
-                for (int i = 0; i < NC; ++i) dbg[i * 48 + c] = GR(c)[i];
+                for (int i = 0; i < NC; ++i) dbg[i * 48 + c] = GP(c, i);
                 dbg[2304 + 576 + c] = (double)cdc;
             }
             if (lane == 0) { dbg[2304 + 640] = NC; dbg[2304 + 641] = n; }
@@ -565,16 +562,17 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             double y = axis == 0 ? y0[0] : (axis == 1 ? y0[1] : y0[2]);
             const double tol = 1e-12 * (1.0 + fmin(fabs(lo), fabs(hi)));
             const double eqb = (vc && lo == hi) ? 1e300 : 0.0;
-            double dg = vc ? GR(crow)[crow] : 1.0, sw = 0.0;
+            double dg = vc ? GP(crow, crow) : 1.0, sw = 0.0;
             bool inW = false;
             lds_publish();
             {
-                const double* const col = sg + crow;     // column c of G (lanes 48..63 carry a copy of column 47: nothing ever reads them)
+                // column c of G (lanes 48..63 carry a copy of column 47: nothing ever reads them)
+                const int tri = crow * (crow + 1) / 2;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    A0[i] = col[i * RS];
-                    A1[i] = col[(16 + i) * RS];
-                    A2[i] = col[(32 + i) * RS];
+                    A0[i] = sg[i >= crow ? i * (i + 1) / 2 + crow : tri + i];
+                    A1[i] = sg[16 + i >= crow ? (16 + i) * (17 + i) / 2 + crow : tri + 16 + i];
+                    A2[i] = sg[32 + i >= crow ? (32 + i) * (33 + i) / 2 + crow : tri + 32 + i];
                 }
             }
 #ifdef UAVQP_DUAL_DEBUG
