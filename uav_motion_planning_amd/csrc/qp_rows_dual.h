@@ -29,6 +29,7 @@ struct RowsDualArgs {
     unsigned long long* warm_rows;   // [problem][2 K]: (active, upper) per row slot, bit s = segment s -- zeroed by the host, written for handled ones
     unsigned char* need_phase1;      // [n_traj]: 1 = not handled here
     const double* gfun;              // [segment][K][2 R]: g_l, g_r of every row (rows_gfun_kernel, launched before this kernel)
+    const double* kd;                // [segment][rows_chain_doubles(R)]: the chain records of rows_chain_kernel (launched before this kernel)
 #ifdef UAVQP_DUAL_DEBUG
     double* dbg;
 #endif
@@ -49,7 +50,7 @@ __device__ __forceinline__ int code7_of(double v) { return (int)(__double_as_lon
 #define RD_T(k) do {} while (0)
 #endif
 
-constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 / 2 + 32 * (R * (R + 1) / 2 + R * R + (R & 1)) + 48 * 2 * R + 34 + 8 + 64; }   // G (lower triangle), chain records, functionals, durations, masks, int tables
+constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 / 2 + 32 * (2 * (R * (R + 1) / 2) + 2 * R * R) + 48 * 2 * R + 34 + 8 + 64; }   // G (lower triangle), chain records (rows_chain_doubles), functionals, durations, masks, int tables
 
 typedef double v16d __attribute__((ext_vector_type(16)));
 // lane `src` (wave-uniform) of a double
@@ -130,13 +131,175 @@ __device__ __forceinline__ double wave_min64(double v) {
     return raw_min(p, q);
 }
 
+// What the prelude needs of the block LDL' chain of a trajectory is the same in all 64 lanes of the wave that solves it (one trajectory
+// per wave: 48 columns): computing it THERE repeats every 3 x 3 recursion 64 times -- a third of the kernel's instructions.
+// rows_chain_kernel computes it once, one LANE per trajectory (forward: S_k^-1 and E_{k-1}; backward: Z_kk = S_k^-1 + E_k Z_{k+1,k+1} E_k' and the
+// last block column Z_kn), and leaves per knot k = 1..M-1 the record {S_k^-1 (lower triangle), E_{k-1}, Z_kk (lower triangle), Z_kn} at
+// kd + (first segment + k - 1) * rows_chain_doubles(R); rows_dual_kernel copies the run of its trajectory into LDS by DMA.
+constexpr int rows_chain_doubles(int R) { return 2 * (R * (R + 1) / 2) + 2 * R * R; }
+
+template <int R>
+__global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __restrict__ kd) {
+    constexpr int NE = R * (R + 1) / 2, NF = rows_chain_doubles(R);
+    using Inv = SmallLDL<R>;
+    for (long long bq = (long long)blockIdx.x * 64 + threadIdx.x; bq < a.n_traj; bq += (long long)gridDim.x * 64) {
+        const int b = (int)bq;
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        if (!(M >= 2 && M <= 32 && (a.uniform > 0 || M <= a.max_segments))) continue;      // (not a trajectory the prelude takes)
+        const int n = M - 1;
+        const double* const T = a.times + s0;
+        double* const out = kd + (size_t)s0 * NF;
+        FullBlocks<R> sa;
+        sa.build(T[0]);
+        Inv lprev;
+        LDLPack<R>::zero(lprev);
+#pragma unroll 1
+        for (int k = 1; k <= n; ++k) {
+            FullBlocks<R> sb;
+            sb.build(T[k]);
+            double D[R][R], Yp[R][R], Zp[R][R], E[R][R];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int q = 0; q < R; ++q) { D[i][q] = sa.B11[i][q] + sb.B00(i, q); E[i][q] = 0.0; }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                double col[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) col[i] = sa.B01[i][q];
+                lprev.forward(col);
+#pragma unroll
+                for (int i = 0; i < R; ++i) { Yp[i][q] = col[i]; Zp[i][q] = col[i] * lprev.dinv[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+#pragma unroll
+                    for (int cc = 0; cc <= i; ++cc) D[i][cc] -= Yp[q][i] * Zp[q][cc];
+            if (k >= 2) {    // E_{k-1} = S_{k-1}^-1 X_{k-1} = L^-T (D^-1 L^-1 X): back-substitution of Zp
+#pragma unroll
+                for (int cc = 0; cc < R; ++cc) {
+#pragma unroll
+                    for (int i = R - 1; i >= 0; --i) {
+                        double v = Zp[i][cc];
+#pragma unroll
+                        for (int q = i + 1; q < R; ++q) v -= lprev.l[q][i] * E[q][cc];
+                        E[i][cc] = v;
+                    }
+                }
+            }
+            Inv ldl;
+            ldl.factor(D);
+            double* const rec = out + (size_t)(k - 1) * NF;
+            {
+                double Si[R][R];
+#pragma unroll
+                for (int cc = 0; cc < R; ++cc) {
+                    double col[R];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) col[i] = (i == cc) ? 1.0 : 0.0;
+                    ldl.solve(col);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) Si[i][cc] = col[i];
+                }
+                int f = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int cc = 0; cc <= i; ++cc) rec[f++] = Si[i][cc];
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int cc = 0; cc < R; ++cc) rec[NE + i * R + cc] = E[i][cc];
+            lprev = ldl;
+            sa = sb;
+        }
+        double Zk1[R][R], Zkn[R][R], Ek[R][R];
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int q = 0; q < R; ++q) { Zk1[i][q] = 0.0; Zkn[i][q] = 0.0; Ek[i][q] = 0.0; }
+#pragma unroll 1
+        for (int k = n; k >= 1; --k) {
+            double* const rec = out + (size_t)(k - 1) * NF;
+            double Si[R][R], Em[R][R];
+            {
+                int f = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int q = 0; q <= i; ++q) { Si[i][q] = rec[f]; Si[q][i] = Si[i][q]; ++f; }
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) Em[i][q] = rec[NE + i * R + q];
+            }
+            double P[R][R], Zkk[R][R];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int p = 0; p < R; ++p) t += Ek[i][p] * Zk1[p][q];
+                    P[i][q] = t;
+                }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int q = 0; q <= i; ++q) {
+                    double t = Si[i][q];
+#pragma unroll
+                    for (int p = 0; p < R; ++p) t += P[i][p] * Ek[q][p];
+                    Zkk[i][q] = t;
+                    Zkk[q][i] = t;
+                }
+            {
+                const double dn = (k == n) ? 1.0 : 0.0;
+                double Zn[R][R];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        double t = dn * Zkk[i][q];
+#pragma unroll
+                        for (int p = 0; p < R; ++p) t -= Ek[i][p] * Zkn[p][q];
+                        Zn[i][q] = t;
+                    }
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) Zkn[i][q] = Zn[i][q];
+            }
+            {
+                int f = NE + R * R;
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int q = 0; q <= i; ++q) rec[f++] = Zkk[i][q];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) rec[f++] = Zkn[i][q];
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int q = 0; q < R; ++q) { Zk1[i][q] = Zkk[i][q]; Ek[i][q] = Em[i][q]; }
+        }
+    }
+}
+
 template <int R, int K>
 __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int max_trips_extra) {
     const RowsArgs& a = aa.r;
     // G is symmetric: only its lower triangle is kept (entry (i, c) at max (max + 1) / 2 + min; 9.4 KB instead of 18.8), next to the chain
     // records -- 16.4 KB per wave in all, so that the register file (256 VGPRs: two waves per SIMD), not LDS, sets the 8 waves per CU.
     // (First version: full rows with the records aliased underneath, 22 KB: 7 waves per CU, one SIMD of four with a single wave.)
-    constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, RS = NE + R * R + (R & 1);
+    constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, RS = rows_chain_doubles(R);
     constexpr int O_ER = NRW * (NRW + 1) / 2, O_GF = O_ER + 32 * RS, O_TB = O_GF + NRW * 2 * R, O_MK = O_TB + 34, O_IT = O_MK + 8;
     static_assert(O_ER % 2 == 0 && O_GF % 2 == 0 && O_TB % 2 == 0 && O_IT % 2 == 0, "16-byte functionals, 8-byte tables on even offsets");
     __shared__ __attribute__((aligned(16))) double sg[rows_dual_lds_doubles(R)];
@@ -148,7 +311,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
     int* const KT = reinterpret_cast<int*>(sg + O_IT);       // [34] per knot: first constraint that sits there | count << 8
     int* const CD = KT + 34;                                   // [48] per constraint: left knot | kind << 8 (0 box, 1 + slot) | segment << 12
     int* const CNT = CD + 48;                                  // [33] rows per segment
-    auto ES = [&](int k) -> double* { return sg + O_ER + (k - 1) * RS; };      // chain record of knot k = 1..31
+    auto ES = [&](int k) -> double* { return sg + O_ER + (k - 1) * RS; };      // chain record of knot k = 1..31: S_k^-1, E_{k-1}, Z_kk, Z_kn
     auto GP = [&](int i, int j) -> double& { const int hi = max(i, j), lo = min(i, j); return sg[hi * (hi + 1) / 2 + lo]; };
     const int crow = min(c, NRW - 1);
 
@@ -163,6 +326,16 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         const int n = M - 1;
         RD_T_DECL
         lds_publish();
+        // the chain records of this trajectory (rows_chain_kernel): HBM -> LDS by DMA, 16 bytes per lane and instruction; they land while the
+        // functionals are prepared
+        {
+            const double* const src = aa.kd + (size_t)s0 * RS;
+            const int pieces = n * (RS / 2);
+            for (int p0 = 0; p0 < pieces; p0 += 64) {
+                const int pp = p0 + lane;
+                if (pp < pieces) __builtin_amdgcn_global_load_lds((gas_ptr)(src + 2 * pp), (las_ptr)(sg + O_ER + 2 * p0), 16, 0, 0);
+            }
+        }
         // ---------------- lane s prepares segment s: the functionals of its rows ----------------
         const bool myseg = lane < M;
         bool segok = true;
@@ -207,7 +380,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             NC += ci;
         }
         const bool handled = (__ballot(segok) == ~0ull) && NC <= NRW;
-        if (!handled) { if (lane == 0) aa.need_phase1[b] = 1; continue; }
+        if (!handled) { if (lane == 0) aa.need_phase1[b] = 1; wait_vmcnt0(); continue; }
         if (lane == 0) aa.need_phase1[b] = 0;
         if (myseg) {
 #pragma unroll
@@ -230,80 +403,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         lds_publish();
 
         RD_T(0);
-        // ---------------- forward: block LDL' chain (one trajectory per wave: every lane computes it, lane 0 stores the records) ----------------
-        FullBlocks<R> sa;
-        sa.build(TB[0]);
-        Inv lprev;
-        LDLPack<R>::zero(lprev);
-#pragma unroll 1
-        for (int k = 1; k <= n; ++k) {
-            FullBlocks<R> sb;
-            sb.build(TB[k]);
-            double D[R][R], Yp[R][R], Zp[R][R];
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int q = 0; q < R; ++q) D[i][q] = sa.B11[i][q] + sb.B00(i, q);
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                double col[R];
-#pragma unroll
-                for (int i = 0; i < R; ++i) col[i] = sa.B01[i][q];
-                lprev.forward(col);
-#pragma unroll
-                for (int i = 0; i < R; ++i) { Yp[i][q] = col[i]; Zp[i][q] = col[i] * lprev.dinv[i]; }
-            }
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int q = 0; q < R; ++q)
-#pragma unroll
-                    for (int cc = 0; cc <= i; ++cc) D[i][cc] -= Yp[q][i] * Zp[q][cc];
-            if (k >= 2) {
-                double E[R][R];
-#pragma unroll
-                for (int cc = 0; cc < R; ++cc) {
-#pragma unroll
-                    for (int i = R - 1; i >= 0; --i) {
-                        double v = Zp[i][cc];
-#pragma unroll
-                        for (int q = i + 1; q < R; ++q) v -= lprev.l[q][i] * E[q][cc];
-                        E[i][cc] = v;
-                    }
-                }
-                if (lane == 0) {
-                    double* const rec = ES(k - 1);
-#pragma unroll
-                    for (int i = 0; i < R; ++i)
-#pragma unroll
-                        for (int cc = 0; cc < R; ++cc) rec[NE + i * R + cc] = E[i][cc];
-                }
-            }
-            Inv ldl;
-            ldl.factor(D);
-            {
-                double Si[R][R];
-#pragma unroll
-                for (int cc = 0; cc < R; ++cc) {
-                    double col[R];
-#pragma unroll
-                    for (int i = 0; i < R; ++i) col[i] = (i == cc) ? 1.0 : 0.0;
-                    ldl.solve(col);
-#pragma unroll
-                    for (int i = 0; i < R; ++i) Si[i][cc] = col[i];
-                }
-                if (lane == 0) {
-                    double* const rec = ES(k);
-                    int f = 0;
-#pragma unroll
-                    for (int i = 0; i < R; ++i)
-#pragma unroll
-                        for (int cc = 0; cc <= i; ++cc) rec[f++] = Si[i][cc];
-                }
-            }
-            lprev = ldl;
-            sa = sb;
-        }
+        wait_vmcnt0();      // the chain records (DMA issued at the top) have landed
         lds_publish();
         RD_T(1);
 
@@ -314,18 +414,18 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         double gLc[R], gRc[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) { gLc[q] = vc ? GF[crow * 2 * R + q] : 0.0; gRc[q] = vc ? GF[crow * 2 * R + R + q] : 0.0; }
-        double Zk1[R][R], Zkn[R][R], Ek[R][R], v[R], wv[R];
+        double Ek[R][R], v[R], wv[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             v[i] = 0.0; wv[i] = 0.0;
 #pragma unroll
-            for (int q = 0; q < R; ++q) { Zk1[i][q] = 0.0; Zkn[i][q] = 0.0; Ek[i][q] = 0.0; }
+            for (int q = 0; q < R; ++q) Ek[i][q] = 0.0;
         }
-        // One knot of the backward pass.  Its LDS operands -- the chain record (S_k^-1, E_{k-1}), the knot's constraint table entry and the
-        // functionals of its first K + 1 constraints -- are loaded one knot ahead (two register sets, the loop below alternates between
-        // them): this phase is issue-bound (the 3 x 3 recursions are the same in every lane), and every exposed LDS round trip -- the compiler
-        // cannot move a load above the G rows written just before it -- was ~10 % on top.
-        constexpr bool PF = R == 3;     // (r = 4: the second register set does not fit beside the 4 x 4 recursions)
+        // One knot of the backward pass.  Its LDS operands -- the chain record (S_k^-1, E_{k-1}, Z_kk, Z_kn), the knot's constraint table entry
+        // and the functionals of its first K + 1 constraints -- are loaded one knot ahead (two register sets, the loop below alternates
+        // between them): the compiler cannot lift a load above the G entries written just before it, and every exposed LDS round trip was
+        // ~10 % on top of an issue-bound phase.
+        constexpr bool PF = R == 3;     // (r = 4: the second register set does not fit)
         struct KnotOps {
             double Si[NE], Em[R][R];
             int kt;
@@ -334,11 +434,10 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             const double* const rec = ES(k);
 #pragma unroll
             for (int f = 0; f < NE; ++f) o.Si[f] = rec[f];
-            const double* const recm = ES(k >= 2 ? k - 1 : 1);
 #pragma unroll
             for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int q = 0; q < R; ++q) o.Em[i][q] = k >= 2 ? recm[NE + i * R + q] : 0.0;
+                for (int q = 0; q < R; ++q) o.Em[i][q] = rec[NE + i * R + q];
             o.kt = KT[k];
         };
         auto knot = [&](int k, const KnotOps& o, KnotOps& nx) __attribute__((always_inline)) {
@@ -357,52 +456,20 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                     gfv[t][p] = g2.x; gfv[t][p + 1] = g2.y;
                 }
             }
-            lds_publish();      // (everything this knot and the record of the next read is on its way before rows of G are written over older slots)
-            double Si[R][R];
+            double Si[R][R], Zkk[R][R], Zkn[R][R];
             {
+                const double* const rec = ES(k);     // (Z_kk and Z_kn of this knot: needed a few dozen instructions further down)
                 int f = 0;
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q <= i; ++q) { Si[i][q] = o.Si[f]; Si[q][i] = o.Si[f]; ++f; }
-            }
-            double P[R][R], Zkk[R][R];
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int q = 0; q < R; ++q) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int p = 0; p < R; ++p) t += Ek[i][p] * Zk1[p][q];
-                    P[i][q] = t;
-                }
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int q = 0; q <= i; ++q) {
-                    double t = Si[i][q];
-#pragma unroll
-                    for (int p = 0; p < R; ++p) t += P[i][p] * Ek[q][p];
-                    Zkk[i][q] = t;
-                    Zkk[q][i] = t;
-                }
-            {
-                const double dn = (k == n) ? 1.0 : 0.0;
-                double Zn[R][R];
+                    for (int q = 0; q <= i; ++q) { Si[i][q] = o.Si[f]; Si[q][i] = o.Si[f]; Zkk[i][q] = rec[NE + R * R + f]; Zkk[q][i] = Zkk[i][q]; ++f; }
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q < R; ++q) {
-                        double t = dn * Zkk[i][q];
-#pragma unroll
-                        for (int p = 0; p < R; ++p) t -= Ek[i][p] * Zkn[p][q];
-                        Zn[i][q] = t;
-                    }
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int q = 0; q < R; ++q) Zkn[i][q] = Zn[i][q];
+                    for (int q = 0; q < R; ++q) Zkn[i][q] = rec[2 * NE + R * R + i * R + q];
             }
+            lds_publish();
             // this lane's column
             const double dR = (k == kLc + 1) ? 1.0 : 0.0, dL = (k == kLc) ? 1.0 : 0.0;
             double inj1[R], inj2[R], wg[R], vn[R];
@@ -457,7 +524,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             for (int i = 0; i < R; ++i) {
                 v[i] = vn[i];
 #pragma unroll
-                for (int q = 0; q < R; ++q) { Zk1[i][q] = Zkk[i][q]; Ek[i][q] = o.Em[i][q]; }
+                for (int q = 0; q < R; ++q) Ek[i][q] = o.Em[i][q];
             }
         };
         if constexpr (PF) {

@@ -1593,7 +1593,8 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     if (prelude) {
         const size_t b_wr = align256(sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_), b_np = align256((size_t)n_traj);
         const size_t b_gf = align256(sizeof(double) * (size_t)(rows - n_traj) * K_ * 2 * r);     // row functionals: made here, used by the prelude AND the rows kernel
-        const size_t need = b_wr + b_np + b_gf;
+        const size_t b_kd = align256(sizeof(double) * (size_t)(rows - n_traj) * uavqp::rows_chain_doubles(r));   // chain records per segment (rows_chain_kernel)
+        const size_t need = b_wr + b_np + b_gf + b_kd;
         if (need > ctx->rows_warm2_bytes) {
             UAVQP_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->rows_warm2) UAVQP_HIP(hipFree(ctx->rows_warm2));
@@ -1605,6 +1606,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         d_warm_rows = (unsigned long long*)ctx->rows_warm2;
         d_need_phase1 = (unsigned char*)ctx->rows_warm2 + b_wr;
         d_gfun_pre = (double*)((char*)ctx->rows_warm2 + b_wr + b_np);
+        double* const d_kd = (double*)((char*)ctx->rows_warm2 + b_wr + b_np + b_gf);
         UAVQP_HIP(hipMemsetAsync(ctx->rows_warm2, 0, b_wr + b_np, ctx->stream));
         {
             uavqp::Rows2Args ga{};
@@ -1626,6 +1628,13 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         da.r.corr_lo = d_corr_lo; da.r.corr_hi = d_corr_hi; da.r.row_tau = d_row_tau; da.r.row_deriv = d_row_deriv; da.r.row_lo = d_row_lo; da.r.row_hi = d_row_hi;
         da.order = nullptr;
         da.warm_box = (unsigned long long*)ctx->rows_warm; da.warm_rows = d_warm_rows; da.need_phase1 = d_need_phase1; da.gfun = d_gfun_pre;
+        da.kd = d_kd;
+        {   // the chain of every trajectory once, one lane each (the prelude's waves would each repeat it in 64 lanes)
+            long long cg = ((long long)n_traj + 63) / 64;
+            if (cg > (long long)ctx->num_cus * 16) cg = (long long)ctx->num_cus * 16;
+            if (r == 3) hipLaunchKernelGGL((uavqp::rows_chain_kernel<3>), dim3((unsigned)cg), dim3(64), 0, ctx->stream, da.r, d_kd);
+            else hipLaunchKernelGGL((uavqp::rows_chain_kernel<4>), dim3((unsigned)cg), dim3(64), 0, ctx->stream, da.r, d_kd);
+        }
 #ifdef UAVQP_DUAL_DEBUG
         {
             if (!g_rows_dbg) { UAVQP_HIP(hipMalloc(&g_rows_dbg, 64 * 2048 * sizeof(double))); }   // (the size uavqp_debug_corridor_dual copies)
