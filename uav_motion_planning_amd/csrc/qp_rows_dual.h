@@ -414,6 +414,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         double gLc[R], gRc[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) { gLc[q] = vc ? GF[crow * 2 * R + q] : 0.0; gRc[q] = vc ? GF[crow * 2 * R + R + q] : 0.0; }
+        const int tri_c = crow * (crow + 1) / 2;       // row c of the packed lower triangle
         double Ek[R][R], v[R], wv[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -502,9 +503,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                     double val = 0.0;
 #pragma unroll
                     for (int p = 0; p < R; ++p) val += kLi == k ? (gfv[t][p] * vn[p] + gfv[t][R + p] * v[p]) : gfv[t][R + p] * vn[p];   // (kLi = 0 at k = 1: only its right knot is a variable)
-                    if (vc && kLi <= kLc) {
-                        GP(i, c) = val;
-                    }
+                    if (vc && i <= c) sg[tri_c + i] = val;      // (constraints are numbered along the knots: i <= c never sits behind c)
                 }
             }
             for (int t = K + 1; t < cnt; ++t) {      // (knot 1 also hosts the rows of segment 0)
@@ -516,9 +515,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                     const double ga = GF[i * 2 * R + p], gb = GF[i * 2 * R + R + p];
                     val += kLi == k ? (ga * vn[p] + gb * v[p]) : gb * vn[p];
                 }
-                if (vc && kLi <= kLc) {
-                    GP(i, c) = val;
-                }
+                if (vc && i <= c) sg[tri_c + i] = val;
             }
 #pragma unroll
             for (int i = 0; i < R; ++i) {
