@@ -391,3 +391,66 @@ def test_dual_prelude_on_ragged_batches(gpu_ctx, r, m_lo, m_hi):
         assert res[2][2][ok].mean() < 1.3 and res[2][2][ok].mean() < 0.5 * res[1][2][ok].mean(), (res[2][2][ok].mean(), res[1][2][ok].mean())
     else:
         assert np.array_equal(res[2][2], res[1][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r,m_hi", [(3, 12), (4, 22), (3, 30)])
+def test_validation_inside_the_dual_prelude_matches_the_prep_kernel(gpu_ctx, r, m_hi):
+    """With the dual prelude in front (corridor_initial_guess = 2) there is no corridor_reset_kernel / corridor_prep_kernel launch: the
+    prelude resets, validates and describes the trajectories it visits and emits the one-segment ones.  Same verdicts and the same
+    bytes as the two-kernel path (guess = 1) on a ragged batch with one-segment trajectories, a zero / negative / NaN / infinite
+    duration, a box with lo > hi on ONE axis, a NaN bound, and a segment count beyond max_segments: invalid trajectories keep the
+    sentinel the output buffer was filled with, on every axis."""
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    n = 240
+    b = W.ragged_batch(5, n, r, m_lo=1, m_hi=m_hi, seed=77 + r + m_hi)
+    so = b["seg_offsets"]
+    Ms = np.diff(so)
+    assert (Ms == 1).sum() >= 2
+    times = np.array(b["times"], dtype=np.float64)
+    lo, hi = W.corridor_boxes(b, config_index=5)
+    multi = np.flatnonzero(Ms >= 3)
+    bad_T = {multi[0]: 0.0, multi[1]: -1.0, multi[2]: np.nan, multi[3]: np.inf}
+    for k, v in bad_T.items():
+        times[so[k] + Ms[k] // 2] = v
+    k_box, k_nan = multi[4], multi[5]
+    row = so[k_box] + k_box + 1                       # first interior knot of that trajectory
+    lo[row, 1], hi[row, 1] = 1.0, -1.0                # one axis only
+    lo[so[k_nan] + k_nan + 1, 2] = np.nan
+    one = np.flatnonzero(Ms == 1)
+    times[so[one[0]]] = -2.0                          # an invalid one-segment trajectory
+    max_seg = m_hi - 1                                # the longest trajectories are beyond max_segments: invalid
+    too_long = np.flatnonzero(Ms > max_seg)
+    assert too_long.size >= 1
+    d_so, d_wp, d_T, d_bc, d_lo, d_hi = up(so), up(b["waypoints"]), up(times), up(b["bc"]), up(lo), up(hi)
+    nco = int(so[-1]) * 6 * r
+    res = {}
+    try:
+        for g in (2, 1):
+            gpu_ctx.set_settings(corridor_initial_guess=g)
+            out = torch.full((nco,), -777.0, dtype=torch.float64, device=dev)
+            st = torch.full((n,), 99, dtype=torch.int32, device=dev)
+            it = torch.full((n,), 99, dtype=torch.int32, device=dev)
+            act = torch.zeros((n, 3, 2), dtype=torch.int64, device=dev)
+            gpu_ctx.solve_corridor_device(r, n, 0, max_seg, d_so, d_wp, d_T, d_bc, d_lo, d_hi, out, st, it, act, False)
+            gpu_ctx.synchronize()
+            res[g] = (out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), act.cpu().numpy())
+    finally:
+        gpu_ctx.set_settings(corridor_initial_guess=2)
+    st2 = res[2][1]
+    invalid = sorted(list(bad_T) + [k_box, k_nan, one[0]] + list(too_long))
+    assert np.all(st2[invalid] == U.UAVQP_INVALID_INPUT)
+    assert np.all(np.delete(st2, invalid) != U.UAVQP_INVALID_INPUT) and (st2 == U.UAVQP_SOLVED).mean() > 0.8
+    assert np.array_equal(st2, res[1][1])
+    co = res[2][0].reshape(-1)
+    for k in invalid:                                  # untouched, all three axes
+        assert np.all(co[so[k] * 6 * r:so[k + 1] * 6 * r] == -777.0), k
+    for k in one[1:]:                                  # one-segment trajectories: emitted (by the prelude / by the prep kernel)
+        assert np.all(co[so[k] * 6 * r:so[k + 1] * 6 * r] != -777.0), k
+    ok = st2 == U.UAVQP_SOLVED
+    sel = np.repeat(ok | (st2 == U.UAVQP_INVALID_INPUT), Ms * 6 * r)
+    assert np.array_equal(res[2][0][sel], res[1][0][sel])           # bit for bit
+    assert np.array_equal(res[2][3][ok], res[1][3][ok])
+    assert np.all(res[2][2][st2 == U.UAVQP_INVALID_INPUT] == res[1][2][st2 == U.UAVQP_INVALID_INPUT])
