@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __re
             ldl.factor(D);
             double* const rec = out + (size_t)(k - 1) * NF;
             {
-                double Si[R][R];
+                double Si[R][R], fw[NE + R * R + 1];
 #pragma unroll
                 for (int cc = 0; cc < R; ++cc) {
                     double col[R];
@@ -208,12 +208,16 @@ __global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __re
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int cc = 0; cc <= i; ++cc) rec[f++] = Si[i][cc];
+                    for (int cc = 0; cc <= i; ++cc) fw[f++] = Si[i][cc];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int cc = 0; cc < R; ++cc) fw[f++] = E[i][cc];
+                // (16-byte stores: the lanes of a wave write records 240 bytes and more apart -- every store instruction is 64 separate pieces)
+#pragma unroll
+                for (int q = 0; q + 1 < NE + R * R; q += 2) *reinterpret_cast<double2_a*>(rec + q) = make_double2(fw[q], fw[q + 1]);
+                if ((NE + R * R) & 1) rec[NE + R * R - 1] = fw[NE + R * R - 1];
             }
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int cc = 0; cc < R; ++cc) rec[NE + i * R + cc] = E[i][cc];
             lprev = ldl;
             sa = sb;
         }
@@ -227,15 +231,19 @@ __global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __re
             double* const rec = out + (size_t)(k - 1) * NF;
             double Si[R][R], Em[R][R];
             {
+                double fw[NE + R * R + 1];
+#pragma unroll
+                for (int q = 0; q + 1 < NE + R * R; q += 2) { const double2 t2 = *reinterpret_cast<const double2_a*>(rec + q); fw[q] = t2.x; fw[q + 1] = t2.y; }
+                if ((NE + R * R) & 1) fw[NE + R * R - 1] = rec[NE + R * R - 1];
                 int f = 0;
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q <= i; ++q) { Si[i][q] = rec[f]; Si[q][i] = Si[i][q]; ++f; }
+                    for (int q = 0; q <= i; ++q) { Si[i][q] = fw[f]; Si[q][i] = fw[f]; ++f; }
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q < R; ++q) Em[i][q] = rec[NE + i * R + q];
+                    for (int q = 0; q < R; ++q) Em[i][q] = fw[f++];
             }
             double P[R][R], Zkk[R][R];
 #pragma unroll
@@ -275,15 +283,21 @@ __global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __re
                     for (int q = 0; q < R; ++q) Zkn[i][q] = Zn[i][q];
             }
             {
-                int f = NE + R * R;
+                constexpr int F0 = NE + R * R;
+                double bw[NE + R * R + 1];
+                int f = 0;
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q <= i; ++q) rec[f++] = Zkk[i][q];
+                    for (int q = 0; q <= i; ++q) bw[f++] = Zkk[i][q];
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q < R; ++q) rec[f++] = Zkn[i][q];
+                    for (int q = 0; q < R; ++q) bw[f++] = Zkn[i][q];
+                if (F0 & 1) rec[F0] = bw[0];
+#pragma unroll
+                for (int q = (F0 & 1); q + 1 < NE + R * R + (F0 & 1) && q + 1 < NE + R * R; q += 2) *reinterpret_cast<double2_a*>(rec + F0 + q) = make_double2(bw[q], bw[q + 1]);
+                if (!(F0 & 1) && ((NE + R * R) & 1)) rec[F0 + NE + R * R - 1] = bw[NE + R * R - 1];
             }
 #pragma unroll
             for (int i = 0; i < R; ++i)
