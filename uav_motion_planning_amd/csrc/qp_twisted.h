@@ -470,8 +470,16 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                     double yj = h[s][d][0], yj1 = Y(s + 1);
                     if constexpr (NSUB == 2) {
                         const int jb = (H + s < mL) ? H + s : mL - 1;
-                        yj = sub ? h[jb][d][0] : yj;
-                        yj1 = sub ? Y(H + s + 1) : yj1;
+                        // (the candidates are pinned as VALUES first: left alone, the optimiser turns a select between two elements of h
+                        // into ONE load through a selected pointer before the loops are unrolled -- and h, indexed at run time, goes to
+                        // scratch: 32-48 bytes per lane in the M = 3, 4, 5 shapes)
+                        double alt = h[jb][d][0], alt1 = Y(H + s + 1);
+                        asm("" : "+v"(alt));
+                        asm("" : "+v"(yj));
+                        asm("" : "+v"(alt1));
+                        asm("" : "+v"(yj1));
+                        yj = sub ? alt : yj;
+                        yj1 = sub ? alt1 : yj1;
                     }
                     ys[d] = isR ? fs * yj1 : yj;
                     ye[d] = isR ? fs * yj : yj1;
