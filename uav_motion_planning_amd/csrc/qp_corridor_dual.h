@@ -95,6 +95,92 @@ constexpr int corridor_dual_lds_doubles(int R, int L, int NRW) {
     return NRW * corridor_dual_slot(R, NRW) + 2 * (NRW + 2) + 8;
 }
 
+// ---- wave-wide helpers of the one-trajectory-per-wave kernels (corridor_dual_wave_kernel below, rows_dual_kernel in qp_rows_dual.h)
+__device__ __forceinline__ double pack_code7(double v, int code) {
+    return __longlong_as_double((__double_as_longlong(v) & ~127ll) | (long long)code);
+}
+__device__ __forceinline__ int code7_of(double v) { return (int)(__double_as_longlong(v) & 127ll); }
+
+typedef double v16d __attribute__((ext_vector_type(16)));
+// lane `src` (wave-uniform) of a double
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// x = [r0 r1 r2 r3] (the four DPP rows of a wave) -> a = [r0 r0 r0 r0], b = [r1 ...], c = [r2 ...]: v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second
+__device__ __forceinline__ void row_replicas32(unsigned x, unsigned& a, unsigned& b, unsigned& c) {
+    const auto p = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // [r0 r0 r2 r2], [r1 r1 r3 r3]
+    const auto u = __builtin_amdgcn_permlane32_swap(p[0], p[0], false, false); // [r0 r0 r0 r0], [r2 r2 r2 r2]
+    const auto w = __builtin_amdgcn_permlane32_swap(p[1], p[1], false, false); // [r1 r1 r1 r1], [r3 ...]
+    a = u[0]; c = u[1]; b = w[0];
+}
+__device__ __forceinline__ void row_replicas(double x, double& a, double& b, double& c) {
+    unsigned al, bl, cl, ah, bh, ch;
+    row_replicas32((unsigned)__double2loint(x), al, bl, cl);
+    row_replicas32((unsigned)__double2hiint(x), ah, bh, ch);
+    a = __hiloint2double((int)ah, (int)al); b = __hiloint2double((int)bh, (int)bl); c = __hiloint2double((int)ch, (int)cl);
+}
+// maximum / minimum over the wave, every lane ends with it, no LDS: DPP inside the rows, permlane swaps across them
+__device__ __forceinline__ void cross_rows(double v, double& p, double& q) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    p = __hiloint2double((int)h[0], (int)l[0]); q = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ void cross_halves(double v, double& p, double& q) {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    p = __hiloint2double((int)h[0], (int)l[0]); q = __hiloint2double((int)h[1], (int)l[1]);
+}
+// acc += (lane I of the own DPP row of t) * ns, one instruction (v_fmac_f64 takes DPP row_newbcast on gfx90a and later)
+// (a VGPR written by the VALU must be two wait states old before a DPP operand reads it, and the compiler's hazard recogniser does not
+// look into the string: the first instruction of a run carries its own s_nop)
+template <int I, bool FIRST = false>
+__device__ __forceinline__ double fmac_rowbcast(double acc, double t, double ns) {
+    if (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(ns), "n"(I));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(ns), "n"(I));
+    return acc;
+}
+// row kq (wave-uniform) of a column held as three 16-row vectors
+__device__ __forceinline__ double pick_row(const v16d A0, const v16d A1, const v16d A2, int kq) {
+    const int e = kq & 15;
+    const double x0 = A0[e], x1 = A1[e], x2 = A2[e];
+    return kq < 16 ? x0 : (kq < 32 ? x1 : x2);
+}
+__device__ __forceinline__ void sweep16(v16d& A, double t, double ns) {
+    A[0] = fmac_rowbcast<0, true>(A[0], t, ns);   A[1] = fmac_rowbcast<1>(A[1], t, ns);   A[2] = fmac_rowbcast<2>(A[2], t, ns);   A[3] = fmac_rowbcast<3>(A[3], t, ns);
+    A[4] = fmac_rowbcast<4>(A[4], t, ns);   A[5] = fmac_rowbcast<5>(A[5], t, ns);   A[6] = fmac_rowbcast<6>(A[6], t, ns);   A[7] = fmac_rowbcast<7>(A[7], t, ns);
+    A[8] = fmac_rowbcast<8>(A[8], t, ns);   A[9] = fmac_rowbcast<9>(A[9], t, ns);   A[10] = fmac_rowbcast<10>(A[10], t, ns); A[11] = fmac_rowbcast<11>(A[11], t, ns);
+    A[12] = fmac_rowbcast<12>(A[12], t, ns); A[13] = fmac_rowbcast<13>(A[13], t, ns); A[14] = fmac_rowbcast<14>(A[14], t, ns); A[15] = fmac_rowbcast<15>(A[15], t, ns);
+}
+
+// maximum of a 32-bit key over the wave (the entering constraint: a float's bits with the column in the low mantissa bits)
+template <int CTRL>
+__device__ __forceinline__ unsigned umax_dpp(unsigned v) {
+    return max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = umax_dpp<0xB1>(v);
+    v = umax_dpp<0x4E>(v);
+    v = umax_dpp<0x141>(v);
+    v = umax_dpp<0x140>(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = max(r[0], r[1]);
+    const auto h = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return max(h[0], h[1]);
+}
+__device__ __forceinline__ double wave_min64(double v) {
+    v = raw_min(v, dpp_f64<0xB1>(v));
+    v = raw_min(v, dpp_f64<0x4E>(v));
+    v = raw_min(v, dpp_f64<0x141>(v));
+    v = raw_min(v, dpp_f64<0x140>(v));
+    double p, q;
+    cross_rows(v, p, q);
+    v = raw_min(p, q);
+    cross_halves(v, p, q);
+    return raw_min(p, q);
+}
+
+
 // One group of L lanes per trajectory; the block handles 64 / L trajectories at a time, grid-stride over the batch in the dealing
 // order of the solve kernel (a.order, longest first), so that the trajectories of a wave are of similar length.
 template <int R, int L, int NRW>
@@ -690,6 +776,237 @@ __global__ __launch_bounds__(64, 2) void corridor_dual_mixed_kernel(CorridorArgs
     __shared__ __attribute__((aligned(16))) double s_all[corridor_dual_mixed_lds(R)];
     if ((int)blockIdx.x < split) corridor_dual_body<R, 8, 16>(a, 1, max_trips_extra, false, s_all, (int)blockIdx.x, split);
     else corridor_dual_body<R, 16, 24>(a, 17, max_trips_extra, true, s_all, (int)blockIdx.x - split, (int)gridDim.x - split);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One trajectory per WAVE, G from the cache of an earlier solve of the same outer loop (CorridorArgs::gcache_mode == 2: loaded and
+// rescaled, no chain) -- the re-solves of the config-5 pipeline.  The batch kernels above advance eight trajectories in lockstep and
+// broadcast the pivot column through LDS: a launch lasts as long as its slowest batch (72-240 us per round for a few hundred to a few
+// thousand trajectories, most of the machine idle).  Here lane c owns tableau column c (two 16-row register vectors), the pivot is
+// wave-uniform and a trip is the LDS-free one of rows_dual_kernel (own-row symmetry, v_fmac_f64 row_newbcast sweep, permlane
+// reductions): no lockstep (a trajectory takes its own 5 exchanges per axis, not the 10-11 of the slowest of eight), no LDS at all,
+// G kept in 8 KB of LDS between the axes (the tableau itself lives in registers): four waves per SIMD.  Same duties as corridor_dual_body with prep_in_dual (reset, validation, descriptors, one-segment trajectories),
+// same hand-over; as there, nothing here decides a result.
+template <int R>
+__device__ __forceinline__ double pick_row2(const v16d A0, const v16d A1, int kq) {
+    const int e = kq & 15;
+    const double x0 = A0[e], x1 = A1[e];
+    return kq < 16 ? x0 : x1;
+}
+
+template <int R>
+__global__ __launch_bounds__(64, 3) void corridor_dual_wave_kernel(CorridorArgs a, int max_trips_extra) {
+    constexpr int ND = R - 1, NC = 2 * R;
+    __shared__ double s_g[32 * 32];      // [row][column]: this trajectory's G, scaled -- every axis starts its tableau from it
+    const int lane = threadIdx.x, c = lane;
+    const int n_eff = a.n_active ? *a.n_active : a.n_traj;
+    for (long long bq = blockIdx.x; bq < n_eff; bq += gridDim.x) {
+        const int b = __builtin_amdgcn_readfirstlane(a.order ? a.order[bq] : (int)bq);
+        int s0, M;
+        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        s0 = __builtin_amdgcn_readfirstlane(s0);
+        M = __builtin_amdgcn_readfirstlane(M);
+        const bool shape_ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;
+        const bool fits = shape_ok && M >= 2 && M - 1 <= 24;          // (the cache holds tableaus of up to 24 rows)
+        const double* const TT = a.times + s0;
+        double Tl = 1.0;
+        bool bad = false;
+        if (shape_ok && M - 1 <= 24 && lane < M) { Tl = TT[lane]; bad = !((Tl > 0.0) && (Tl < INFINITY)); }
+        const bool t_ok = __ballot(bad) == 0ull;
+        if (!(fits && t_ok)) {
+            // nothing to solve: an invalid trajectory (left untouched) or a single segment (its polynomial follows from the boundary data)
+            const bool valid1 = shape_ok && t_ok && M == 1;
+            if (lane == 0) {
+                a.status[b] = (shape_ok && t_ok) ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
+                if (a.iters) a.iters[b] = 0;
+            }
+            if (lane < 3) {
+                a.desc[3LL * b + lane] = 0ull;
+                if (valid1 && a.active) { a.active[2 * (3LL * b + lane)] = 0ull; a.active[2 * (3LL * b + lane) + 1] = 0ull; }
+                if (valid1) {
+                    const long long base3 = 3LL * ((long long)s0 + b) + lane;
+                    const double* bc = a.bc + (size_t)b * 2 * ND * 3 + lane;
+                    double ys[ND], ye[ND], c1[NC];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) { ys[d] = bc[d * 3]; ye[d] = bc[(ND + d) * 3]; }
+                    const double Tk = TT[0];
+                    segment_coeffs_det<R>(a.waypoints[base3], ys, a.waypoints[base3 + 3], ye, Tk, fast_rcp(Tk), c1);
+                    if (!((fabs(c1[NC - 1]) < INFINITY) && (fabs(c1[R]) < INFINITY))) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+                    double* o = a.coeff + ((size_t)3 * s0 + lane) * NC;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) o[j] = c1[j];
+                }
+            }
+            continue;
+        }
+        const int n = M - 1;
+        const bool vc = c < n;
+        const int cc = vc ? c : 0;
+        const bool wide = n > 16;                     // the cache was written by the shape that took the trajectory: 16 or 24 rows
+        const int NRWs = wide ? 24 : 16;
+        const double* const gc = a.gcache + (size_t)b * corridor_gcache_stride;
+        double pw[R];                                 // pw[q] = s^(2R-1-q): entry ((i, a), (j, b)) of H^-1 scales by s^(2R-1-a-b)
+        {
+            const double sc = a.gscale[b];
+            pw[R - 1] = sc;
+#pragma unroll
+            for (int e = 1; e < R; ++e) pw[R - 1] *= sc;
+#pragma unroll
+            for (int q = R - 2; q >= 0; --q) pw[q] = pw[q + 1] * sc;
+        }
+        // ---------------- column c of G, its diagonal entry, the two vector families: all loads in flight together ----------------
+        double dg0, cv[R], wv[R];
+        {
+            const double* const rowp = gc + (size_t)cc * NRWs;
+            double2 t0[8], t1[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t0[i] = *reinterpret_cast<const double2_a*>(rowp + 2 * i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t1[i] = wide ? *reinterpret_cast<const double2_a*>(rowp + 16 + 2 * i) : make_double2(0.0, 0.0);
+            dg0 = rowp[cc];
+#pragma unroll
+            for (int q = 0; q < R; ++q) { cv[q] = gc[NRWs * NRWs + cc * 2 * R + q]; wv[q] = gc[NRWs * NRWs + cc * 2 * R + R + q]; }
+            const double g = vc ? pw[0] : 0.0;
+            lds_publish();
+            if (c < 32) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s_g[(2 * i) * 32 + c] = t0[i].x * g; s_g[(2 * i + 1) * 32 + c] = t0[i].y * g; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s_g[(16 + 2 * i) * 32 + c] = t1[i].x * g; s_g[(17 + 2 * i) * 32 + c] = t1[i].y * g; }
+            }
+            lds_publish();
+            dg0 = vc ? dg0 * pw[0] : 1.0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) { cv[q] *= pw[q]; wv[q] *= pw[q]; }
+        }
+        // ---------------- per axis: unconstrained minimiser and box of this lane's knot ----------------
+        double y0[3], lo3[3], hi3[3];
+        {
+            FullBlocks<R> seg0, segl;
+            seg0.build(readlane_f64(Tl, 0));
+            segl.build(readlane_f64(Tl, M - 1));
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const long long base3 = 3LL * ((long long)s0 + b) + ax;
+                const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+                double x0[R], xM[R], r1[R], rn[R];
+                x0[0] = a.waypoints[base3];
+                xM[0] = a.waypoints[base3 + 3LL * M];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { x0[d + 1] = bc[d * 3]; xM[d + 1] = bc[(ND + d) * 3]; }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    double v1 = 0.0, vn = 0.0;
+#pragma unroll
+                    for (int q = 0; q < R; ++q) { v1 -= seg0.B01[q][i] * x0[q]; vn -= segl.B01[i][q] * xM[q]; }
+                    r1[i] = v1;
+                    rn[i] = vn;
+                }
+                lo3[ax] = vc ? a.corr_lo[base3 + 3LL * (cc + 1)] : 0.0;
+                hi3[ax] = vc ? a.corr_hi[base3 + 3LL * (cc + 1)] : 0.0;
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < R; ++q) v += cv[q] * r1[q] + wv[q] * rn[q];
+                y0[ax] = vc ? v : 0.0;
+            }
+        }
+        // box check and equality rows (as corridor_prep_kernel would: lo <= hi at every interior knot, or the trajectory is invalid as a whole)
+        unsigned long long dsc[3];
+        {
+            bool badb = false;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                badb = badb || (vc && !(lo3[ax] <= hi3[ax]));
+                dsc[ax] = ((__ballot(vc && lo3[ax] == hi3[ax]) & 0xFFFFFFFFull) << 1) | 1ull;
+            }
+            const bool box_ok = __ballot(badb) == 0ull;
+            if (lane == 0) {
+                a.status[b] = box_ok ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
+                if (a.iters) a.iters[b] = 0;
+            }
+            if (lane < 3) a.desc[3LL * b + lane] = box_ok ? (lane == 0 ? dsc[0] : (lane == 1 ? dsc[1] : dsc[2])) : 0ull;
+            if (!box_ok) continue;
+        }
+        // ---------------- the three axes ----------------
+        const int max_trips = 4 * n + 16 + max_trips_extra;
+#pragma unroll 1
+        for (int axis = 0; axis < 3; ++axis) {
+            const double lo = axis == 0 ? lo3[0] : (axis == 1 ? lo3[1] : lo3[2]);
+            const double hi = axis == 0 ? hi3[0] : (axis == 1 ? hi3[1] : hi3[2]);
+            double y = axis == 0 ? y0[0] : (axis == 1 ? y0[1] : y0[2]);
+            const double tol = 1e-12 * (1.0 + fmin(fabs(lo), fabs(hi)));
+            const double eqb = (vc && lo == hi) ? 1e300 : 0.0;
+            double dg = dg0, sw = 0.0;
+            bool inW = false;
+            v16d A0, A1;
+            {
+                const double* const col = s_g + (c & 31);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) A0[i] = col[i * 32];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) A1[i] = col[(16 + i) * 32];
+#pragma unroll
+                for (int i = 8; i < 16; ++i) A1[i] = 0.0;
+            }
+            int trips = 0;
+            for (;;) {
+                // entering constraint: steepest dual ascent, violation^2 / T_qq, ranked in single precision (a heuristic choice)
+                const double below = lo - y, above = y - hi;
+                const double viol = raw_max(below, above);
+                const bool cand = vc && !inW && viol > tol && dg > 0.0;
+                const float kf = eqb != 0.0 ? 3.0e38f : (float)raw_min(viol * viol * __builtin_amdgcn_rcp(dg), 1e38);
+                const unsigned key = wave_umax(cand ? ((__float_as_uint(kf) & ~127u) | (unsigned)((below > above ? 64 : 0) | c)) : 0u);
+                const int cd = __builtin_amdgcn_readfirstlane((int)key);
+                if (cd < 128 || trips >= max_trips) break;
+                const int q = cd & 63;
+                const double sdir = (cd & 64) ? 1.0 : -1.0;
+                double muq = 0.0;
+                double aq = pick_row2<R>(A0, A1, q);
+                for (;;) {
+                    const double d = sdir * (c == q ? dg : aq);
+                    const double pvl = rcp1(dg);
+                    const double t1 = readlane_f64(((sdir > 0.0 ? lo : hi) - y) * sdir * pvl, q);
+                    const bool blocks = sw * d > 0.0;
+                    const double ratio = raw_min(raw_max(-y * rcp1(d), 0.0), 1e299);
+                    const double rmin = wave_min64(blocks ? pack_code7(ratio, c) : 1e300);
+                    const bool partial = __builtin_amdgcn_readfirstlane((int)(rmin < t1)) != 0;
+                    const double t = partial ? rmin : t1;
+                    const int kp = partial ? (__builtin_amdgcn_readfirstlane(code7_of(rmin)) & 63) : q;
+                    y = fma(t, d, y);
+                    muq = fma(sdir, t, muq);
+                    // sweep on the pivot kp: the constraint q enters (full step) or the blocking one leaves (partial step)
+                    const bool pc = c == kp;
+                    const double ak = partial ? pick_row2<R>(A0, A1, kp) : aq;
+                    const double tc = pc ? dg - (partial ? -1.0 : 1.0) : ak;
+                    const double piv = readlane_f64(pvl, kp);
+                    const double scl = tc * piv;
+                    const double dn = fma(-tc, scl, dg);
+                    dg = pc ? -piv : dn;
+                    const double yb = sw < 0.0 ? hi : lo;
+                    y = pc ? (partial ? yb : -muq) : y;
+                    sw = pc ? ((partial || eqb != 0.0) ? 0.0 : sdir) : sw;
+                    inW = pc ? !partial : inW;
+                    {
+                        double ta, tb, tunused;
+                        row_replicas(tc, ta, tb, tunused);
+                        const double ns = -scl;
+                        sweep16(A0, ta, ns);
+                        if (wide) sweep16(A1, tb, ns);
+                    }
+                    ++trips;
+                    if (!partial || trips >= max_trips) break;
+                    aq = pick_row2<R>(A0, A1, q);
+                }
+            }
+            // ---- hand the working set of this axis over (bit k = interior knot k, as the solve kernel reads it)
+            const unsigned long long bw = __ballot(inW && sw != 0.0), bu = __ballot(inW && sw < 0.0);
+            if (lane == 0) {
+                a.guess[2 * (3LL * b + axis)] = (bw & 0xFFFFFFFFull) << 1;
+                a.guess[2 * (3LL * b + axis) + 1] = (bu & 0xFFFFFFFFull) << 1;
+            }
+        }
+    }
 }
 
 }  // namespace uavqp

@@ -35,11 +35,6 @@ struct RowsDualArgs {
 #endif
 };
 
-__device__ __forceinline__ double pack_code7(double v, int code) {
-    return __longlong_as_double((__double_as_longlong(v) & ~127ll) | (long long)code);
-}
-__device__ __forceinline__ int code7_of(double v) { return (int)(__double_as_longlong(v) & 127ll); }
-
 // debug build: cycles per section of the wave that solves one of the first 16 trajectories -> dbg[3100 + k]
 // (k: 0 prologue, 1 forward chain, 2 backward pass + G, 3 per-axis set-up, 4 selection, 5 direction + ratio test, 6 sweep, 7 hand-over; 8 = trips)
 #ifdef UAVQP_DUAL_DEBUG
@@ -51,85 +46,6 @@ __device__ __forceinline__ int code7_of(double v) { return (int)(__double_as_lon
 #endif
 
 constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 / 2 + 32 * (2 * (R * (R + 1) / 2) + 2 * R * R) + 48 * 2 * R + 34 + 8 + 64; }   // G (lower triangle), chain records (rows_chain_doubles), functionals, durations, masks, int tables
-
-typedef double v16d __attribute__((ext_vector_type(16)));
-// lane `src` (wave-uniform) of a double
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
-}
-// x = [r0 r1 r2 r3] (the four DPP rows of a wave) -> a = [r0 r0 r0 r0], b = [r1 ...], c = [r2 ...]: v_permlane16_swap exchanges the odd
-// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second
-__device__ __forceinline__ void row_replicas32(unsigned x, unsigned& a, unsigned& b, unsigned& c) {
-    const auto p = __builtin_amdgcn_permlane16_swap(x, x, false, false);       // [r0 r0 r2 r2], [r1 r1 r3 r3]
-    const auto u = __builtin_amdgcn_permlane32_swap(p[0], p[0], false, false); // [r0 r0 r0 r0], [r2 r2 r2 r2]
-    const auto w = __builtin_amdgcn_permlane32_swap(p[1], p[1], false, false); // [r1 r1 r1 r1], [r3 ...]
-    a = u[0]; c = u[1]; b = w[0];
-}
-__device__ __forceinline__ void row_replicas(double x, double& a, double& b, double& c) {
-    unsigned al, bl, cl, ah, bh, ch;
-    row_replicas32((unsigned)__double2loint(x), al, bl, cl);
-    row_replicas32((unsigned)__double2hiint(x), ah, bh, ch);
-    a = __hiloint2double((int)ah, (int)al); b = __hiloint2double((int)bh, (int)bl); c = __hiloint2double((int)ch, (int)cl);
-}
-// maximum / minimum over the wave, every lane ends with it, no LDS: DPP inside the rows, permlane swaps across them
-__device__ __forceinline__ void cross_rows(double v, double& p, double& q) {
-    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
-    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
-    p = __hiloint2double((int)h[0], (int)l[0]); q = __hiloint2double((int)h[1], (int)l[1]);
-}
-__device__ __forceinline__ void cross_halves(double v, double& p, double& q) {
-    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
-    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
-    p = __hiloint2double((int)h[0], (int)l[0]); q = __hiloint2double((int)h[1], (int)l[1]);
-}
-// acc += (lane I of the own DPP row of t) * ns, one instruction (v_fmac_f64 takes DPP row_newbcast on gfx90a and later)
-// (a VGPR written by the VALU must be two wait states old before a DPP operand reads it, and the compiler's hazard recogniser does not
-// look into the string: the first instruction of a run carries its own s_nop)
-template <int I, bool FIRST = false>
-__device__ __forceinline__ double fmac_rowbcast(double acc, double t, double ns) {
-    if (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(ns), "n"(I));
-    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(ns), "n"(I));
-    return acc;
-}
-// row kq (wave-uniform) of a column held as three 16-row vectors
-__device__ __forceinline__ double pick_row(const v16d A0, const v16d A1, const v16d A2, int kq) {
-    const int e = kq & 15;
-    const double x0 = A0[e], x1 = A1[e], x2 = A2[e];
-    return kq < 16 ? x0 : (kq < 32 ? x1 : x2);
-}
-__device__ __forceinline__ void sweep16(v16d& A, double t, double ns) {
-    A[0] = fmac_rowbcast<0, true>(A[0], t, ns);   A[1] = fmac_rowbcast<1>(A[1], t, ns);   A[2] = fmac_rowbcast<2>(A[2], t, ns);   A[3] = fmac_rowbcast<3>(A[3], t, ns);
-    A[4] = fmac_rowbcast<4>(A[4], t, ns);   A[5] = fmac_rowbcast<5>(A[5], t, ns);   A[6] = fmac_rowbcast<6>(A[6], t, ns);   A[7] = fmac_rowbcast<7>(A[7], t, ns);
-    A[8] = fmac_rowbcast<8>(A[8], t, ns);   A[9] = fmac_rowbcast<9>(A[9], t, ns);   A[10] = fmac_rowbcast<10>(A[10], t, ns); A[11] = fmac_rowbcast<11>(A[11], t, ns);
-    A[12] = fmac_rowbcast<12>(A[12], t, ns); A[13] = fmac_rowbcast<13>(A[13], t, ns); A[14] = fmac_rowbcast<14>(A[14], t, ns); A[15] = fmac_rowbcast<15>(A[15], t, ns);
-}
-
-// maximum of a 32-bit key over the wave (the entering constraint: a float's bits with the column in the low mantissa bits)
-template <int CTRL>
-__device__ __forceinline__ unsigned umax_dpp(unsigned v) {
-    return max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ unsigned wave_umax(unsigned v) {
-    v = umax_dpp<0xB1>(v);
-    v = umax_dpp<0x4E>(v);
-    v = umax_dpp<0x141>(v);
-    v = umax_dpp<0x140>(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    v = max(r[0], r[1]);
-    const auto h = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return max(h[0], h[1]);
-}
-__device__ __forceinline__ double wave_min64(double v) {
-    v = raw_min(v, dpp_f64<0xB1>(v));
-    v = raw_min(v, dpp_f64<0x4E>(v));
-    v = raw_min(v, dpp_f64<0x141>(v));
-    v = raw_min(v, dpp_f64<0x140>(v));
-    double p, q;
-    cross_rows(v, p, q);
-    v = raw_min(p, q);
-    cross_halves(v, p, q);
-    return raw_min(p, q);
-}
 
 // What the prelude needs of the block LDL' chain of a trajectory is the same in all 64 lanes of the wave that solves it (one trajectory
 // per wave: 48 columns): computing it THERE repeats every 3 x 3 recursion 64 times -- a third of the kernel's instructions.

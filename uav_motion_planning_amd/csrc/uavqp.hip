@@ -739,6 +739,8 @@ struct uavqp_ctx {
     void* rows_warm2 = nullptr;      // rows part of the starting set of the general-rows solve + the "box phase needed" flags (qp_rows_dual.h)
     size_t rows_warm2_bytes = 0;
     void* dbg_queue = nullptr;  // (debug builds) where the last corridor solve kept its work counter
+    int dual_trips_extra = 0;   // added to the trip budget 4 n + 16 of the dual preludes (UAVQP_DUAL_TRIPS_EXTRA, may be negative: tools/ experiments)
+    int wave_prelude = 1;       // re-solves with G in the cache: corridor_dual_wave_kernel (UAVQP_NO_WAVE_PRELUDE: the batch kernels, for A/B runs)
     void* dbg_dual = nullptr;   // (UAVQP_DUAL_DEBUG builds) dump area of corridor_dual_kernel
     void* dbg_guess = nullptr;  // (UAVQP_DUAL_DEBUG builds) the starting sets of the last cold corridor solve
     int32_t* perm = nullptr;  // ragged dealing permutation (window_sort_kernel); behind it the packed {b, s0, M, 0} records
@@ -866,6 +868,8 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
         }
     }
     if (std::getenv("UAVQP_NO_LSORT")) ctx->settings.ragged_window_sort = 0;
+    if (std::getenv("UAVQP_NO_WAVE_PRELUDE")) ctx->wave_prelude = 0;
+    if (const char* e = std::getenv("UAVQP_DUAL_TRIPS_EXTRA")) ctx->dual_trips_extra = std::atoi(e);
     if (const char* e = std::getenv("UAVQP_GENERIC_NAX")) ctx->settings.generic_lanes_per_traj = std::atoi(e) == 3 ? 1 : 3;
     if (const char* e = std::getenv("UAVQP_GENERIC_WPC")) {
         const int w = std::atoi(e);
@@ -1438,7 +1442,13 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
         if (r == 3) hipLaunchKernelGGL(uavqp::corridor_prep_kernel<3>, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(uavqp::corridor_prep_kernel<4>, dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, a);
     }
-    if (dual) {
+    if (dual && gcache_mode == 2 && d_gcache && d_gscale && ctx->wave_prelude) {
+        // G of every trajectory is in the cache of an earlier solve of this outer loop: one trajectory per wave, no chain, no lockstep
+        long long wgrid = (long long)n_traj < (long long)ctx->num_cus * 12 ? (long long)n_traj : (long long)ctx->num_cus * 12;
+        if (wgrid < 1) wgrid = 1;
+        if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<3>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
+        else hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<4>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
+    } else if (dual) {
         // groups of 8 lanes (two tableau columns each) for the trajectories of up to 17 segments, whole DPP rows for the longer ones: a batch
         // of mixed lengths gets both launches, each skipping (per wave: the dealing order is by length) what the other one takes
         auto launch_dual = [&](int L, int NRW, int n_lo, int last) {
