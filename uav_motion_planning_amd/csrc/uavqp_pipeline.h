@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void pipe_shrink_kernel(int n, int uniform, con
 }  // namespace uavqp
 
 static int ensure_pipe_ws(uavqp_ctx* ctx, size_t bytes) {
-    if (!ctx->h_pipe) UAVQP_HIP(hipHostMalloc(&ctx->h_pipe, 256, hipHostMallocDefault));
+    if (!ctx->h_pipe) UAVQP_HIP(hipHostMalloc(&ctx->h_pipe, 1024, hipHostMallocDefault));   // counter block [0] + the ring of per-round blocks [4..7]
     if (bytes <= ctx->pipe_bytes) return UAVQP_OK;
     UAVQP_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->d_pipe) UAVQP_HIP(hipFree(ctx->d_pipe));
@@ -263,16 +263,45 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     rc = uavqp_corridor_from_cloud_device(ctx, r, n, uni, d_seg_offsets, n_rows, d_waypoints, d_times, d_coeff_out, d_obstacles, n_obs,
                                           P.robot_r, P.robot_h, P.h_max, d_corr_lo, d_corr_hi, nullptr);
     if (rc != UAVQP_OK) return rc;
-    // 3. outer loop
+    // 3. outer loop.  The host only needs a round's counter to know whether ANOTHER round is due, so it does not stop the stream for it:
+    // the counter block of round k goes to its own pinned slot behind an event, and while the last examined round still stretched
+    // many trajectories (> n / 64) round k + 1 is enqueued before round k's counter is looked at -- if that one then reports zero, the
+    // extra round re-solves nobody and stretches nobody (same bytes everywhere), at the price of a few empty launches.  Was: copy +
+    // stream synchronisation + 25-30 us of idle device per round.
     int rounds = 0, still = 0;
-    for (int rnd = 0; rnd < P.max_rounds; ++rnd) {
-        rc = corridor_solve(rnd > 0 ? 2 : 0, rnd > 0 ? (const int32_t*)d_changed : nullptr);
-        if (rc != UAVQP_OK) return rc;
-        ++rounds;
-        rc = reallocate();
-        if (rc != UAVQP_OK) return rc;
-        still = (int)h_cnt->changed;
-        if (still == 0) break;   // the last solve already belongs to the final durations
+    {
+        for (int k = 0; k < 4; ++k)
+            if (!ctx->pipe_ev[k]) UAVQP_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[k], hipEventDisableTiming));
+        uavqp::PipeCounters* const h_ring = (uavqp::PipeCounters*)ctx->h_pipe + 4;
+        auto enqueue_round = [&](int rnd) -> int {
+            int rc_ = corridor_solve(rnd > 0 ? 2 : 0, rnd > 0 ? (const int32_t*)d_changed : nullptr);
+            if (rc_ != UAVQP_OK) return rc_;
+            rc_ = time_reallocate_impl(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
+                                       P.max_stretch, d_changed, d_scale);
+            if (rc_ != UAVQP_OK) return rc_;
+            hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
+            hipLaunchKernelGGL(uavqp::pipe_count_kernel, dim3(cgrid), dim3(256), 0, s, (const int32_t*)d_changed, (const int32_t*)nullptr, n, d_cnt);
+            UAVQP_HIP(hipMemcpyAsync(&h_ring[rnd & 3], d_cnt, sizeof(uavqp::PipeCounters), hipMemcpyDeviceToHost, s));
+            UAVQP_HIP(hipEventRecord(ctx->pipe_ev[rnd & 3], s));
+            return UAVQP_OK;
+        };
+        int enq = 0, exam = 0;
+        unsigned int last = 0;
+        for (;;) {
+            while (enq < P.max_rounds && (enq <= exam || (enq == exam + 1 && exam >= 1 && (long long)last * 64 > (long long)n))) {
+                rc = enqueue_round(enq);
+                if (rc != UAVQP_OK) return rc;
+                ++enq;
+            }
+            if (exam >= enq) break;
+            UAVQP_HIP(hipEventSynchronize(ctx->pipe_ev[exam & 3]));
+            last = h_ring[exam & 3].changed;
+            ++exam;
+            ++rounds;
+            still = (int)last;
+            if (still == 0 || exam >= P.max_rounds) break;   // the last solve already belongs to the final durations / cap reached
+        }
+        // (a speculative round may still be in flight: everything that follows is ordered behind it on the same stream)
     }
     if (still != 0) {
         // cap reached with durations changed by the last re-allocation: one more solve so that the coefficients match d_times
