@@ -426,6 +426,13 @@ __global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
     };
 
     const long long total = (long long)(a.n_active ? *a.n_active : a.n_traj) * 3;
+#ifdef UAVQP_DUAL_DEBUG
+    if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) {   // (tools/pipeline_round_probe.py: when every verifying solve of a pipeline call started)
+        if (total >= 4500 && total <= 9000) a.dbg[5 * 16384 + 1] = (double)wall_clock64();
+        const unsigned slot = atomicAdd(reinterpret_cast<unsigned int*>(a.dbg + 63 * 2048 + 1400 + 9), 1u);
+        if (slot < 16) { a.dbg[63 * 2048 + 1400 + 64 + 2 * slot] = (double)wall_clock64(); a.dbg[63 * 2048 + 1400 + 65 + 2 * slot] = (double)total; }
+    }
+#endif
     bool queue_empty = false;
     UAVQP_CT_DECL
 

@@ -801,7 +801,19 @@ __global__ __launch_bounds__(64, 3) void corridor_dual_wave_kernel(CorridorArgs 
     __shared__ double s_g[32 * 32];      // [row][column]: this trajectory's G, scaled -- every axis starts its tableau from it
     const int lane = threadIdx.x, c = lane;
     const int n_eff = a.n_active ? *a.n_active : a.n_traj;
+#ifdef UAVQP_DUAL_DEBUG
+    if (a.dbg && n_eff >= 1500 && n_eff <= 3000 && threadIdx.x == 0 && (blockIdx.x == gridDim.x - 1 || blockIdx.x == 0)) a.dbg[5 * 16384 + (blockIdx.x == 0 ? 2 : 3)] = (double)wall_clock64();   // entry of the first / last block
+    if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned slot = atomicAdd(reinterpret_cast<unsigned int*>(a.dbg + 63 * 2048 + 1400 + 8), 1u);
+        if (slot < 16) { a.dbg[63 * 2048 + 1400 + 16 + 2 * slot] = (double)wall_clock64(); a.dbg[63 * 2048 + 1400 + 17 + 2 * slot] = (double)n_eff; }
+    }
+#endif
     for (long long bq = blockIdx.x; bq < n_eff; bq += gridDim.x) {
+#ifdef UAVQP_DUAL_DEBUG
+        // debug build (tools/pipeline_round_probe.py): per trajectory of a re-solve of 1500-3000 trajectories {trips, cycles, n, entry time}
+        const long long dbg_t0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
+        int dbg_trips = 0;
+#endif
         const int b = __builtin_amdgcn_readfirstlane(a.order ? a.order[bq] : (int)bq);
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
@@ -1005,7 +1017,17 @@ __global__ __launch_bounds__(64, 3) void corridor_dual_wave_kernel(CorridorArgs 
                 a.guess[2 * (3LL * b + axis)] = (bw & 0xFFFFFFFFull) << 1;
                 a.guess[2 * (3LL * b + axis) + 1] = (bu & 0xFFFFFFFFull) << 1;
             }
+#ifdef UAVQP_DUAL_DEBUG
+            dbg_trips += trips;
+#endif
         }
+#ifdef UAVQP_DUAL_DEBUG
+        if (a.dbg && n_eff >= 1500 && n_eff <= 3000 && bq < 16384 && lane == 0) {
+            a.dbg[4 * bq] = dbg_trips; a.dbg[4 * bq + 1] = (double)(__builtin_readcyclecounter() - dbg_t0);
+            a.dbg[4 * bq + 2] = n; a.dbg[4 * bq + 3] = (double)dbg_w0;
+            a.dbg[4 * 16384 + bq] = (double)wall_clock64();
+        }
+#endif
     }
 }
 

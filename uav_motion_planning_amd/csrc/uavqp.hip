@@ -1424,7 +1424,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     {
         static double* s_dbg = nullptr;
         if (!s_dbg) { UAVQP_HIP(hipMalloc(&s_dbg, 64 * 2048 * sizeof(double))); }
-        UAVQP_HIP(hipMemsetAsync(s_dbg, 0, 64 * 2048 * sizeof(double), ctx->stream));
+        if (gcache_mode != 2) UAVQP_HIP(hipMemsetAsync(s_dbg, 0, 64 * 2048 * sizeof(double), ctx->stream));   // (re-solves of a pipeline call keep what the wave prelude recorded)
         a.dbg = s_dbg;
         ctx->dbg_dual = s_dbg;
         ctx->dbg_guess = a.guess;
