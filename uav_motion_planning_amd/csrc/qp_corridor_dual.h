@@ -662,7 +662,6 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
                 CB[slq * CBS + qq] = dq;
                 SC[0] = (bq_ - pq) * sdir * pv;
                 SC[1] = pv;
-                SC[2] = bq_;
             }
             lds_publish();
             double d[2];
@@ -705,7 +704,6 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
             lds_publish();
             {
                 const double piv = go ? SC[1] : 0.0;
-                const double bnd_q = SC[2];
                 double s[2];
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
@@ -720,7 +718,6 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
                     sw[sl] = pc ? ((partial || eqb[sl] != 0.0) ? 0.0 : sdir) : sw[sl];
                     inW[sl] = pc ? !partial : inW[sl];
                 }
-                (void)bnd_q;
 #pragma unroll
                 for (int i = 0; i < NRW; i += 2) {
                     if (i < nrows) {

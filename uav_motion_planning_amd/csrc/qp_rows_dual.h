@@ -233,7 +233,6 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
     constexpr int O_ER = NRW * (NRW + 1) / 2, O_GF = O_ER + 32 * RS, O_TB = O_GF + NRW * 2 * R, O_MK = O_TB + 34, O_IT = O_MK + 8;
     static_assert(O_ER % 2 == 0 && O_GF % 2 == 0 && O_TB % 2 == 0 && O_IT % 2 == 0, "16-byte functionals, 8-byte tables on even offsets");
     __shared__ __attribute__((aligned(16))) double sg[rows_dual_lds_doubles(R)];
-    using Inv = SmallLDL<R>;
     const int lane = threadIdx.x, c = lane;
     double* const GF = sg + O_GF;      // [48][2 R]: g_l, g_r of every constraint (a box: e_0, 0)
     double* const TB = sg + O_TB;      // [33]: durations
