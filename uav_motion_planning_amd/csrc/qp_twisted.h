@@ -252,6 +252,14 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
         }
 #pragma unroll
         for (int j = 1; j < mL; ++j) {
+#ifdef UAVQP_TW_SKIP_LAST_ELIM   // timing-only build (tools/ubench/tw: h_16s): the last elimination step takes its inputs from TWO knots back, so it no
+            // longer waits for the step before it -- the same work on a dependent chain one level shorter, i.e. what a cyclic reduction could buy
+            // AT MOST (its exchanges not counted); the results are wrong
+            constexpr bool tw_short = true;
+#else
+            constexpr bool tw_short = false;
+#endif
+            const int jp = (tw_short && j == mL - 1 && j >= 2) ? j - 2 : j - 1;
             if (j < m) {
                 SegBlocks<R> sb;
                 {
@@ -285,10 +293,10 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
                     for (int q = 0; q < ND; ++q) {
                         if (j > 1) {
 #pragma unroll
-                            for (int c = 0; c <= i; ++c) S[i][c] -= sa.A01[q][i] * E[j - 1][q][c];
+                            for (int c = 0; c <= i; ++c) S[i][c] -= sa.A01[q][i] * E[jp][q][c];
                         }
 #pragma unroll
-                        for (int ax = 0; ax < NAX; ++ax) z[i][ax] -= sa.A01[q][i] * h[j - 1][q][ax];
+                        for (int ax = 0; ax < NAX; ++ax) z[i][ax] -= sa.A01[q][i] * h[jp][q][ax];
                     }
                 typename std::conditional<LPT >= 8, SymInv<ND>, SmallLDL<ND>>::type ldl;
                 ldl.factor(S);
