@@ -758,6 +758,7 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
 template <int R, int L, int NRW>
 __global__ __launch_bounds__(64, (NRW <= 24 ? 2 : 1)) void corridor_dual_kernel(CorridorArgs a, int n_lo, int max_trips_extra, int last) {
     __shared__ __attribute__((aligned(16))) double s_all[(64 / L) * corridor_dual_lds_doubles(R, L, NRW)];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.queue = 0u;      // the work counter of the solve kernel that follows (was a memset node of its own)
     corridor_dual_body<R, L, NRW>(a, n_lo, max_trips_extra, last != 0, s_all, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -771,6 +772,7 @@ constexpr int corridor_dual_mixed_lds(int R) {
 template <int R>
 __global__ __launch_bounds__(64, 2) void corridor_dual_mixed_kernel(CorridorArgs a, int split, int max_trips_extra) {
     __shared__ __attribute__((aligned(16))) double s_all[corridor_dual_mixed_lds(R)];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.queue = 0u;
     if ((int)blockIdx.x < split) corridor_dual_body<R, 8, 16>(a, 1, max_trips_extra, false, s_all, (int)blockIdx.x, split);
     else corridor_dual_body<R, 16, 24>(a, 17, max_trips_extra, true, s_all, (int)blockIdx.x - split, (int)gridDim.x - split);
 }
@@ -797,6 +799,7 @@ __global__ __launch_bounds__(64, 3) void corridor_dual_wave_kernel(CorridorArgs 
     constexpr int ND = R - 1, NC = 2 * R;
     __shared__ double s_g[32 * 32];      // [row][column]: this trajectory's G, scaled -- every axis starts its tableau from it
     const int lane = threadIdx.x, c = lane;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.queue = 0u;
     const int n_eff = a.n_active ? *a.n_active : a.n_traj;
 #ifdef UAVQP_DUAL_DEBUG
     if (a.dbg && n_eff >= 1500 && n_eff <= 3000 && threadIdx.x == 0 && (blockIdx.x == gridDim.x - 1 || blockIdx.x == 0)) a.dbg[5 * 16384 + (blockIdx.x == 0 ? 2 : 3)] = (double)wall_clock64();   // entry of the first / last block

@@ -1433,7 +1433,7 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
 #ifdef UAVQP_CORRIDOR_TIMING
     a.stamps = (long long*)((char*)a.queue + 64);   // debug build: section cycles of wave 0, read back by uavqp_debug_corridor_stamps
 #endif
-    UAVQP_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), ctx->stream));
+    if (!dual) UAVQP_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), ctx->stream));     // (with a prelude: its first block resets the work counter)
     // with the dual prelude in front, resetting, validating and describing the problems is its business (one launch less, and the inputs are
     // not read a third time); otherwise corridor_reset_kernel + corridor_prep_kernel
     a.prep_in_dual = dual ? 1 : 0;
