@@ -1336,7 +1336,8 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
                               double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
                               uint64_t* d_active_set, int warm_start, long long total_segments, const int32_t* d_order_ready = nullptr,
                               const int32_t* d_only_i32 = nullptr, const unsigned char* d_only_u8 = nullptr,
-                              double* d_gcache = nullptr, const double* d_gscale = nullptr, int gcache_mode = 0) {
+                              double* d_gcache = nullptr, const double* d_gscale = nullptr, int gcache_mode = 0,
+                              const int32_t* d_compact_ready = nullptr, const int* d_n_active_ready = nullptr) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0) return UAVQP_ERR_INVALID_ARG;
     if (n_traj == 0) return UAVQP_OK;
     if (!d_waypoints || !d_times || !d_bc || !d_corr_lo || !d_corr_hi || !d_coeff_out || !d_status_out) return UAVQP_ERR_INVALID_ARG;
@@ -1413,7 +1414,12 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
         if (rc != UAVQP_OK) return rc;
     }
     a.n_active = nullptr;
-    if (masked) {
+    if (masked && d_compact_ready && d_n_active_ready) {
+        // (the caller compacted the dealing order of the participating trajectories already: the pipeline does it right behind the
+        // re-allocation whose flags are the mask, where the count doubles as "how many did it stretch")
+        a.order = d_compact_ready;
+        a.n_active = d_n_active_ready;
+    } else if (masked) {
         int32_t* d_compact = (int32_t*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order + b_state + b_guess);
         int* d_n_active = (int*)((char*)d_compact + align256(sizeof(int32_t) * (size_t)n_traj));
         hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.order, n_traj, d_only_i32, d_only_u8, d_compact, d_n_active);

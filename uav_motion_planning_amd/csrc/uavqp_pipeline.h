@@ -202,7 +202,8 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     const bool deal_by_length = uni == 0 && n >= 64 && ctx->settings.ragged_window_sort;
     // G of the dual prelude across the rounds (the re-allocation multiplies all durations of a trajectory by one factor: G only rescales)
     const bool g_across = ctx->settings.corridor_initial_guess == 2 && mx - 1 <= 24 && mx >= 2;
-    const size_t o_sc = o_or + (deal_by_length ? length_order_bytes(n) : 0);
+    const size_t o_cp = o_or + (deal_by_length ? length_order_bytes(n) : 0);          // compacted dealing order of the next re-solve + its count
+    const size_t o_sc = o_cp + align256(sizeof(int32_t) * (size_t)n) + 256;
     const size_t o_gc = o_sc + (g_across ? align256(sizeof(double) * (size_t)n) : 0);
     const size_t need = o_gc + (g_across ? align256(sizeof(double) * (size_t)n * uavqp::corridor_gcache_stride) : 0);
     int rc = ensure_pipe_ws(ctx, need);
@@ -213,6 +214,8 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     int32_t* d_changed = (int32_t*)(base + o_ch);
     int32_t* d_fh = d_first_hit ? d_first_hit : (int32_t*)(base + o_fh);
     uint64_t* d_active = (uint64_t*)(base + o_as);
+    int32_t* d_cp = (int32_t*)(base + o_cp);
+    int* d_na = (int*)(base + o_cp + align256(sizeof(int32_t) * (size_t)n));
     double* d_scale = g_across ? (double*)(base + o_sc) : nullptr;     // factor by which every trajectory was stretched since its G was stored
     double* d_gcache = g_across ? (double*)(base + o_gc) : nullptr;
     int solves_done = 0;
@@ -239,13 +242,13 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     // cold start (uavqp_settings.corridor_initial_guess = 2: the working set of the position-space dual method, verified by one block
     // solve) a re-solve is a cold solve; with the other settings it is warm-started from the previous round as before.
     const bool cold_rounds = ctx->settings.corridor_initial_guess == 2 && (uni > 0 ? uni : mx) - 1 <= 32;
-    auto corridor_solve = [&](int warm, const int32_t* only_i32 = nullptr, const unsigned char* only_u8 = nullptr) {
+    auto corridor_solve = [&](int warm, const int32_t* only_i32 = nullptr, const unsigned char* only_u8 = nullptr, bool precompacted = false) {
         // first solve: every trajectory takes part, its G is stored; later solves load it and rescale by the stretch since then
         const int gmode = (g_across && cold_rounds) ? (solves_done == 0 ? 1 : 2) : 0;
         ++solves_done;
         return corridor_warm_impl(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_corr_lo, d_corr_hi, d_coeff_out,
                                   d_status_out, d_iters, d_active, cold_rounds ? 0 : warm, total_segments, d_order, only_i32, only_u8,
-                                  d_gcache, d_scale, gmode);
+                                  d_gcache, d_scale, gmode, precompacted ? d_cp : nullptr, precompacted ? d_na : nullptr);
     };
     auto reallocate = [&]() -> int {      // + count of the trajectories it stretched
         int rc_ = time_reallocate_impl(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
@@ -274,14 +277,15 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
             if (!ctx->pipe_ev[k]) UAVQP_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[k], hipEventDisableTiming));
         uavqp::PipeCounters* const h_ring = (uavqp::PipeCounters*)ctx->h_pipe + 4;
         auto enqueue_round = [&](int rnd) -> int {
-            int rc_ = corridor_solve(rnd > 0 ? 2 : 0, rnd > 0 ? (const int32_t*)d_changed : nullptr);
+            int rc_ = corridor_solve(rnd > 0 ? 2 : 0, rnd > 0 ? (const int32_t*)d_changed : nullptr, nullptr, rnd > 0);
             if (rc_ != UAVQP_OK) return rc_;
             rc_ = time_reallocate_impl(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
                                        P.max_stretch, d_changed, d_scale);
             if (rc_ != UAVQP_OK) return rc_;
-            hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
-            hipLaunchKernelGGL(uavqp::pipe_count_kernel, dim3(cgrid), dim3(256), 0, s, (const int32_t*)d_changed, (const int32_t*)nullptr, n, d_cnt);
-            UAVQP_HIP(hipMemcpyAsync(&h_ring[rnd & 3], d_cnt, sizeof(uavqp::PipeCounters), hipMemcpyDeviceToHost, s));
+            // the dealing order of the trajectories it stretched, for the re-solve of the next round -- and their number, which is the
+            // round's counter (was: a zeroing kernel, a counting kernel, and the compaction at the head of the next solve)
+            hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, s, d_order, n, (const int32_t*)d_changed, (const unsigned char*)nullptr, d_cp, d_na);
+            UAVQP_HIP(hipMemcpyAsync(&h_ring[rnd & 3].changed, d_na, sizeof(int), hipMemcpyDeviceToHost, s));
             UAVQP_HIP(hipEventRecord(ctx->pipe_ev[rnd & 3], s));
             return UAVQP_OK;
         };
@@ -305,7 +309,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     }
     if (still != 0) {
         // cap reached with durations changed by the last re-allocation: one more solve so that the coefficients match d_times
-        rc = corridor_solve(2, (const int32_t*)d_changed);
+        rc = corridor_solve(2, (const int32_t*)d_changed, nullptr, true);
         if (rc != UAVQP_OK) return rc;
     }
     // 4. check + repair
