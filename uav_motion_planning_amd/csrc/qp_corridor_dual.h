@@ -1031,4 +1031,254 @@ __global__ __launch_bounds__(64, 3) void corridor_dual_wave_kernel(CorridorArgs 
     }
 }
 
+
+// Two trajectories per wave (lanes 0-31 / 32-63): corridor_dual_wave_kernel leaves half of every wave's lanes idle (a tableau has at most
+// 32 columns) and the big re-solves of the pipeline are issue-bound.  Everything that was wave-uniform there is uniform per HALF here
+// (a VGPR holding the same value in the 32 lanes of a half); the two halves advance in lockstep through one flat loop with a per-half
+// state (select an entering constraint / step / done), as the groups of corridor_dual_body do -- a lockstep of two instead of eight.
+// The own-row look-ups are done once per half (two s_set_gpr_idx moves, the lane keeps its half's); the row replicas of the sweep need
+// ONE v_permlane16_swap (rows 0, 1 serve the lower half, rows 2, 3 the upper one) and the reductions stop at the half.
+__device__ __forceinline__ unsigned half_umax(unsigned v) {
+    v = umax_dpp<0xB1>(v);
+    v = umax_dpp<0x4E>(v);
+    v = umax_dpp<0x141>(v);
+    v = umax_dpp<0x140>(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return max(r[0], r[1]);
+}
+__device__ __forceinline__ double half_min64(double v) {
+    v = raw_min(v, dpp_f64<0xB1>(v));
+    v = raw_min(v, dpp_f64<0x4E>(v));
+    v = raw_min(v, dpp_f64<0x141>(v));
+    v = raw_min(v, dpp_f64<0x140>(v));
+    double p, q;
+    cross_rows(v, p, q);
+    return raw_min(p, q);
+}
+
+template <int R>
+__global__ __launch_bounds__(64, 2) void corridor_dual_wave2_kernel(CorridorArgs a, int max_trips_extra) {
+    constexpr int ND = R - 1, NC = 2 * R;
+    const int lane = threadIdx.x, h = lane >> 5, c = lane & 31;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.queue = 0u;
+    const int n_eff = a.n_active ? *a.n_active : a.n_traj;
+    // (fewer trajectories than waves: one per wave, the upper half idle -- a lone trajectory does not wait for a partner's trips)
+    const bool single = n_eff <= (int)gridDim.x;
+    const long long n_pairs = single ? (long long)n_eff : ((long long)n_eff + 1) / 2;
+    for (long long pr = blockIdx.x; pr < n_pairs; pr += gridDim.x) {
+        const long long bq = single ? pr : 2 * pr + h;
+        const bool have = bq < n_eff && !(single && h == 1);
+        const int b = have ? (a.order ? a.order[bq] : (int)bq) : 0;
+        int s0 = 0, M = 0;
+        if (have) { if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; } }
+        const bool shape_ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;
+        const bool fits = shape_ok && M >= 2 && M - 1 <= 24;
+        const double* const TT = a.times + s0;
+        double Tl = 1.0;
+        bool bad = false;
+        if (have && shape_ok && M - 1 <= 24 && c < M) { Tl = TT[c]; bad = !((Tl > 0.0) && (Tl < INFINITY)); }
+        const unsigned long long hm = 0xFFFFFFFFull << (32 * h);
+        const bool t_ok = (__ballot(bad) & hm) == 0ull;
+        const bool solve = have && fits && t_ok;
+        if (have && !solve) {
+            // nothing to solve: an invalid trajectory (left untouched) or a single segment (its polynomial follows from the boundary data)
+            const bool valid1 = shape_ok && t_ok && M == 1;
+            if (c == 0) {
+                a.status[b] = (shape_ok && t_ok) ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
+                if (a.iters) a.iters[b] = 0;
+            }
+            if (c < 3) {
+                a.desc[3LL * b + c] = 0ull;
+                if (valid1 && a.active) { a.active[2 * (3LL * b + c)] = 0ull; a.active[2 * (3LL * b + c) + 1] = 0ull; }
+                if (valid1) {
+                    const long long base3 = 3LL * ((long long)s0 + b) + c;
+                    const double* bc = a.bc + (size_t)b * 2 * ND * 3 + c;
+                    double ys[ND], ye[ND], c1[NC];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) { ys[d] = bc[d * 3]; ye[d] = bc[(ND + d) * 3]; }
+                    const double Tk = TT[0];
+                    segment_coeffs_det<R>(a.waypoints[base3], ys, a.waypoints[base3 + 3], ye, Tk, fast_rcp(Tk), c1);
+                    if (!((fabs(c1[NC - 1]) < INFINITY) && (fabs(c1[R]) < INFINITY))) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+                    double* o = a.coeff + ((size_t)3 * s0 + c) * NC;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) o[j] = c1[j];
+                }
+            }
+        }
+        if (__ballot(solve) == 0ull) continue;
+        const int Ms = solve ? M : 2;                 // (keeps every index of a half without a problem in range)
+        const int n = Ms - 1;
+        const bool vc = solve && c < n;
+        const int cc = vc ? c : 0;
+        const bool wide = n > 16;                     // the cache was written by the shape that took the trajectory: 16 or 24 rows
+        const bool any_wide = __ballot(solve && wide) != 0ull;
+        const int NRWs = wide ? 24 : 16;
+        const double* const gc = a.gcache + (size_t)b * corridor_gcache_stride;
+        double pw[R];
+        {
+            const double sc = solve ? a.gscale[b] : 1.0;
+            pw[R - 1] = sc;
+#pragma unroll
+            for (int e = 1; e < R; ++e) pw[R - 1] *= sc;
+#pragma unroll
+            for (int q = R - 2; q >= 0; --q) pw[q] = pw[q + 1] * sc;
+        }
+        v16d G0, G1;
+        double dg0, cv[R], wv[R];
+        {
+            const double* const rowp = gc + (size_t)cc * NRWs;
+            double2 t0[8], t1[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t0[i] = solve ? *reinterpret_cast<const double2_a*>(rowp + 2 * i) : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t1[i] = (solve && wide) ? *reinterpret_cast<const double2_a*>(rowp + 16 + 2 * i) : make_double2(0.0, 0.0);
+            dg0 = solve ? rowp[cc] : 1.0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) { cv[q] = solve ? gc[NRWs * NRWs + cc * 2 * R + q] : 0.0; wv[q] = solve ? gc[NRWs * NRWs + cc * 2 * R + R + q] : 0.0; }
+            const double g = vc ? pw[0] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { G0[2 * i] = t0[i].x * g; G0[2 * i + 1] = t0[i].y * g; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { G1[2 * i] = t1[i].x * g; G1[2 * i + 1] = t1[i].y * g; }
+#pragma unroll
+            for (int i = 8; i < 16; ++i) G1[i] = 0.0;
+            dg0 = vc ? dg0 * pw[0] : 1.0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) { cv[q] *= pw[q]; wv[q] *= pw[q]; }
+        }
+        // ---------------- per axis: unconstrained minimiser and box of this lane's knot ----------------
+        double y0[3], lo3[3], hi3[3];
+        {
+            // (durations 0 and M - 1 of the own half: every lane of a half reads them from that half's lanes)
+            const int l0 = 32 * h, lM = 32 * h + Ms - 1;
+            const double T0 = __hiloint2double(__shfl(__double2hiint(Tl), l0, 64), __shfl(__double2loint(Tl), l0, 64));
+            const double TM = __hiloint2double(__shfl(__double2hiint(Tl), lM, 64), __shfl(__double2loint(Tl), lM, 64));
+            FullBlocks<R> seg0, segl;
+            seg0.build(solve ? T0 : 1.0);
+            segl.build(solve ? TM : 1.0);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const long long base3 = 3LL * ((long long)s0 + b) + ax;
+                const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+                double x0[R], xM[R], r1[R], rn[R];
+                x0[0] = solve ? a.waypoints[base3] : 0.0;
+                xM[0] = solve ? a.waypoints[base3 + 3LL * Ms] : 0.0;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { x0[d + 1] = solve ? bc[d * 3] : 0.0; xM[d + 1] = solve ? bc[(ND + d) * 3] : 0.0; }
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    double v1 = 0.0, vn = 0.0;
+#pragma unroll
+                    for (int q = 0; q < R; ++q) { v1 -= seg0.B01[q][i] * x0[q]; vn -= segl.B01[i][q] * xM[q]; }
+                    r1[i] = v1;
+                    rn[i] = vn;
+                }
+                lo3[ax] = vc ? a.corr_lo[base3 + 3LL * (cc + 1)] : 0.0;
+                hi3[ax] = vc ? a.corr_hi[base3 + 3LL * (cc + 1)] : 0.0;
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < R; ++q) v += cv[q] * r1[q] + wv[q] * rn[q];
+                y0[ax] = vc ? v : 0.0;
+            }
+        }
+        // box check and equality rows, per half
+        bool box_ok;
+        {
+            bool badb = false;
+            unsigned long long dsc[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                badb = badb || (vc && !(lo3[ax] <= hi3[ax]));
+                dsc[ax] = (((__ballot(vc && lo3[ax] == hi3[ax]) >> (32 * h)) & 0xFFFFFFFFull) << 1) | 1ull;
+            }
+            box_ok = (__ballot(badb) & hm) == 0ull;
+            if (solve && c == 0) {
+                a.status[b] = box_ok ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
+                if (a.iters) a.iters[b] = 0;
+            }
+            if (solve && c < 3) a.desc[3LL * b + c] = box_ok ? (c == 0 ? dsc[0] : (c == 1 ? dsc[1] : dsc[2])) : 0ull;
+        }
+        const bool run = solve && box_ok;
+        // ---------------- the three axes: both halves in lockstep ----------------
+        const int max_trips = 4 * n + 16 + max_trips_extra;
+#pragma unroll 1
+        for (int axis = 0; axis < 3; ++axis) {
+            const double lo = axis == 0 ? lo3[0] : (axis == 1 ? lo3[1] : lo3[2]);
+            const double hi = axis == 0 ? hi3[0] : (axis == 1 ? hi3[1] : hi3[2]);
+            double y = axis == 0 ? y0[0] : (axis == 1 ? y0[1] : y0[2]);
+            const double tol = 1e-12 * (1.0 + fmin(fabs(lo), fabs(hi)));
+            const double eqb = (vc && lo == hi) ? 1e300 : 0.0;
+            double dg = dg0, sw = 0.0, sdir = 0.0, muq = 0.0;
+            bool inW = false, done = !run;
+            int q = -1, trips = 0;
+            v16d A0 = G0, A1 = G1;
+            for (;;) {
+                // ---- entering constraint of the halves that need one: steepest dual ascent, ranked in single precision
+                if (__ballot(!done && q < 0) != 0ull) {
+                    const double below = lo - y, above = y - hi;
+                    const double viol = raw_max(below, above);
+                    const bool cand = vc && !inW && viol > tol && dg > 0.0;
+                    const float kf = eqb != 0.0 ? 3.0e38f : (float)raw_min(viol * viol * __builtin_amdgcn_rcp(dg), 1e38);
+                    const int cd = (int)half_umax(cand ? ((__float_as_uint(kf) & ~127u) | (unsigned)((below > above ? 64 : 0) | c)) : 0u);
+                    if (!done && q < 0) {
+                        if (cd >= 128 && trips < max_trips) { q = cd & 63; sdir = (cd & 64) ? 1.0 : -1.0; muq = 0.0; }
+                        else done = true;
+                    }
+                }
+                if (__ballot(!done) == 0ull) break;
+                const bool go = !done;
+                const int qq = go ? q : 0;
+                const int qA = __builtin_amdgcn_readlane(qq, 0), qB = __builtin_amdgcn_readlane(qq, 32);
+                const double aqA = pick_row2<R>(A0, A1, qA), aqB = pick_row2<R>(A0, A1, qB);
+                const double aq = h ? aqB : aqA;
+                const double d = go ? sdir * (c == qq ? dg : aq) : 0.0;
+                const double pvl = rcp1(dg);
+                const double t1l = ((sdir > 0.0 ? lo : hi) - y) * sdir * pvl;
+                const double t1A = readlane_f64(t1l, qA), t1B = readlane_f64(t1l, 32 + qB);
+                const double t1 = h ? t1B : t1A;
+                const bool blocks = sw * d > 0.0;
+                const double ratio = raw_min(raw_max(-y * rcp1(d), 0.0), 1e299);
+                const double rmin = half_min64(blocks ? pack_code7(ratio, c) : 1e300);
+                const bool partial = go && rmin < t1;
+                const double t = go ? (partial ? rmin : t1) : 0.0;
+                const int kp = partial ? (code7_of(rmin) & 63) : qq;
+                y = fma(t, d, y);
+                muq = fma(sdir, t, muq);
+                // ---- sweep on the pivot: the constraint q enters (full step) or the blocking one leaves (partial step)
+                const int kA = __builtin_amdgcn_readlane(kp, 0), kB = __builtin_amdgcn_readlane(kp, 32);
+                const double akA = pick_row2<R>(A0, A1, kA), akB = pick_row2<R>(A0, A1, kB);
+                const double ak = h ? akB : akA;
+                const bool pc = go && c == kp;
+                const double tc = go ? (pc ? dg - (partial ? -1.0 : 1.0) : ak) : 0.0;
+                const double pvA = readlane_f64(pvl, kA), pvB = readlane_f64(pvl, 32 + kB);
+                const double piv = go ? (h ? pvB : pvA) : 0.0;
+                const double scl = tc * piv;
+                const double dn = fma(-tc, scl, dg);
+                dg = pc ? -piv : dn;
+                const double yb = sw < 0.0 ? hi : lo;
+                y = pc ? (partial ? yb : -muq) : y;
+                sw = pc ? ((partial || eqb != 0.0) ? 0.0 : sdir) : sw;
+                inW = pc ? !partial : inW;
+                {
+                    double ta, tb;
+                    cross_rows(tc, ta, tb);          // [r0 r0 r2 r2], [r1 r1 r3 r3]: rows 0-15 / 16-31 of each half's own t
+                    const double ns = -scl;
+                    sweep16(A0, ta, ns);
+                    if (any_wide) sweep16(A1, tb, ns);
+                }
+                if (go) {
+                    if (!partial) q = -1;
+                    ++trips;
+                }
+            }
+            // ---- hand the working set of this axis over (bit k = interior knot k, as the solve kernel reads it)
+            const unsigned long long bw = __ballot(inW && sw != 0.0), bu = __ballot(inW && sw < 0.0);
+            if (run && c == 0) {
+                a.guess[2 * (3LL * b + axis)] = ((bw >> (32 * h)) & 0xFFFFFFFFull) << 1;
+                a.guess[2 * (3LL * b + axis) + 1] = ((bu >> (32 * h)) & 0xFFFFFFFFull) << 1;
+            }
+        }
+    }
+}
+
 }  // namespace uavqp

@@ -740,7 +740,8 @@ struct uavqp_ctx {
     size_t rows_warm2_bytes = 0;
     void* dbg_queue = nullptr;  // (debug builds) where the last corridor solve kept its work counter
     int dual_trips_extra = 0;   // added to the trip budget 4 n + 16 of the dual preludes (UAVQP_DUAL_TRIPS_EXTRA, may be negative: tools/ experiments)
-    int wave_prelude = 1;       // re-solves with G in the cache: corridor_dual_wave_kernel (UAVQP_NO_WAVE_PRELUDE: the batch kernels, for A/B runs)
+    int wave_prelude = 2;       // re-solves with G in the cache: 2 = corridor_dual_wave2_kernel (two trajectories per wave), 1 = corridor_dual_wave_kernel (one),
+                                // 0 = the batch kernels (UAVQP_WAVE_PRELUDE=0|1|2, UAVQP_NO_WAVE_PRELUDE: A/B runs)
     void* dbg_dual = nullptr;   // (UAVQP_DUAL_DEBUG builds) dump area of corridor_dual_kernel
     void* dbg_guess = nullptr;  // (UAVQP_DUAL_DEBUG builds) the starting sets of the last cold corridor solve
     int32_t* perm = nullptr;  // ragged dealing permutation (window_sort_kernel); behind it the packed {b, s0, M, 0} records
@@ -871,6 +872,7 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
     if (std::getenv("UAVQP_NO_LSORT")) ctx->settings.ragged_window_sort = 0;
     if (std::getenv("UAVQP_NO_WAVE_PRELUDE")) ctx->wave_prelude = 0;
     if (const char* e = std::getenv("UAVQP_DUAL_TRIPS_EXTRA")) ctx->dual_trips_extra = std::atoi(e);
+    if (const char* e = std::getenv("UAVQP_WAVE_PRELUDE")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) ctx->wave_prelude = v; }
     if (const char* e = std::getenv("UAVQP_GENERIC_NAX")) ctx->settings.generic_lanes_per_traj = std::atoi(e) == 3 ? 1 : 3;
     if (const char* e = std::getenv("UAVQP_GENERIC_WPC")) {
         const int w = std::atoi(e);
@@ -1452,10 +1454,17 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     }
     if (dual && gcache_mode == 2 && d_gcache && d_gscale && ctx->wave_prelude) {
         // G of every trajectory is in the cache of an earlier solve of this outer loop: one trajectory per wave, no chain, no lockstep
-        long long wgrid = (long long)n_traj < (long long)ctx->num_cus * 12 ? (long long)n_traj : (long long)ctx->num_cus * 12;
-        if (wgrid < 1) wgrid = 1;
-        if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<3>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
-        else hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<4>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
+        if (ctx->wave_prelude == 2) {   // two trajectories per wave (lanes 0-31 / 32-63)
+            long long wgrid = (long long)n_traj < (long long)ctx->num_cus * 8 ? (long long)n_traj : (long long)ctx->num_cus * 8;
+            if (wgrid < 1) wgrid = 1;
+            if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_wave2_kernel<3>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
+            else hipLaunchKernelGGL((uavqp::corridor_dual_wave2_kernel<4>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
+        } else {
+            long long wgrid = (long long)n_traj < (long long)ctx->num_cus * 12 ? (long long)n_traj : (long long)ctx->num_cus * 12;
+            if (wgrid < 1) wgrid = 1;
+            if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<3>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
+            else hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<4>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
+        }
     } else if (dual) {
         // groups of 8 lanes (two tableau columns each) for the trajectories of up to 17 segments, whole DPP rows for the longer ones: a batch
         // of mixed lengths gets both launches, each skipping (per wave: the dealing order is by length) what the other one takes
