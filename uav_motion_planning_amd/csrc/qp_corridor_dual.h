@@ -28,6 +28,11 @@
 //   * reductions over the group (best entering constraint, first blocking multiplier) are DPP butterflies on doubles that carry
 //     the column index in their low mantissa bits.
 // Rows and columns beyond n are zero and never selected; ragged batches pad the chain with decoupled identity knots.
+//
+// Three kernels share the method: corridor_dual_kernel / corridor_dual_mixed_kernel (the batch shapes above: they build G, and with
+// prep_in_dual they are also the reset / validation / descriptor kernel of the solve), and -- for the re-solves of an outer loop whose G
+// is in the cache (gcache_mode 2) -- corridor_dual_wave_kernel / corridor_dual_wave2_kernel at the end of this file: one / two
+// trajectories per wave, wave- / half-uniform pivots, a trip without LDS (the wave-wide helpers below).
 #pragma once
 #include "qp_corridor.h"
 

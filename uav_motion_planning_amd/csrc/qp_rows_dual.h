@@ -4,18 +4,20 @@
 // A row is a linear functional of the Hermite states of the two end knots of its segment, c' x = g_l' x_i + g_r' x_{i+1}
 // (row_functional, qp_rows.h); a knot box is the functional e_0' x_k.  The dual method only needs the dense matrix
 // G_ij = c_i' H^-1 c_j over all constraints and their unconstrained values c_j' H^-1 rhs.  Both come from the chain of
-// qp_corridor_dual.h: with z_j = H^-1 c_j, the components of z_j at and above its own knots follow the back-substitution
-//     z^(k) = dR Z_kk (g_r - E_{k-1}' g_l) + dL S_k^-1 g_l - E_k z^(k+1)        (dR: k = i + 1, dL: k = i; zero below the start)
-// and G_ij = g_l,i' z_j^(k_i) + g_r,i' z_j^(k_i + 1) is taken whenever constraint i does not sit behind constraint j (the other
-// half by symmetry).  This is the QP of rows_pair_kernel itself, not a relaxation: the set the dual method ends with is that
+// qp_corridor_dual.h: with z_j = H^-1 c_j, the components of z_j at its own knots and at the knots before them follow the back-substitution
+//     z^(k) = dR Z_kk (g_r - E_{k-1}' g_l) + dL S_k^-1 g_l - E_k z^(k+1)        (dR: k = i + 1, dL: k = i; nothing is computed behind i + 1)
+// and G_ij = g_l,i' z_j^(k_i) + g_r,i' z_j^(k_i + 1) is taken for i <= j in constraint order (constraints are numbered along the knots; the
+// other half by symmetry: only the lower triangle of G is stored).  This is the QP of rows_pair_kernel itself, not a relaxation: the set the dual method ends with is that
 // QP's working set.  (The first version refined the time grid by a knot at every row and bounded components of the inserted knots --
 // a relaxation, an inserted knot with an active row may break the higher derivatives: 3.65 verifying solves mean instead of 1.)
 // BASELINE config 3 with K = 2 rows per segment: 15 knots, 47 constraints per axis, ~7 active at the solution, ~9 exchanges.
 // As in qp_corridor_dual.h nothing here decides a result: the set goes to rows_pair_kernel as its starting working set.
 //
-// One trajectory per wave: lane c owns tableau column c (48 rows) in registers, lane s also prepares segment s (functionals of its
-// rows); every branch of the dual loop is wave-uniform.  Handled: at most 48 constraints ((M - 1) + used rows), M <= 32; anything else
-// is left to the box phase (need_phase1) and starts the rows solve from the box set as before.
+// One trajectory per wave: lane c owns tableau column c (48 rows: three 16-row register vectors), lane s also prepares segment s
+// (functionals of its rows); every branch of the dual loop is wave-uniform and a trip touches no LDS (own-row symmetry, v_fmac_f64
+// row_newbcast sweep, permlane reductions: see the loop).  The 3 x 3 chain quantities, the same for all lanes, come from
+// rows_chain_kernel (one LANE per trajectory) through HBM and an LDS-DMA copy.  Handled: at most 48 constraints ((M - 1) + used rows),
+// M <= 32; anything else is left to the box phase (need_phase1) and starts the rows solve from the box set as before.
 #pragma once
 #include "qp_corridor_dual.h"
 #include "qp_rows2.h"
