@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Soak of the config-5 pipeline's re-solve preludes (GPU box): python tools/soak_pipeline.py [draws] [seed]
+Random ragged batches (order, lengths, sizes, cloud densities, limits that force several re-allocation rounds); every draw runs the
+pipeline with UAVQP_WAVE_PRELUDE = 2 (two trajectories per wave), 1 (one) and 0 (batch preludes) and compares coefficients, durations,
+boxes, statuses, collision flags, rounds and repairs bit for bit -- the preludes only hand starting sets to the exact solve."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import uav_motion_planning_amd as U  # noqa: E402
+from uav_motion_planning_amd import pipeline as P  # noqa: E402
+from uav_motion_planning_amd import workloads as W  # noqa: E402
+
+draws = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda", 0)
+up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+rounds_seen = []
+for it in range(draws):
+    r = int(rng.choice([3, 4]))
+    m_hi = int(rng.integers(3, 25))
+    m_lo = int(rng.integers(1, m_hi + 1))
+    n = int(rng.choice([1, 2, 3, 63, 64, 65, 257, 1000, 4097]))
+    b = W.ragged_batch(5, n, r, m_lo=m_lo, m_hi=m_hi, seed=int(rng.integers(1 << 30)))
+    so = b["seg_offsets"]
+    obs = W.pillar_cloud(5, n_pillars=int(rng.integers(5, 80)), resolution=0.25)
+    kw = dict(max_segments=m_hi, v_max=float(rng.choice([2.0, 4.0, 7.0])), a_max=float(rng.choice([4.0, 10.0])), max_rounds=int(rng.integers(1, 7)))
+    out = {}
+    for tag in ("2", "1", "0"):
+        os.environ["UAVQP_WAVE_PRELUDE"] = tag
+        with U.Context(0) as ctx:
+            d_so, d_wp, d_T, d_bc, d_obs = up(so), up(np.asarray(b["waypoints"]).reshape(-1, 3)), up(b["times"]), up(b["bc"]), up(obs)
+            res = P.corridor_pipeline_device(ctx, r, d_so, d_wp, d_T, d_bc, d_obs, **kw)
+            ctx.synchronize()
+            out[tag] = (res["coeff"].cpu().numpy(), d_T.cpu().numpy(), res["corr_lo"].cpu().numpy(), res["corr_hi"].cpu().numpy(),
+                        res["status"].cpu().numpy(), res["first_hit"].cpu().numpy(), res["rounds"], res["repairs"])
+    os.environ.pop("UAVQP_WAVE_PRELUDE", None)
+    for tag in ("2", "1"):
+        for k, (a, c) in enumerate(zip(out[tag], out["0"])):
+            same = np.array_equal(a, c, equal_nan=True) if isinstance(a, np.ndarray) else a == c
+            assert same, (it, tag, k, r, n, m_lo, m_hi, kw)
+    rounds_seen.append(out["0"][6])
+print("pipeline soak ok: %d draws, seed %d, rounds per draw %s" % (draws, seed, rounds_seen))
