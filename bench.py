@@ -415,7 +415,7 @@ def main():
         if args.config == 5:
             # the whole device pipeline per step (uav_motion_planning_amd/pipeline.py): plain solve -> corridor boxes from the pillar
             # cloud (SE(3) robot ellipsoid) -> <= 5 x (warm-started corridor solve + time re-allocation) -> grid collision check
-            # (+ repair of what it flags).  Host-sequenced in C++ behind the C ABI (one counter read-back per round): no graph, no pipelined sub-record.
+            # (+ repair of what it flags).  Host-sequenced in C++ behind the C ABI (a round counter read back behind an event, no stream stop per round): no graph, no pipelined sub-record.
             obstacles = W.pillar_cloud(5, n_pillars=60, resolution=0.2)       # the same map on every rank (seeded)
             bytes_local += int(sum(8 * 2 * 3 * (int(m) - 1) for m in Ms))     # corridor rows
             args.graph = 0
