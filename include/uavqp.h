@@ -373,8 +373,10 @@ int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  *   are halved towards its waypoints -- in the last repair round collapsed onto them: the reference's equality rows --, warm re-solve,
  *   one re-allocation, re-solve if that stretched anything, check again).  A colliding trajectory with an interior waypoint whose box
  *   is degenerate (the cloud leaves no room around the searcher's waypoint) cannot be helped by narrower boxes: counted, not repaired.
- * Loop control is data dependent: one 64-byte device-to-host copy and one stream synchronisation per round; the call returns with
- * the stream idle (SYNCHRONOUS).
+ * Loop control is data dependent: the number of trajectories a round stretched travels to the host behind an event (the host waits for
+ * the event, not for the stream; while rounds still stretch more than n_traj / 64 trajectories the next round is enqueued before the
+ * count is looked at -- a round that turns out to be unnecessary changes no byte); the check and the summary read their counters with a
+ * stream synchronisation each, and the call returns with the stream idle (SYNCHRONOUS).
  *   total_segments      sum_b M_b (the host knows it: it sized the buffers); uniform batches: n_traj * uniform_segments
  *   d_times             [total_segments] IN / OUT: stretched in place by the re-allocation (never shrunk)
  *   grid                uniform grid over d_obstacles with cell = check radius + 0.1 (uavqp_obstacle_grid_build_device), or NULL: built
