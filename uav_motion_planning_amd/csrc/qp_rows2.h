@@ -50,48 +50,83 @@ struct Rows2Args {
     int lam_knots;              // own knots per lane in `lam` (= own segments per lane in `gfun`)
 };
 
-// validation + permanent masks, one lane per (trajectory, axis) problem.  desc[0]: bit 0 = valid, bit 1 = has a free knot (M >= 2),
-// bits 8.. = M; desc[1] = knot boxes with lo == hi; then per row slot: used mask, equality mask (bit = ORIGINAL segment).
+// validation + permanent masks.  desc[0]: bit 0 = valid, bit 1 = has a free knot (M >= 2), bits 8.. = M; desc[1] = knot boxes with
+// lo == hi; then per row slot: used mask, equality mask (bit = ORIGINAL segment).
+// One trajectory per wave, lane s = segment s (and interior knot s), all three axes: every array is read in contiguous runs and the
+// masks are ballots.  (Round 2-4: one lane per (trajectory, axis) walking its own 1.3 KB of strided inputs -- 0.77 GB of fetch for
+// 0.24 GB of inputs on config 3 + K = 2, 132 us.)
 template <int R, int K>
 __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
     const RowsArgs& a = aa.r;
-    const long long total = (long long)a.n_traj * 3;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(q / 3), ax = (int)(q - 3LL * b);
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long bq = (long long)blockIdx.x * (blockDim.x >> 6) + wib; bq < a.n_traj; bq += n_waves) {
+        const int b = (int)bq;
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
-        const long long base3 = 3LL * ((long long)s0 + b) + ax;
-        bool ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;
-        unsigned long long eq = 0ull, used[K], req[K];
+        const bool shape_ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;
+        const bool seg = shape_ok && lane < M;                  // this lane has a segment
+        bool t_bad = false;
+        if (seg) { const double t = a.times[s0 + lane]; t_bad = !((t > 0.0) && (t < INFINITY)); }
+        const bool t_ok = shape_ok && __ballot(t_bad) == 0ull;
+        // knot boxes: lane k = interior knot k = 1..M-1, the three axes are 24 contiguous bytes per array
+        const bool knot = t_ok && lane >= 1 && lane < M;
+        bool kbad[3] = {false, false, false}, keq[3] = {false, false, false};
+        if (knot) {
+            const long long at = 3LL * ((long long)s0 + b + lane);
 #pragma unroll
-        for (int j = 0; j < K; ++j) { used[j] = 0ull; req[j] = 0ull; }
-        if (ok)
-            for (int i = 0; i < M; ++i) { const double t = a.times[s0 + i]; ok = ok && (t > 0.0) && (t < INFINITY); }
-        if (ok) {
-            for (int k = 1; k < M; ++k) {
-                const double l = a.corr_lo ? a.corr_lo[base3 + 3 * k] : a.waypoints[base3 + 3 * k];
-                const double h = a.corr_hi ? a.corr_hi[base3 + 3 * k] : a.waypoints[base3 + 3 * k];
-                ok = ok && (l <= h);
-                if (l == h) eq |= 1ull << k;
+            for (int ax = 0; ax < 3; ++ax) {
+                const double l = a.corr_lo ? a.corr_lo[at + ax] : a.waypoints[at + ax];
+                const double h = a.corr_hi ? a.corr_hi[at + ax] : a.waypoints[at + ax];
+                kbad[ax] = !(l <= h);
+                keq[ax] = l == h;
             }
-            for (int s = 0; s < M; ++s)
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int d = a.row_deriv[(size_t)(s0 + s) * K + j];
-                    if (d < 0) continue;
-                    const double tau = a.row_tau[(size_t)(s0 + s) * K + j];
-                    const double l = a.row_lo[((size_t)(s0 + s) * K + j) * 3 + ax], h = a.row_hi[((size_t)(s0 + s) * K + j) * 3 + ax];
-                    ok = ok && (d < R) && (tau >= 0.0) && (tau < 1.0) && (l <= h) && !(tau == 0.0 && d == 0);
-                    used[j] |= 1ull << s;
-                    if (l == h) req[j] |= 1ull << s;
-                }
         }
-        if (!ok) atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
-        unsigned long long* o = aa.desc + (size_t)q * (2 + 2 * K);
-        o[0] = ok ? (1ull | (M >= 2 ? 2ull : 0ull) | ((unsigned long long)M << 8)) : 0ull;
-        o[1] = eq;
+        // rows of segment `lane`
+        bool rused[K], rbad_any[K], rbad[K][3], req[K][3];
 #pragma unroll
-        for (int j = 0; j < K; ++j) { o[2 + 2 * j] = used[j]; o[3 + 2 * j] = req[j]; }
+        for (int j = 0; j < K; ++j) {
+            rused[j] = false; rbad_any[j] = false;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { rbad[j][ax] = false; req[j][ax] = false; }
+        }
+        if (t_ok && lane < M) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const size_t e = (size_t)(s0 + lane) * K + j;
+                const int d = a.row_deriv[e];
+                if (d < 0) continue;
+                const double tau = a.row_tau[e];
+                rused[j] = true;
+                rbad_any[j] = !((d < R) && (tau >= 0.0) && (tau < 1.0) && !(tau == 0.0 && d == 0));
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double l = a.row_lo[e * 3 + ax], h = a.row_hi[e * 3 + ax];
+                    rbad[j][ax] = !(l <= h);
+                    req[j][ax] = l == h;
+                }
+            }
+        }
+        unsigned long long used[K], anybad = 0ull;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { used[j] = __ballot(rused[j]); anybad |= __ballot(rbad_any[j]); }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            unsigned long long bad = anybad | __ballot(kbad[ax]);
+            const unsigned long long eq = __ballot(keq[ax]);
+            unsigned long long rq[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) { bad |= __ballot(rbad[j][ax]); rq[j] = __ballot(req[j][ax]); }
+            const bool ok = t_ok && bad == 0ull;
+            if (lane == ax) {
+                if (!ok) atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
+                unsigned long long* o = aa.desc + ((size_t)3 * b + ax) * (2 + 2 * K);
+                o[0] = ok ? (1ull | (M >= 2 ? 2ull : 0ull) | ((unsigned long long)M << 8)) : 0ull;
+                o[1] = eq;
+#pragma unroll
+                for (int j = 0; j < K; ++j) { o[2 + 2 * j] = used[j]; o[3 + 2 * j] = rq[j]; }
+            }
+        }
     }
 }
 

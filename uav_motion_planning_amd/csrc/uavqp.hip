@@ -1755,7 +1755,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
         if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
         aa.r = a;
-        long long pgrid = (pairs + 255) / 256;
+        long long pgrid = ((long long)n_traj + 3) / 4;          // rows_prep_kernel: one trajectory per wave, four waves per block
         if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
         long long ggrid = (total_seg * K + 255) / 256;
         if (ggrid > (long long)ctx->num_cus * 16) ggrid = (long long)ctx->num_cus * 16;
