@@ -127,7 +127,14 @@ __device__ __forceinline__ bool corridor_takes_part(const int32_t* only_i32, con
 // Dealing order of a masked re-solve: the entries of `order` (null: 0, 1, 2, ...) whose trajectory takes part, in the same sequence (the
 // order is by segment count: waves keep trajectories of similar length), and their number.  One workgroup: a block scan over n_traj flags.
 __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __restrict__ order, int n_traj, const int32_t* __restrict__ only_i32,
-                                                             const unsigned char* __restrict__ only_u8, int32_t* __restrict__ out, int* __restrict__ n_out) {
+                                                             const unsigned char* __restrict__ only_u8, int32_t* __restrict__ out, int* __restrict__ n_out,
+                                                             const unsigned int* __restrict__ none_if_zero = nullptr) {
+    // (a caller that counted the participating trajectories while it flagged them passes the count: nothing to scan when it is zero --
+    // the rows solve, whose prelude usually takes every trajectory and leaves the box phase none)
+    if (none_if_zero && *none_if_zero == 0u) {
+        if (threadIdx.x == 0) *n_out = 0;
+        return;
+    }
     // wave w takes the contiguous slice [w per, (w + 1) per) in sub-chunks of 64 (all loads of a lane in flight together: two round trips
     // per pass of 16 sub-chunks, not one per element), ranks by ballot; the 16 wave totals are scanned through LDS
     __shared__ int s_tot[16];

@@ -30,6 +30,7 @@ struct RowsDualArgs {
     unsigned long long* warm_box;    // [problem][2]: (active, upper) of the knot boxes, bit k = interior knot k -- written for handled trajectories
     unsigned long long* warm_rows;   // [problem][2 K]: (active, upper) per row slot, bit s = segment s -- zeroed by the host, written for handled ones
     unsigned char* need_phase1;      // [n_traj]: 1 = not handled here
+    unsigned int* n_phase1;          // their number (zeroed by the host)
     const double* gfun;              // [segment][K][2 R]: g_l, g_r of every row (rows_gfun_kernel, launched before this kernel)
     const double* kd;                // [segment][rows_chain_doubles(R)]: the chain records of rows_chain_kernel (launched before this kernel)
 #ifdef UAVQP_DUAL_DEBUG
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         s0 = __builtin_amdgcn_readfirstlane(s0);
         M = __builtin_amdgcn_readfirstlane(M);
         const bool shape_ok = M >= 2 && M <= 32 && (a.uniform > 0 || M <= a.max_segments);
-        if (!shape_ok) { if (lane == 0) aa.need_phase1[b] = 1; continue; }
+        if (!shape_ok) { if (lane == 0) { aa.need_phase1[b] = 1; atomicAdd(aa.n_phase1, 1u); } continue; }
         const int n = M - 1;
         RD_T_DECL
         lds_publish();
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             NC += ci;
         }
         const bool handled = (__ballot(segok) == ~0ull) && NC <= NRW;
-        if (!handled) { if (lane == 0) aa.need_phase1[b] = 1; wait_vmcnt0(); continue; }
+        if (!handled) { if (lane == 0) { aa.need_phase1[b] = 1; atomicAdd(aa.n_phase1, 1u); } wait_vmcnt0(); continue; }
         if (lane == 0) aa.need_phase1[b] = 0;
         if (myseg) {
 #pragma unroll

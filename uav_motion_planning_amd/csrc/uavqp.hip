@@ -1617,11 +1617,15 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     unsigned long long* d_warm_rows = nullptr;
     unsigned char* d_need_phase1 = nullptr;
     double* d_gfun_pre = nullptr;
+    unsigned int* d_n_phase1 = nullptr;
+    int32_t* d_cp1 = nullptr;
+    int* d_na1 = nullptr;
     if (prelude) {
         const size_t b_wr = align256(sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_), b_np = align256((size_t)n_traj);
         const size_t b_gf = align256(sizeof(double) * (size_t)(rows - n_traj) * K_ * 2 * r);     // row functionals: made here, used by the prelude AND the rows kernel
         const size_t b_kd = align256(sizeof(double) * (size_t)(rows - n_traj) * uavqp::rows_chain_doubles(r));   // chain records per segment (rows_chain_kernel)
-        const size_t need = b_wr + b_np + b_gf + b_kd;
+        const size_t b_cp = align256(sizeof(int32_t) * (size_t)n_traj) + 256;     // compacted order of the box phase + its count
+        const size_t need = b_wr + b_np + 256 + b_gf + b_kd + b_cp;
         if (need > ctx->rows_warm2_bytes) {
             UAVQP_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->rows_warm2) UAVQP_HIP(hipFree(ctx->rows_warm2));
@@ -1632,9 +1636,12 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         }
         d_warm_rows = (unsigned long long*)ctx->rows_warm2;
         d_need_phase1 = (unsigned char*)ctx->rows_warm2 + b_wr;
-        d_gfun_pre = (double*)((char*)ctx->rows_warm2 + b_wr + b_np);
-        double* const d_kd = (double*)((char*)ctx->rows_warm2 + b_wr + b_np + b_gf);
-        UAVQP_HIP(hipMemsetAsync(ctx->rows_warm2, 0, b_wr + b_np, ctx->stream));
+        d_n_phase1 = (unsigned int*)((char*)ctx->rows_warm2 + b_wr + b_np);
+        d_gfun_pre = (double*)((char*)ctx->rows_warm2 + b_wr + b_np + 256);
+        double* const d_kd = (double*)((char*)ctx->rows_warm2 + b_wr + b_np + 256 + b_gf);
+        d_cp1 = (int32_t*)((char*)ctx->rows_warm2 + b_wr + b_np + 256 + b_gf + b_kd);
+        d_na1 = (int*)((char*)d_cp1 + align256(sizeof(int32_t) * (size_t)n_traj));
+        UAVQP_HIP(hipMemsetAsync(ctx->rows_warm2, 0, b_wr + b_np + 256, ctx->stream));
         {
             uavqp::Rows2Args ga{};
             ga.r.row_tau = d_row_tau; ga.r.row_deriv = d_row_deriv; ga.r.times = d_times;
@@ -1655,7 +1662,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         da.r.corr_lo = d_corr_lo; da.r.corr_hi = d_corr_hi; da.r.row_tau = d_row_tau; da.r.row_deriv = d_row_deriv; da.r.row_lo = d_row_lo; da.r.row_hi = d_row_hi;
         da.order = nullptr;
         da.warm_box = (unsigned long long*)ctx->rows_warm; da.warm_rows = d_warm_rows; da.need_phase1 = d_need_phase1; da.gfun = d_gfun_pre;
-        da.kd = d_kd;
+        da.kd = d_kd; da.n_phase1 = d_n_phase1;
         {   // the chain of every trajectory once, one lane each (the prelude's waves would each repeat it in 64 lanes)
             long long cg = ((long long)n_traj + 63) / 64;
             if (cg > (long long)ctx->num_cus * 16) cg = (long long)ctx->num_cus * 16;
@@ -1679,10 +1686,13 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         else hipLaunchKernelGGL((uavqp::rows_dual_kernel<4, 2>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
     }
     if (warm) {
-        // (with the prelude: only for the trajectories it did not take)
+        // (with the prelude: only for the trajectories it did not take -- their dealing order is compacted here, where their count is known:
+        // usually zero, and then nothing is scanned)
+        if (prelude) hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)nullptr, n_traj, (const int32_t*)nullptr,
+                                        (const unsigned char*)d_need_phase1, d_cp1, d_na1, (const unsigned int*)d_n_phase1);
         const int rc1 = corridor_warm_impl(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times,
                                            d_bc, d_corr_lo, d_corr_hi, d_coeff_out, d_status_out, nullptr, ctx->rows_warm, 0, rows - n_traj, nullptr,
-                                           nullptr, d_need_phase1);
+                                           nullptr, d_need_phase1, nullptr, nullptr, 0, prelude ? d_cp1 : nullptr, prelude ? d_na1 : nullptr);
         if (rc1 != UAVQP_OK) return rc1;
     }
 #ifdef UAVQP_DUAL_DEBUG
