@@ -65,9 +65,13 @@ def parse():
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--no-fp64", action="store_true", help="skip the rocprofv3 passes that fill roofline.fp64 and the per-kernel table")
+    ap.add_argument("--kernels-only", action="store_true", help="with --no-fp64: still run the rocprofv3 --kernel-trace --stats pass that fills the per-kernel table (durations, no FP64 counters)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the barrier / communicator / all-gather code even at world size 1 (self-test)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # child run under rocprofv3: kernels only
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default invocation (config 2, one GPU): skip the `other_configs` sub-record (short runs of configs 3, 3 + rows, 4, 5 and the config-1 latency)")
+    ap.add_argument("--master-port", type=int, default=0, help="--gpus N > 1 without a launcher: rendezvous port of the ranks this script spawns (0 = a free one)")
     ap.add_argument("--data", default="astar", choices=["astar", "uniform"],
                     help="astar: configs[1] generator; uniform: iid waypoints/times (tuning aid)")
     return ap.parse_args()
@@ -313,8 +317,8 @@ def measure_kernel_times(args, steps):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def main():
-    args = parse()
+def run(args):
+    """One bench record (a dict on rank 0, None elsewhere and for --inner child runs)."""
     import torch
     import torch.distributed as dist
 
@@ -340,7 +344,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, or without a launcher: the script spawns its ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the uavqp product path has no CPU fallback")
     if backend not in (None, "nccl"):
@@ -385,14 +390,7 @@ def main():
             rows_np = None
             if args.rows:
                 K_ = args.rows
-                wpn = np.asarray(batch["waypoints"])
-                tau = np.full((B * M, K_), 0.5)
-                drv = np.tile(np.array([0, 1], dtype=np.int32), (B * M, 1))
-                mid = 0.5 * (wpn[:, :-1] + wpn[:, 1:]).reshape(B * M, 3)
-                rlo, rhi = np.zeros((B * M, K_, 3)), np.zeros((B * M, K_, 3))
-                rlo[:, 0], rhi[:, 0] = mid - 0.25, mid + 0.25
-                rlo[:, 1], rhi[:, 1] = -3.5, 3.5
-                rows_np = (tau, drv, rlo, rhi)
+                rows_np = W.config3_rows(batch, K_)
                 bytes_local += B * M * K_ * (8 + 4 + 2 * 3 * 8)
             workload = (f"configs[2]: batch of {B} independent {M}-segment minimum-jerk (r=3) 3-axis trajectories per GPU, interior waypoints relaxed to "
                         f"corridor boxes (half-width U(0.3, 0.8) m)" + (f" + {args.rows} general rows per segment (mid-segment position sample, velocity limit)" if args.rows else "")
@@ -543,7 +541,7 @@ def main():
     elif n_local > 0:
         assert int((d_st[:n_local] == U.UAVQP_SOLVED).sum().item()) == n_local, "some trajectories were not solved"
     if args.inner:
-        return
+        return None
 
     # ------------------------------------------------------------------ config 2: the same block on the OTHER time allocation of SURVEY 8-d
     # (reference: T_i = 1.0, test_minimum_jerk.cpp:65-71; distance: T_i = max(0.3, |dp| / 2 m/s)) -- same kernel, same bytes, other numbers
@@ -689,20 +687,23 @@ def main():
         traffic = measure_traffic(args) if (world == 1 and not args.no_traffic) else None
         # FP64 roof ("report FP64 FLOP/s next to GB/s") and per-kernel view, from counters / traces of child runs
         fp64 = kernels = None
-        if world == 1 and not args.no_fp64:
+        if world == 1 and (not args.no_fp64 or args.kernels_only):
             prof_steps = 2 if args.config == 5 else (6 if args.config == 3 else 40)
-            trace_steps = 2 if args.config == 5 else (20 if args.config == 3 else 1000)   # the trace is cheap: enough launches that the average is the steady state
-            f64 = measure_fp64(args, prof_steps)
+            trace_steps = 2 if args.config == 5 else ((4 if args.rows else 20) if args.config == 3 else 1000)   # the trace is cheap: enough launches that the average is the steady state
+            f64 = measure_fp64(args, prof_steps) if not args.no_fp64 else None
             kt = measure_kernel_times(args, trace_steps)
-            if f64 and kt:
+            if kt:
                 kernels = []
                 tot_us = sum(v["total_us"] for v in kt.values())
                 for name, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_us"]):
-                    fl = f64.get(name, {}).get("flops_per_launch", 0.0)
-                    kernels.append({"kernel": name, "launches_per_step": v["calls"] / (trace_steps + 1), "avg_us": v["avg_us"],
-                                    "share_of_gpu_time": v["total_us"] / tot_us if tot_us else None, "fp64_flops_per_launch": fl,
-                                    "fp64_tflops": fl / (v["avg_us"] * 1e-6) / 1e12 if v["avg_us"] > 0 else None,
-                                    "fp64_frac_of_vector_peak": fl / (v["avg_us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if v["avg_us"] > 0 else None})
+                    k_ = {"kernel": name, "launches_per_step": v["calls"] / (trace_steps + 1), "avg_us": v["avg_us"],
+                          "share_of_gpu_time": v["total_us"] / tot_us if tot_us else None}
+                    if f64:
+                        fl = f64.get(name, {}).get("flops_per_launch", 0.0)
+                        k_.update({"fp64_flops_per_launch": fl, "fp64_tflops": fl / (v["avg_us"] * 1e-6) / 1e12 if v["avg_us"] > 0 else None,
+                                   "fp64_frac_of_vector_peak": fl / (v["avg_us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if v["avg_us"] > 0 else None})
+                    kernels.append(k_)
+            if f64 and kt:
                 dom = kernels[0]
                 step_flops = sum(k_["fp64_flops_per_launch"] * k_["launches_per_step"] for k_ in kernels)
                 # ONE clock per record: `achieved` / `frac` are the step's FP64 work over the SAME HIP-event time per step that
@@ -776,6 +777,10 @@ def main():
             out["corridor"] = {"iterations_mean": float(d_it[:n_local].double().mean().item()), "iterations_max": int(d_it[:n_local].max().item()),
                                "solved": int((d_st[:n_local] == U.UAVQP_SOLVED).sum().item()), "rows_per_segment": args.rows,
                                "note": "block solves per (trajectory, axis) problem after the position-space dual prelude (uavqp_settings.corridor_initial_guess = 2)"}
+        if args.config == 5 and "res" in pipe_state:
+            pr = pipe_state["res"]
+            out["pipeline"] = {"rounds": int(pr["rounds"]), "still_stretching": int(pr["still_stretching"]), "all_solved": bool(pr["all_solved"]),
+                               "colliding_before_repair": int(pr["colliding_before_repair"]), "repairs": int(pr["repairs"])}
         if pipelined:
             out["pipelined"] = pipelined
         if gather:
@@ -784,7 +789,112 @@ def main():
         ctx.graph_destroy(graph)
     if use_dist:
         dist.destroy_process_group()  # RCCL prints its version banner here: keep the JSON line last
-    if rank == 0:
+    return out
+
+
+OTHER_CONFIGS = (
+    # (key, config, rows, steps, warmup): short runs -- what the default invocation appends so that every BASELINE.json config has a
+    # figure in the driver's own record; the headline `value` / `config` stay configs[1]
+    ("config3_corridor", 3, 0, 10, 3),
+    ("config3_rows2", 3, 2, 4, 2),
+    ("config4_ragged", 4, 0, 50, 5),
+    ("config5_pipeline", 5, 0, 4, 2),
+)
+
+
+def config1_latency():
+    """BASELINE configs[0] (plumbing): ONE 8-waypoint / 7-segment 3-axis min-snap trajectory from host pointers through the drop-in
+    facades -- MinimumControl.solve per axis (the reference's call, test_minimum_jerk.cpp:75,100,125) and TrajOptimizer.solve (3 axes)."""
+    import uav_motion_planning_amd as U
+    from uav_motion_planning_amd import workloads as W
+    b = W.uniform_batch(1, 1, 7, 4, time_mode="reference")
+    wp, T, bc = b["waypoints"][0], b["times"][0], b["bc"][0]
+    opt = U.MinimumControl(order=4)
+    ok = True
+    for _ in range(20):
+        opt.solve(wp[:, 0], [bc[0, 0, 0], 0.0], [0.0, 0.0], T)
+    N = 300
+    t0 = time.perf_counter()
+    for i in range(N):
+        ok = opt.solve(wp[:, i % 3], [bc[0, 0, i % 3], 0.0], [0.0, 0.0], T) and ok
+    one = (time.perf_counter() - t0) / N
+    to = U.TrajOptimizer(order=4)
+    to.setWaypoints(wp, n_waypoints=8); to.setTimeAllocation(T); to.setBoundary(bc.reshape(1, 2, 3, 3))
+    for _ in range(20):
+        to.solve()
+    t0 = time.perf_counter()
+    for i in range(N):
+        ok = to.solve() and ok
+    three = (time.perf_counter() - t0) / N
+    return {"workload": "configs[0]: single 8-waypoint / 7-segment 3-axis min-snap QP from host pointers (plumbing)", "all_solved": bool(ok),
+            "minimum_control_solve_us_per_axis_call": one * 1e6, "three_axis_calls_us": 3 * one * 1e6,
+            "traj_optimizer_solve_us_three_axes": three * 1e6, "value": 1.0 / three, "unit": "trajectories/s",
+            "note": "wall time per synchronous call incl. H2D / D2H through one pinned page; mean of 300 calls after 20 warm-up calls"}
+
+
+def other_configs(args):
+    """Short runs of the other BASELINE configs in this process, one trimmed record each (same code path as `bench.py --config X`);
+    a config that fails reports its error instead of taking the headline line down."""
+    import copy
+    out = {}
+    t_all = time.perf_counter()
+    for key, cfg, rows, steps, warm in OTHER_CONFIGS:
+        a = copy.copy(args)
+        a.config, a.rows, a.steps, a.warmup = cfg, rows, steps, warm
+        a.batch, a.sets, a.repeats, a.cpu_sample = 0, 0, 0, 0
+        a.order, a.segments, a.time_mode, a.data, a.variant, a.graph = 4, 8, "distance", "astar", 0, 1
+        a.no_traffic, a.no_fp64, a.kernels_only = True, True, True
+        a.pipelined_streams, a.no_allgather, a.force_dist, a.inner = 0, True, False, False
+        t0 = time.perf_counter()
+        try:
+            rec = run(a)
+            rl = rec["roofline"]
+            out[key] = {"command": f"bench.py --config {cfg}" + (f" --rows {rows}" if rows else "") + f" --steps {steps} --warmup {warm}",
+                        "metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
+                        "steps": steps, "warmup": warm, "workload": rec["config"]["workload"],
+                        "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms")},
+                        "kernels": rec.get("kernels"), "wall_s": time.perf_counter() - t0}
+            if "corridor" in rec:
+                out[key]["corridor"] = rec["corridor"]
+            if "pipeline" in rec:
+                out[key]["pipeline"] = rec["pipeline"]
+        except BaseException as e:  # noqa: BLE001 (SystemExit of a sub-run included)
+            out[key] = {"error": repr(e), "wall_s": time.perf_counter() - t0}
+    t0 = time.perf_counter()
+    try:
+        out["config1_latency"] = config1_latency()
+    except BaseException as e:  # noqa: BLE001
+        out["config1_latency"] = {"error": repr(e)}
+    out["config1_latency"]["wall_s"] = time.perf_counter() - t0
+    out["wall_s"] = time.perf_counter() - t_all
+    return out
+
+
+def respawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: this process becomes the launcher -- the same command
+    line under torch.distributed.run, one rank per GPU (the shape the driver uses for N > 1), rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if port <= 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_ranks(args))
+    out = run(args)
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == 0 and out is not None:
+        if args.config == 2 and out["n_gpus"] == 1 and not args.no_other_configs and args.batch <= 0:
+            out["other_configs"] = other_configs(args)
         # RCCL (NCCL_DEBUG=VERSION on the GPU boxes) leaves its banner in the C stdio buffer; flush it so that
         # the JSON line is the last line of stdout
         try:

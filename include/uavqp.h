@@ -61,7 +61,10 @@ enum {
 /* per-trajectory status (positive = OSQP's OSQP_SOLVED value, which the reference's solve() maps to true) */
 enum {
     UAVQP_SOLVED = 1,
-    UAVQP_MAX_ITER_REACHED = -2, /* corridor solve only (OSQP's OSQP_MAX_ITER_REACHED value): feasible, not proven optimal */
+    UAVQP_MAX_ITER_REACHED = -2, /* inequality-constrained solves only (OSQP's OSQP_MAX_ITER_REACHED value): iteration cap reached, or a
+                                  * working set went singular and could neither be repaired nor certified infeasible (undecided) */
+    UAVQP_PRIMAL_INFEASIBLE = -3, /* general-rows solve only (OSQP's OSQP_PRIMAL_INFEASIBLE value): the rows have no common point, proven
+                                   * by a Farkas certificate that passes OSQP's test at uavqp_settings.eps_prim_inf */
     UAVQP_INVALID_INPUT = -10, /* M < 1, M > max_segments, T <= 0 or non-finite input */
     UAVQP_NON_FINITE = -11     /* solution overflowed / NaN (pathological time allocation) */
 };

@@ -139,6 +139,7 @@ class PortInfo(ctypes.Structure):
 
 PORT_SOLVED = 1
 PORT_MAX_ITER_REACHED = -2
+PORT_PRIMAL_INFEASIBLE = -3
 
 
 def osqp_settings(**overrides):

@@ -423,6 +423,7 @@ static int solve_axis_rows(int r, int M, const double* pos, const double* bcs, c
     double* xz = (double*)calloc((size_t)N, sizeof(double));
     double* Ax = (double*)calloc((size_t)m, sizeof(double)); double* Px = (double*)calloc((size_t)n, sizeof(double));
     double* Aty = (double*)calloc((size_t)n, sizeof(double)); double* tn = (double*)calloc((size_t)N, sizeof(double));
+    double* dy = (double*)calloc((size_t)m, sizeof(double));   /* delta_y of the last iteration (the infeasibility certificate candidate) */
     int status = PORT_UNSOLVED, iter = 0, rho_updates = 0;
     double pri_res = 0, dua_res = 0;
     for (iter = 1; rc == 0 && iter <= st.max_iter; ++iter) {
@@ -438,7 +439,8 @@ static int solve_axis_rows(int r, int M, const double* pos, const double* bcs, c
             double zn = zr + rho_inv[i] * y[i];
             zn = zn < l[i] ? l[i] : (zn > u[i] ? u[i] : zn);                               /* projection */
             z[i] = zn;
-            y[i] += rho_vec[i] * (zr - zn);
+            dy[i] = rho_vec[i] * (zr - zn);
+            y[i] += dy[i];
         }
         const int can_check = st.check_termination && (iter % st.check_termination == 0);
         const int can_adapt = st.adaptive_rho && st.adaptive_rho_interval && (iter % st.adaptive_rho_interval == 0);
@@ -455,8 +457,32 @@ static int solve_axis_rows(int r, int M, const double* pos, const double* bcs, c
                 double bm = b1 > b2 ? b1 : b2; bm = bm > b3 ? bm : b3;
                 const double eps_dual = st.eps_abs + st.eps_rel * sc.cinv * bm;
                 if (pri_res < eps_prim && dua_res < eps_dual) { status = PORT_SOLVED; break; }
-                /* infeasibility certificates cannot fire for this full-row-rank equality QP with P PSD on
-                 * null(A); they are omitted (eps_prim_inf only loosens a test that never triggers). */
+                /* Primal infeasibility (paper section 3.4; the one tolerance the reference sets, minimum_control.cpp:161): delta_y, projected
+                 * onto the polar of the recession cone of [l, u], is a certificate when  ||A' dy||_inf <= eps ||dy||_inf  and
+                 * u' max(dy, 0) + l' min(dy, 0) <= -eps ||dy||_inf  (norms unscaled: scaled_termination = 0).  It cannot fire for the
+                 * reference's own full-row-rank equality QP; it does for contradictory corridor / general rows (extension).  The dual
+                 * infeasibility test cannot fire at all (P is positive definite on null(A)): omitted. */
+                {
+                    double nd = 0.0, lhs = 0.0;
+                    for (int i = 0; i < m; ++i) {
+                        double d_ = dy[i];
+                        if (u[i] > OSQP_INFTY * MIN_SCALING) d_ = (l[i] < -OSQP_INFTY * MIN_SCALING) ? 0.0 : (d_ < 0.0 ? d_ : 0.0);
+                        else if (l[i] < -OSQP_INFTY * MIN_SCALING) d_ = d_ > 0.0 ? d_ : 0.0;
+                        tn[n + i] = d_;
+                        const double a_ = fabs(sc.E[i] * d_);
+                        if (a_ > nd) nd = a_;
+                    }
+                    if (nd > 1.0 / OSQP_INFTY) {
+                        for (int i = 0; i < m; ++i) {
+                            const double d_ = tn[n + i];
+                            if (d_ > 0.0) lhs += u[i] * d_; else if (d_ < 0.0) lhs += l[i] * d_;
+                        }
+                        if (lhs < -st.eps_prim_inf * nd) {
+                            mat_tpose_vec(&A, tn + n, tn);
+                            if (norm_inf_scaled(sc.Dinv, tn, n) < st.eps_prim_inf * nd) { status = PORT_PRIMAL_INFEASIBLE; break; }
+                        }
+                    }
+                }
             }
             if (can_adapt) {
                 for (int i = 0; i < m; ++i) tn[i] = Ax[i] - z[i];
@@ -490,7 +516,7 @@ static int solve_axis_rows(int r, int M, const double* pos, const double* bcs, c
     /* ---- cleanup (clearSolver) ---- */
     ldl_free(&F); csc_free(&P); csc_free(&A);
     free(q); free(l); free(u); free(sc.D); free(sc.Dinv); free(sc.E); free(sc.Einv); free(rho_vec); free(rho_inv); free(ctype); free(perm);
-    free(x); free(z); free(y); free(xp); free(zp); free(xz); free(Ax); free(Px); free(Aty); free(tn);
+    free(x); free(z); free(y); free(xp); free(zp); free(xz); free(Ax); free(Px); free(Aty); free(tn); free(dy);
     return status == PORT_SOLVED ? 0 : 1;
 }
 
@@ -542,7 +568,7 @@ static void* job_run(void* arg) {
             }
             solve_axis_rows(r, M, pos, bs, be, j->times + s0, lo, hi, ex.n > 0 ? &ex : NULL, j->st, j->out + (size_t)3 * 2 * r * s0 + (size_t)ax * 2 * r * M, &info);
             free(lo); free(hi); free(eseg); free(ed); free(et); free(elo); free(ehi);
-            if (info.status != PORT_SOLVED) worst = info.status;
+            if (info.status != PORT_SOLVED && worst != PORT_PRIMAL_INFEASIBLE) worst = info.status;   /* an infeasible axis decides the trajectory */
             if (info.iters > it_max) it_max = info.iters;
         }
         if (j->status) j->status[b] = worst;

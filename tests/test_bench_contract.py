@@ -92,3 +92,15 @@ def test_bench_defaults_follow_the_contract():
     assert re.search(r'"--config", type=int, default=2', src)      # BASELINE.json configs[1]: the configuration the metric is quoted on
     assert re.search(r'"--order", type=int, default=4', src)
     assert "oracle" not in re.sub(r"def cpu_baseline.*?\n\n\n", "", src, flags=re.S).replace("oracle/osqp_port.c", "")  # oracle only in cpu_baseline
+
+
+def test_bench_spawns_its_ranks_and_appends_the_other_configs():
+    """Source-level contract of the two round-5 additions (exercised on the GPU by tests/test_gpu_bench_two_ranks.py and by the driver's
+    own run): --gpus N > 1 without a launcher re-executes under torch.distributed.run with the same argv; the default one-GPU config-2
+    line carries `other_configs` with a record per other BASELINE config, the headline metric / config untouched."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ:' in src and '"torch.distributed.run"' in src and "sys.argv[1:]" in src
+    assert "assert world == args.gpus" not in src
+    assert 'out["other_configs"] = other_configs(args)' in src and "args.config == 2 and out[\"n_gpus\"] == 1" in src
+    for key in ("config3_corridor", "config3_rows2", "config4_ragged", "config5_pipeline", "config1_latency"):
+        assert f'"{key}"' in src, key

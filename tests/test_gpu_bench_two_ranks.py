@@ -36,3 +36,16 @@ def test_bench_two_ranks_on_one_gpu(config, port):
         assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     if "allgather" in d:
         assert d["allgather"]["own_shard_intact"]
+
+
+def test_bench_gpus_2_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the shape of the driver's N = 1 command with another N): the
+    script re-executes itself under torch.distributed.run instead of dying on an assertion (bench.py:343)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(UAVQP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--cpu-sample", "0", "--no-traffic",
+           "--no-fp64", "--repeats", "2"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["shard_bounds"] == [0, 4096, 8192] and "other_configs" not in d

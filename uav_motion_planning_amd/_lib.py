@@ -21,6 +21,7 @@ UAVQP_UNIQUE_ID_BYTES = 128
 
 UAVQP_SOLVED = 1
 UAVQP_MAX_ITER_REACHED = -2
+UAVQP_PRIMAL_INFEASIBLE = -3
 UAVQP_INVALID_INPUT = -10
 UAVQP_NON_FINITE = -11
 

@@ -115,6 +115,25 @@ def corridor_boxes(batch, config_index=3, h_lo=0.3, h_hi=0.8, seed=None):
     return lo.reshape(wp.shape), hi.reshape(wp.shape)
 
 
+def config3_rows(batch, rows_per_segment=2, h_pos=0.25, v_lim=3.5):
+    """Config 3's "K = 2 mid-segment samples"  as general rows lo <= p_i^(d)(tau T_i) <= hi: slot 0 a position
+    sample at mid-segment inside the chord midpoint +- h_pos, slot 1 a per-axis velocity limit there.  The reference hands any
+    l <= A x <= u to OSQP (minimum_control.cpp:146-147) but builds equality rows only (:98-125): no reference data for these.
+    Uniform batches.  Returns (tau [n M][K], deriv [n M][K] int32, lo [n M][K][3], hi [n M][K][3]) -- what bench.py --config 3 --rows 2
+    times and tests/test_gpu_baseline_sizes.py checks at full size."""
+    wp = np.asarray(batch["waypoints"], dtype=np.float64)
+    n, M = wp.shape[0], wp.shape[1] - 1
+    K = rows_per_segment
+    tau = np.full((n * M, K), 0.5)
+    drv = np.tile(np.array([0, 1], dtype=np.int32)[:K], (n * M, 1))
+    mid = 0.5 * (wp[:, :-1] + wp[:, 1:]).reshape(n * M, 3)
+    lo, hi = np.zeros((n * M, K, 3)), np.zeros((n * M, K, 3))
+    lo[:, 0], hi[:, 0] = mid - h_pos, mid + h_pos
+    if K > 1:
+        lo[:, 1], hi[:, 1] = -v_lim, v_lim
+    return tau, drv, lo, hi
+
+
 def pillar_cloud(config_index=5, n_pillars=60, resolution=0.2, radius=(0.5, 0.7), height=3.0, box=None, seed=None,
                  keep_clear=None, clear_radius=1.0):
     """Obstacle point cloud in the style of the reference's random map (simulator map_generator,
