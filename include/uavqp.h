@@ -103,9 +103,14 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *   warm_start             reference: true.  The equality-constrained solve is direct (nothing to warm-start); for the
  *                          inequality-constrained entry points it is the default of their warm_start argument semantics:
  *                          uavqp_solve_corridor_warm_device's explicit argument wins.  Kept for API parity.
- *   eps_prim_inf           reference: 1e-3 (OSQP's primal-infeasibility tolerance).  Stored and reported for API parity
- *                          only: the device solvers are direct and detect an empty feasible set exactly
- *                          (lo > hi -> UAVQP_INVALID_INPUT), no tolerance is involved.
+ *   eps_prim_inf           reference: 1e-3 (OSQP's primal-infeasibility tolerance, the one tolerance the reference sets).  OSQP calls a problem
+ *                          primal infeasible when its dual increment dy satisfies |A' dy|_inf <= eps |dy|_inf and
+ *                          u' max(dy, 0) + l' min(dy, 0) <= -eps |dy|_inf.  The general-rows solve applies exactly that test to the Farkas
+ *                          certificate its dual active-set method ends with when a violated row depends on the working set and no
+ *                          multiplier blocks (dy = the dependency's coefficients, value = minus the row's violation): accepted ->
+ *                          UAVQP_PRIMAL_INFEASIBLE; a certificate below the margin -> UAVQP_MAX_ITER_REACHED (undecided, as OSQP would run
+ *                          into its iteration cap).  Smaller eps: every provable infeasibility is reported.  (lo > hi on one row or box is
+ *                          rejected up front, UAVQP_INVALID_INPUT, as OSQP's data validation does.)  Knot boxes alone are always feasible.
  *   max_iter               reference: 1000 (ADMM iterations).  Here: cap on active-set iterations of the
  *                          inequality-constrained solves; <= 0 = automatic (8 * max_segments + 20).  Hitting it yields
  *                          UAVQP_MAX_ITER_REACHED with a feasible, smooth trajectory (as OSQP's status of the same name).
@@ -239,12 +244,15 @@ int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  *   d_active_out [n_traj][3][2 + 2 rows_per_segment] uint64 (may be NULL): working set at the solution -- word 0 / 1: knot boxes
  *                active / at the upper bound (bit k = interior waypoint k), then per row slot j words 2+2j / 3+2j (bit i = segment i)
  * Exact dual active-set solve (Goldfarb-Idnani on the block-tridiagonal KKT system with the rows' multipliers riding in the knot
- * blocks): no feasible starting point is needed, the result is the QP's minimiser to rounding.  An infeasible or
- * degenerate problem ends with UAVQP_MAX_ITER_REACHED and the minimiser of the last regular working set (which need NOT satisfy
- * the remaining rows): either at uavqp_settings.max_iter (default 12 M (1 + rows_per_segment) + 30), or as soon as a row of the
- * working set is no longer on its bound after the solve -- the working set's KKT system has become singular to working
- * precision (rows that no free unknown can move, e.g. a position sample right behind the fixed start state).  A single-segment
- * trajectory has no free unknown at all: its rows are only checked (violated -> UAVQP_MAX_ITER_REACHED).  M <= 63.
+ * blocks): no feasible starting point is needed, the result is the QP's minimiser to rounding.  A row that enters and turns
+ * out to depend on the working set (the KKT system goes singular: rows that no free unknown can move, duplicated or contradictory
+ * rows, a degenerate vertex) takes the method's zero-primal-step route: the multipliers move along the dependency until one of the
+ * working set reaches zero -- that constraint leaves, the solve goes on (degenerate but feasible problems are SOLVED) -- or none does:
+ * a Farkas certificate, status UAVQP_PRIMAL_INFEASIBLE if it passes OSQP's test at uavqp_settings.eps_prim_inf (the reference's 1e-3,
+ * minimum_control.cpp:161), else UAVQP_MAX_ITER_REACHED.  UAVQP_MAX_ITER_REACHED also ends a problem at uavqp_settings.max_iter (default
+ * 12 M (1 + rows_per_segment) + 30) and one whose working set is regular but too ill-conditioned for the block solve (undecided).  Both
+ * statuses hand back the minimiser of the last regular working set, which need NOT satisfy the remaining rows.  A single-segment
+ * trajectory has no free unknown at all: its rows are only checked (violated -> UAVQP_PRIMAL_INFEASIBLE).  M <= 63.
  * Asynchronous for uniform batches; a ragged batch costs one 4-byte read-back + stream synchronisation (see uavqp_solve_corridor_batch_device). */
 int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                   const int32_t* d_seg_offsets, const double* d_waypoints, const double* d_times,
@@ -253,8 +261,8 @@ int uavqp_solve_rows_batch_device(uavqp_ctx* ctx, int r, int n_traj, int uniform
                                   const double* d_row_hi, double* d_coeff_out, int32_t* d_status_out, int32_t* d_iters_out,
                                   uint64_t* d_active_out);
 /* The same solve from HOST pointers (staged through device memory, synchronous; a trajectory flagged UAVQP_INVALID_INPUT comes back
- * as zeros, a UAVQP_MAX_ITER_REACHED one carries the minimiser of its last regular working set -- which need NOT satisfy the
- * remaining rows: check the status, not the coefficients): what a caller of the reference's solver interface has -- it hands its rows to OSQP from host memory,
+ * as zeros, a UAVQP_MAX_ITER_REACHED / UAVQP_PRIMAL_INFEASIBLE one carries the minimiser of its last regular working set -- which need NOT
+ * satisfy the remaining rows: check the status, not the coefficients): what a caller of the reference's solver interface has -- it hands its rows to OSQP from host memory,
  * minimum_control.cpp:164-170. */
 int uavqp_solve_rows_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, int max_segments,
                                 const int32_t* seg_offsets, const double* waypoints, const double* times, const double* bc,

@@ -24,7 +24,7 @@ def _arrays(case):
 def test_osqp_port_with_corridor_rows_converges_to_exact_minimiser(oracle, case):
     r, M = case["r"], case["M"]
     wp, lo, hi, T, bc = _arrays(case)
-    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=400000)
+    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=400000, eps_prim_inf=1e-7)
     so = np.array([0, M], dtype=np.int32)
     got, st, _ = oracle.osqp_solve_batch(r, so, wp[None], T[None], bc[None], settings=s, corr_lo=lo[None], corr_hi=hi[None])
     assert st[0] == oracle.PORT_SOLVED

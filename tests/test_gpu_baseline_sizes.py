@@ -103,7 +103,7 @@ def test_config3_full_size_corridor_parity(gpu_ctx, oracle):
     sample[:2] = [0, n - 1]      # both ends of the batch (first / last wave, last grid round)
     certificate_on_sample(oracle, r, so, wp, T, b["bc"], coef, lo_f, hi_f, sample)
     # OSQP-faithful port with the same rows, eps 1e-10: converges onto the same minimiser (1e-5 = what ADMM reaches)
-    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
+    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000, eps_prim_inf=1e-7)
     sub = dict(wp=b["waypoints"][sample], T=b["times"][sample], bc=b["bc"][sample], lo=lo[sample], hi=hi[sample])
     so_s = (np.arange(sample.size + 1) * M).astype(np.int32)
     ref, st_ref, _ = oracle.osqp_solve_batch(r, so_s, sub["wp"], sub["T"], sub["bc"], settings=s, corr_lo=sub["lo"], corr_hi=sub["hi"], threads=8)

@@ -73,7 +73,7 @@ def test_corridor_vs_osqp_port_and_kkt_certificate(gpu_ctx, oracle, r, M, n):
             worst = np.maximum(worst, [prim, stat, comp])
     assert worst[0] < 1e-9 and worst[1] < 1e-7 and worst[2] < 1e-6, worst
     # (2) OSQP port at tight eps
-    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
+    s = oracle.osqp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000, eps_prim_inf=1e-7)
     ref, st_ref, _ = oracle.osqp_solve_batch(r, b["seg_offsets"], b["waypoints"], b["times"], b["bc"], settings=s,
                                              corr_lo=lo, corr_hi=hi, threads=8)
     good = st_ref == oracle.PORT_SOLVED

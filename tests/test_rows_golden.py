@@ -26,7 +26,7 @@ def _arrays(case):
 def test_osqp_port_with_extra_rows_converges_to_exact_minimiser(oracle, case):
     r, M, K = case["r"], case["M"], case["K"]
     wp, lo, hi, T, bc, tau, drv, rlo, rhi = _arrays(case)
-    s = oracle.osqp_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=1000000)
+    s = oracle.osqp_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=1000000, eps_prim_inf=1e-7)
     so = np.array([0, M], dtype=np.int32)
     got, st, _ = oracle.osqp_solve_batch(r, so, wp[None], T[None], bc[None], settings=s, corr_lo=lo[None], corr_hi=hi[None],
                                          rows_per_segment=K, row_tau=tau, row_deriv=drv, row_lo=rlo, row_hi=rhi)

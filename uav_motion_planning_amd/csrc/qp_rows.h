@@ -15,8 +15,15 @@
 //     equality rows to begin with);
 //   * the most violated constraint p joins W; the multipliers move linearly from lambda(W) towards lambda(W + p) while p's bound
 //     is approached; the first one to reach zero leaves W (one more solve), until the full step is possible;
-//   * no violated constraint left: optimal.  A cap on the iterations (infeasible or degenerate problems) ends with
-//     UAVQP_MAX_ITER_REACHED.
+//   * no violated constraint left: optimal.  A cap on the iterations ends with UAVQP_MAX_ITER_REACHED;
+//   * p is linearly DEPENDENT on W (the solve with W + p is singular: an active row no longer sits on its bound): Goldfarb-Idnani's
+//     zero-primal-step case (round 5).  One extra solve with W and the right-hand side -+c_p, all data zeroed ("direction mode") gives
+//     the rates d lambda(W) / d |lambda_p| -- the coefficients of c_p in the rows of W -- and a primal direction z that must vanish.
+//     The multipliers move along those rates until the first of them reaches zero: that constraint leaves and p enters for good; if
+//     none ever does, (rates, 1) is a Farkas certificate: UAVQP_PRIMAL_INFEASIBLE when it passes OSQP's test at eps_prim_inf
+//     (|violation of p| >= eps |dy|_inf, |H z| <~ eps |dy|_inf), UAVQP_MAX_ITER_REACHED (undecided) otherwise;
+//   * a STARTING set that is singular (equality rows, a warm start) is dropped once: the iteration restarts from the empty set and
+//     lets the equality rows enter like any violated constraint (a redundant duplicate never does).
 // Every solve is one block-Thomas pass over the knots with blocks [x_k ; mu_(rows of segment k-1)] of size R + K: the rows'
 // multipliers ride in the block of the knot that closes their segment, so the KKT matrix stays block tridiagonal; a free knot
 // position, an inactive row (mu fixed at 0) and a pinned position are the same thing to the elimination -- a component with a
@@ -33,6 +40,7 @@ namespace uavqp {
 
 struct RowsArgs {
     int n_traj, uniform, max_segments, max_iter;
+    double eps_prim_inf;        // acceptance margin of an infeasibility certificate (uavqp_settings.eps_prim_inf: OSQP's test, minimum_control.cpp:161)
     const int32_t* seg_offsets;
     const double* waypoints;
     const double* times;
@@ -140,6 +148,17 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
 #pragma unroll
     for (int j = 0; j < K; ++j) pract[j] = 0ull;
     int new_kind = -1, new_idx = -1;
+    // direction mode (the entering constraint depends on the working set) -- see the header
+    bool dirm = false, restarted = false;
+    int fail = 0;                // status of a problem that ends without a solution (0: none)
+    bool pend_inf = false;       // a Farkas certificate was found: its margin is taken in the closing solve (violation of q at the minimiser for W)
+    double dyn_keep = 1.0;       // |dy|_inf of that certificate
+#ifdef UAVQP_ROWS_REASON         // probe build: why a problem ended without a solution -> iters += 1000 * reason
+    int reason = 0;
+#define ROWS_REASON(x) reason = (x)
+#else
+#define ROWS_REASON(x) do {} while (0)
+#endif
 
     for (;;) {
       if (g < 0 && !exhausted) {
@@ -234,6 +253,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
 #pragma unroll
         for (int j = 0; j < K; ++j) pract[j] = 0ull;
         new_kind = -1; new_idx = -1;   // the constraint being added (kind 0: knot box, 1 + j: row slot j), not subject to the sign test
+        dirm = false; restarted = false; fail = capped ? (int)UAVQP_PRIMAL_INFEASIBLE : 0; pend_inf = false; dyn_keep = 1.0;
         }      // valid problem
         }      // ticket in range
       }        // refill
@@ -245,6 +265,18 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
         bool finish = done;    // (M == 1: nothing to iterate)
 
         if (!done) {
+            const double dat = dirm ? 0.0 : 1.0;      // direction mode: homogeneous system (every bound, pinned value and boundary state is 0)
+            // direction mode: the entering constraint q = (new_kind, new_idx), unit step of its multiplier towards the violated side:
+            // H z + G_W' dmu = -+ c_q (row) / +- e_0 (box); qs = -1: upper side, +1: lower side
+            const double qs = dirm ? ((new_kind == 0 ? ((upper >> new_idx) & 1ull) : ((rup[new_kind > 0 ? new_kind - 1 : 0] >> new_idx) & 1ull)) ? -1.0 : 1.0) : 0.0;
+            double qgl[R], qgr[R];
+#pragma unroll
+            for (int c = 0; c < R; ++c) { qgl[c] = 0.0; qgr[c] = 0.0; }
+            int qk = -100;              // the functional sits on knots qk (qgl) and qk + 1 (qgr)
+            if (dirm) {
+                if (new_kind == 0) { qk = new_idx - 1; qgr[0] = 1.0; }
+                else { qk = new_idx; row_functional<R>(T[new_idx], rta(new_idx, new_kind - 1), rdv(new_idx, new_kind - 1), qgl, qgr); }
+            }
             // ================= forward sweep: blocks k = 1..M =================
             {
                 FullBlocks<R> sa;
@@ -253,7 +285,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                 LDLPack<B>::zero(lprev);   // knot 0: nothing free, h = its Hermite data
                 double hprev[B];
 #pragma unroll
-                for (int i = 0; i < B; ++i) hprev[i] = i < R ? x0[i] : 0.0;
+                for (int i = 0; i < B; ++i) hprev[i] = (i < R && !dirm) ? x0[i] : 0.0;
                 bool pprev = false;         // knot k-1 position pinned (k-1 >= 1)
                 double zprev = 0.0;
                 for (int k = 1; k <= M; ++k) {
@@ -271,13 +303,13 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                         for (int c = 0; c < R; ++c) { gl[j][c] = 0.0; gr[j][c] = 0.0; }
                         if (racv[j]) {
                             row_functional<R>(T[k - 1], rta(k - 1, j), rdv(k - 1, j), gl[j], gr[j]);
-                            rb[j] = ((rup[j] >> (k - 1)) & 1ull) ? rhi(k - 1, j) : rlo(k - 1, j);
+                            rb[j] = dirm ? 0.0 : (((rup[j] >> (k - 1)) & 1ull) ? rhi(k - 1, j) : rlo(k - 1, j));
                         }
                     }
                     const bool pk = !last && ((pin >> k) & 1ull);
-                    const double zc = pk ? (((upper >> k) & 1ull) ? khi(k) : klo(k)) : 0.0;
+                    const double zc = (pk && !dirm) ? (((upper >> k) & 1ull) ? khi(k) : klo(k)) : 0.0;
                     const bool pnext = (k + 1 < M) && ((pin >> (k + 1)) & 1ull);
-                    const double zn = pnext ? (((upper >> (k + 1)) & 1ull) ? khi(k + 1) : klo(k + 1)) : 0.0;
+                    const double zn = (pnext && !dirm) ? (((upper >> (k + 1)) & 1ull) ? khi(k + 1) : klo(k + 1)) : 0.0;
                     // ---- block matrix (lower triangle), right-hand side
                     double D[B][B], rhs[B];
 #pragma unroll
@@ -296,6 +328,10 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                         for (int c = 0; c < R; ++c) D[R + j][c] = gr[j][c];
                         rhs[R + j] = rb[j];
                     }
+                    if (dirm && (k == qk || k == qk + 1)) {
+#pragma unroll
+                        for (int i = 0; i < R; ++i) rhs[i] += qs * (k == qk ? qgl[i] : qgr[i]);
+                    }
                     // known values of the neighbours: pinned position of knot k-1, pinned position of knot k+1 / the end knot
                     if (pprev) {
 #pragma unroll
@@ -308,7 +344,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
 #pragma unroll
                             for (int i = 0; i < R; ++i)
 #pragma unroll
-                                for (int c = 0; c < R; ++c) rhs[i] -= sb.B01[i][c] * xM[c];
+                                for (int c = 0; c < R; ++c) rhs[i] -= sb.B01[i][c] * (dat * xM[c]);
                         } else if (pnext) {
 #pragma unroll
                             for (int i = 0; i < R; ++i) rhs[i] -= sb.B01[i][0] * zn;
@@ -321,7 +357,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                     for (int i = 0; i < B; ++i) { fx[i] = false; vx[i] = 0.0; }
                     if (last) {
 #pragma unroll
-                        for (int c = 0; c < R; ++c) { fx[c] = true; vx[c] = xM[c]; }
+                        for (int c = 0; c < R; ++c) { fx[c] = true; vx[c] = dat * xM[c]; }
                     } else if (pk) {
                         fx[0] = true;
                         vx[0] = zc;
@@ -397,10 +433,11 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                 }
             }
             // ================= backward sweep k = M..1 (+ the late parts at k = 0), decisions =================
-            double vmax = 0.0;           // most violated inactive constraint (normalised violation)
+            double vmax = 0.0, vq_now = 0.0;   // most violated inactive constraint (normalised violation); violation of the constraint (new_kind, new_idx)
             int vkind = -1, vidx = NONE;
             bool vupper = false;
-            double tmin = 2.0;           // first multiplier to reach zero on the way to the new point
+            double tmin = dirm ? 1e300 : 2.0;   // first multiplier to reach zero on the way to the new point (direction mode: along the dependency, unbounded)
+            double hz = 0.0, dymax = 0.0;       // direction mode: |H z| (diagonal proxy) and the largest rate of a multiplier of the working set
             int tkind = -1, tidx = NONE;
             bool inconsistent = false;   // an active row is not on its bound: singular working set
             {
@@ -471,7 +508,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                         for (int i = 0; i < B; ++i) Wf(k, F_Y + i) = y[i];
                     } else {
 #pragma unroll
-                        for (int i = 0; i < B; ++i) y[i] = i < R ? x0[i] : 0.0;
+                        for (int i = 0; i < B; ++i) y[i] = i < R ? dat * x0[i] : 0.0;
                     }
                     // ---- late parts, now that x_k is known: knot k+1's box multiplier, the values of the rows of segment k
                     if (k + 1 <= M - 1) {
@@ -484,22 +521,26 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                             mag += fabs(t1);
                         }
                         const bool pj = (pin >> kj) & 1ull, ej = (eqmask >> kj) & 1ull, uj = (upper >> kj) & 1ull;
+                        // (direction mode: the injected right-hand side is no part of the multiplier; lam is then the RATE of this multiplier)
+                        if (dirm) lam -= qs * (kj == qk ? qgl[0] : (kj == qk + 1 ? qgr[0] : 0.0));
                         // stored multipliers of this constraint: previous lam_new -> lam_cur by the pending interpolation
                         double lc = Wf(kj, F_LC), ln = Wf(kj, F_LN);
                         const bool was = (ppin >> kj) & 1ull;
-                        lc = was ? lc + tpend * (ln - lc) : 0.0;
+                        lc = was ? (tpend == 0.0 ? lc : lc + tpend * (ln - lc)) : 0.0;
+                        const double lnew = dirm ? lc + lam : lam;
                         if (pj && !ej) {
                             // lower bound active: need lam >= 0, upper: lam <= 0 (lam = d cost / d p, up to the factor 2)
                             const double bad = uj ? lam : -lam;
-                            if (bad > 1e-13 * mag && !(new_kind == 0 && new_idx == kj)) {
-                                const double den = lc - lam;
+                            if (bad > (dirm ? 1e-9 + 1e-11 * mag : 1e-13 * mag) && !(new_kind == 0 && new_idx == kj)) {
+                                const double den = lc - lnew;
                                 double t = den != 0.0 ? lc / den : 0.0;
-                                t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+                                t = t < 0.0 ? 0.0 : ((t > 1.0 && !dirm) ? 1.0 : t);
                                 if (t < tmin || (t == tmin && tkind == 0 && kj < tidx)) { tmin = t; tkind = 0; tidx = kj; }
                             }
                         }
+                        if (dirm && pj) dymax = fmax(dymax, fabs(lam));
                         Wf(kj, F_LC) = pj ? lc : 0.0;
-                        Wf(kj, F_LN) = pj ? lam : 0.0;
+                        Wf(kj, F_LN) = pj ? lnew : ((dirm && new_kind == 0 && new_idx == kj) ? qs : 0.0);     // (the entering box: unit rate)
                     }
                     if (k <= M - 1) {
 #pragma unroll
@@ -507,17 +548,18 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                             if (!usedn[j]) continue;
                             double v = 0.0;
 #pragma unroll
-                            for (int c = 0; c < R; ++c) v += gln[j][c] * y[c] + grn[j][c] * (k + 1 == M ? xM[c] : yn[c]);
+                            for (int c = 0; c < R; ++c) v += gln[j][c] * y[c] + grn[j][c] * (k + 1 == M ? dat * xM[c] : yn[c]);
                             if ((ract[j] >> k) & 1ull) {
                                 // a row of the working set must sit ON its bound.  If it does not, the working set's KKT system is
                                 // singular to working precision: its rows are (numerically) dependent on the free unknowns -- an
                                 // infeasible or degenerate problem (e.g. a position sample right behind the fixed start state,
                                 // which no free derivative can move).  The solve is then worthless; the iteration ends as the
                                 // iteration cap does (found by tools/soak_rows.py: such a problem came back "solved").
-                                const double bnd = ((rup[j] >> k) & 1ull) ? rhi(k, j) : rlo(k, j);
+                                const double bnd = dirm ? 0.0 : (((rup[j] >> k) & 1ull) ? rhi(k, j) : rlo(k, j));
                                 if (!(fabs(v - bnd) <= 1e-8 * (1.0 + fabs(bnd)))) inconsistent = true;
                                 continue;
                             }
+                            if (dirm) continue;      // (no constraint is looked for: the one that enters is known)
                             const double l = rlo(k, j), h = rhi(k, j);
                             const double below = l - v, above = v - h;
                             const double viol = (below > above ? below : above);
@@ -525,6 +567,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                             if (sc > 1e-12 && (sc > vmax || (sc == vmax && (1 + j < vkind || (1 + j == vkind && k < vidx))))) {
                                 vmax = sc; vkind = 1 + j; vidx = k; vupper = above > below;
                             }
+                            if (new_kind == 1 + j && new_idx == k) vq_now = viol;
                         }
                     }
                     // ---- this block's own constraints
@@ -535,24 +578,22 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                             const bool aj = (ract[j] >> s) & 1ull, ej = (req[j] >> s) & 1ull, uj = (rup[j] >> s) & 1ull;
                             double lc = Wf(k, F_LC + 1 + j), ln = Wf(k, F_LN + 1 + j);
                             const bool was = (pract[j] >> s) & 1ull;
-                            lc = was ? lc + tpend * (ln - lc) : 0.0;
-                            const double mu = y[R + j];
+                            lc = was ? (tpend == 0.0 ? lc : lc + tpend * (ln - lc)) : 0.0;
+                            const double mu = y[R + j];                   // (direction mode: the RATE of this multiplier)
+                            const double lnew = dirm ? lc + mu : mu;
                             if (aj && !ej) {
                                 // stationarity H x + G' mu = 0: lower bound active needs mu <= 0, upper mu >= 0
                                 const double bad = uj ? -mu : mu;
-                                double mag = 0.0;
-#pragma unroll
-                                for (int c = 0; c < R; ++c) mag += fabs(grk[j][c] * y[c]);
-                                if (bad > 1e-13 * (fabs(lc) + fabs(mu)) && bad > 0.0 && !(new_kind == 1 + j && new_idx == s)) {
-                                    const double den = lc - mu;
+                                if (bad > (dirm ? 1e-9 : 1e-13 * (fabs(lc) + fabs(mu))) && bad > 0.0 && !(new_kind == 1 + j && new_idx == s)) {
+                                    const double den = lc - lnew;
                                     double t = den != 0.0 ? lc / den : 0.0;
-                                    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+                                    t = t < 0.0 ? 0.0 : ((t > 1.0 && !dirm) ? 1.0 : t);
                                     if (t < tmin || (t == tmin && (tkind < 0 || 1 + j < tkind || (1 + j == tkind && s < tidx)))) { tmin = t; tkind = 1 + j; tidx = s; }
                                 }
-                                (void)mag;
                             }
+                            if (dirm && aj) dymax = fmax(dymax, fabs(mu));
                             Wf(k, F_LC + 1 + j) = aj ? lc : 0.0;
-                            Wf(k, F_LN + 1 + j) = aj ? mu : 0.0;
+                            Wf(k, F_LN + 1 + j) = aj ? lnew : ((dirm && new_kind == 1 + j && new_idx == s) ? -qs : 0.0);     // (the entering row: unit rate)
                         }
                         if (k < M) {
                             // first part of knot k's box multiplier: row 0 of its own block and of the right-hand segment
@@ -561,7 +602,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
 #pragma unroll
                             for (int c = 0; c < R; ++c) {
                                 const double d0 = sk.B11[0][c] + sn.B00(0, c);
-                                const double t2 = d0 * y[c], t3 = sn.B01[0][c] * (k + 1 == M ? xM[c] : yn[c]);
+                                const double t2 = d0 * y[c], t3 = sn.B01[0][c] * (k + 1 == M ? dat * xM[c] : yn[c]);
                                 lamA += t2 + t3;
                                 magA += fabs(t2) + fabs(t3);
                             }
@@ -570,13 +611,19 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                                 if ((ract[j] >> (k - 1)) & 1ull) { const double t4 = grk[j][0] * y[R + j]; lamA += t4; magA += fabs(t4); }
                                 if ((ract[j] >> k) & 1ull) { const double t5 = gln[j][0] * yn[R + j]; lamA += t5; magA += fabs(t5); }
                             }
+                            if (dirm) {
+                                // |H z|_inf by its diagonal part: the primal direction of a dependent constraint must vanish
+#pragma unroll
+                                for (int c = 0; c < R; ++c) hz = fmax(hz, fabs((sk.B11[c][c] + sn.B00(c, c)) * y[c]));
+                            }
                             // free knot position outside its box?
-                            if (!((pin >> k) & 1ull)) {
+                            if (!dirm && !((pin >> k) & 1ull)) {
                                 const double l = klo(k), h = khi(k), v = y[0];
                                 const double below = l - v, above = v - h;
                                 const double viol = below > above ? below : above;
                                 const double sc = viol / (1.0 + fabs(below > above ? l : h));
                                 if (sc > 1e-12 && (sc > vmax || (sc == vmax && (0 < vkind || k < vidx)))) { vmax = sc; vkind = 0; vidx = k; vupper = above > below; }
+                                if (new_kind == 0 && new_idx == k) vq_now = viol;
                             }
                         }
                     }
@@ -599,18 +646,55 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
             for (int j = 0; j < K; ++j) pract[j] = ract[j];
             if (capped) {
                 finish = true;   // the last solve (for the working set it stopped with) is what is handed over
-            } else if (inconsistent) {
-                // as at the iteration cap: one more solve WITHOUT the constraint that was being added (or, if none was, without
-                // the rows of the working set), status UAVQP_MAX_ITER_REACHED
-                if (new_kind == 0) pin &= ~(1ull << new_idx);
-                else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
-                else {
-#pragma unroll
-                    for (int j = 0; j < K; ++j) ract[j] = req[j];
+                // (a pending certificate: accepted as OSQP accepts one -- its support-function value, the violation of q at this minimiser, is at
+                // least eps_prim_inf |dy|_inf; below that margin the verdict stays "undecided")
+                if (pend_inf && vq_now >= a.eps_prim_inf * dyn_keep) fail = (int)UAVQP_PRIMAL_INFEASIBLE;
+            } else if (dirm) {
+                // ---- the direction-mode solve: rates of the multipliers of W along the dependency of q on W
+                dirm = false;
+                const unsigned long long qbit = 1ull << new_idx;
+                const double dyn = fmax(1.0, dymax);                                   // |dy|_inf: the entering constraint's own rate is 1
+                const bool dep = !inconsistent && hz <= fmax(a.eps_prim_inf, 1e-6) * dyn;   // (OSQP: |A' dy| <= eps |dy|; NaNs fail the test)
+                if (!inconsistent && tkind >= 0) {
+                    // a multiplier of W reaches zero first: that constraint leaves, q enters for good with the multiplier it has by then.
+                    // (Also when z did not vanish -- W + q is regular but so ill-conditioned that its solve was worthless: the full step cannot
+                    // be computed, leaving with the constraint that blocks the dual direction is the way on; what counts as SOLVED is decided by
+                    // the KKT conditions of a later solve, not here.)
+                    tpend = tmin;
+                    if (tkind == 0) pin &= ~(1ull << tidx);
+                    else ract[tkind - 1] &= ~(1ull << tidx);
+                    if (new_kind == 0) { pin |= qbit; ppin |= qbit; }
+                    else { ract[new_kind - 1] |= qbit; pract[new_kind - 1] |= qbit; }
+                } else {
+                    // none ever does: (rates, 1) is a Farkas certificate of infeasibility (a direction that did not vanish proves nothing)
+                    fail = (int)UAVQP_MAX_ITER_REACHED;
+                    pend_inf = dep;
+                    dyn_keep = dyn;
+                    ROWS_REASON(inconsistent ? 1 : (dep ? 3 : 2));
+                    tpend = 0.0;
+                    capped = true;      // one more solve for W: the minimiser of the last regular working set is what is handed over
                 }
-                new_kind = -1;
-                tpend = 1.0;
-                capped = true;
+            } else if (inconsistent) {
+                if (new_kind >= 0) {
+                    // the constraint that has just entered depends on the working set: take it out again and solve for the direction
+                    if (new_kind == 0) pin &= ~(1ull << new_idx);
+                    else ract[new_kind - 1] &= ~(1ull << new_idx);
+                    dirm = true;
+                    tpend = 0.0;        // (the multipliers of W stay where they are: the solve that went singular left garbage in their "new" slots)
+                } else if (!restarted) {
+                    // a singular STARTING set (equality rows that depend on each other, a warm start): once more from the boxes' equalities
+                    // alone; the equality rows enter like any violated constraint -- a redundant one never does
+                    restarted = true;
+                    pin = eqmask; upper = 0ull; ppin = 0ull;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) { ract[j] = 0ull; rup[j] = 0ull; pract[j] = 0ull; }
+                    tpend = 1.0;
+                } else {
+                    tpend = 1.0;
+                    capped = true;
+                    fail = (int)UAVQP_MAX_ITER_REACHED;
+                    ROWS_REASON(4);
+                }
             } else if (tkind >= 0) {
                 // a multiplier of W reaches zero before the new point: it leaves, the others stop at that fraction of the way
                 tpend = tmin;
@@ -632,12 +716,18 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
                     new_kind = vkind; new_idx = vidx;
                 }
             }
-            if (!done && !finish && it >= a.max_iter) {
+            if (!done && !finish && !capped && it >= a.max_iter) {
                 // give up: re-solve once for the working set as it stands WITHOUT the constraint that was being added
-                if (new_kind == 0) pin &= ~(1ull << new_idx);
-                else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
+                if (!dirm) {
+                    if (new_kind == 0) pin &= ~(1ull << new_idx);
+                    else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
+                }
+                dirm = false;
                 new_kind = -1;
                 capped = true;
+                pend_inf = false;
+                fail = (int)UAVQP_MAX_ITER_REACHED;
+                ROWS_REASON(5);
             }
             if (done) finish = true;
         }
@@ -649,7 +739,10 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
 #pragma unroll
                 for (int c = 0; c < R; ++c) o[c] = Wf(k, F_Y + c);
             }
-            if (capped) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
+            if (capped) atomicMin(&a.status[b], (int32_t)fail);      // (UAVQP_PRIMAL_INFEASIBLE < UAVQP_MAX_ITER_REACHED: an infeasible axis decides the trajectory)
+#ifdef UAVQP_ROWS_REASON
+            if (capped) it += 1000 * reason;
+#endif
             if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
             if (a.active) {
                 unsigned long long* o = a.active + (size_t)g * (2 + 2 * K);

@@ -42,6 +42,7 @@ constexpr int rows2_lds_knots(int R, int K) { return (UAVQP_ROWS2_LDS_KB * 1024)
 struct Rows2Args {
     RowsArgs r;
     unsigned long long* desc;   // [problem][2 + 2 K]: {valid | M >= 2 flag, eqmask, rused[K], req[K]} from rows_prep_kernel
+    unsigned int* redo;         // [problems]: the (trajectory, axis) problems the first pass leaves to the second (count: queue[1]; tickets of the second: queue[2])
     const int32_t* order;       // dealing order of the trajectories (longest first), may be null
     double* lam;                // dual state [wave][own knot 0..kown][2 (1 + K)][lane]: current / new multiplier of the knot box and the rows
     double* gfun;               // row functionals [segment][K][2 R] (g_l, g_r of p^(d)(tau T) = g_l' x_k + g_r' x_{k+1}, ORIGINAL frame), made once per
@@ -147,7 +148,13 @@ __global__ __launch_bounds__(256) void rows_gfun_kernel(Rows2Args aa, long long 
     }
 }
 
-template <int R, int K, bool WS>
+// GI = false: the FIRST pass over all problems.  A problem whose working set goes singular (the entering constraint depends on it, or a
+// singular starting set) is not decided here: it is put on the redo list (queue[1] = count, aa.redo) with no output written, and the
+// second launch, GI = true, solves the listed problems from their start with Goldfarb-Idnani's zero-primal-step route, the restart
+// and the infeasibility certificate (qp_rows.h's header).  So the pass that sees every problem carries none of that machinery --
+// selects on a mode flag in the sweeps, the entering functional, the certificate's bookkeeping: measured +10 % on config 3 + K = 2,
+// where not one of 196 608 problems needs it -- and the second launch finds an empty list (a few microseconds).
+template <int R, int K, bool WS, bool GI>
 __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
     const RowsArgs& a = aa.r;
     constexpr int ND = R - 1, B = R + K, NL = B * (B + 1) / 2, NCN = 1 + K, F = NL + B, BM = R + 2 * K;
@@ -168,8 +175,10 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
     auto LC = [&](int s, int c) -> double& { return lamb[((size_t)s * 2 * NCN + c) * 64]; };
     auto LN = [&](int s, int c) -> double& { return lamb[((size_t)s * 2 * NCN + NCN + c) * 64]; };
 
-    const long long total = (long long)a.n_traj * 3;
+    const long long total = GI ? (long long)a.queue[1] : (long long)a.n_traj * 3;    // (GI: the redo list of the first pass)
+    unsigned int* const ticket = GI ? a.queue + 2 : a.queue;
     bool queue_empty = false;
+    bool redo = false;           // !GI: this problem goes to the second pass
     R2_CT_DECL
 
     // ---- problem state (identical in both lanes of a pair unless noted)
@@ -188,6 +197,10 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
     bool capped = false;
     double tpend = 1.0;
     int new_kind = -1, new_idx = -1;
+    // direction mode (qp_rows.h's header: the entering constraint depends on the working set) -- pair-uniform state
+    bool dirm = false, restarted = false, pend_inf = false;
+    int fail = 0;                // status of a problem that ends without a solution
+    double dyn_keep = 1.0;       // |dy|_inf of a pending Farkas certificate
 
     // own frame -> original data
     auto korig = [&](int j) -> int { return isR ? M - j : j; };                   // original knot of own knot j
@@ -224,15 +237,16 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 const int npairs = __popcll(needm) >> 1;
                 const int leader = (int)__builtin_ctzll(needm);
                 unsigned int qb = 0;
-                if (lane == leader) qb = atomicAdd(a.queue, (unsigned int)npairs);
+                if (lane == leader) qb = atomicAdd(ticket, (unsigned int)npairs);
                 qb = __shfl(qb, leader, 64);
                 if ((long long)qb + npairs >= total) queue_empty = true;
                 if (need) {
                     const int rank = __popcll(needm & ((1ull << lane) - 1ull)) >> 1;
                     const long long q = (long long)qb + rank;
                     if (q < total) {
-                        const int bq = (int)(q / 3), axn = (int)(q - 3LL * bq);
-                        const int bn = aa.order ? aa.order[bq] : bq;
+                        int bq = (int)(q / 3), axn = (int)(q - 3LL * bq);
+                        int bn = aa.order ? aa.order[bq] : bq;
+                        if (GI) { const unsigned int gr_ = aa.redo[q]; bn = (int)(gr_ / 3u); axn = (int)(gr_ - 3u * (unsigned int)bn); }
                         const long long gn = 3LL * bn + axn;
                         const unsigned long long* dsc = aa.desc + (size_t)gn * (2 + 2 * K);
                         const unsigned long long d0 = dsc[0];
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                                 }
                             }
                             it = 0; capped = false; tpend = 1.0; ppin = 0ull; new_kind = -1; new_idx = -1;
+                            dirm = false; restarted = false; pend_inf = false; fail = 0; dyn_keep = 1.0; redo = false;
                         }
                     }
                 }
@@ -284,6 +299,43 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         const int mm = act ? m : 0;
         bool finish = false;
         bool single = act && (M == 1);   // no free knot: the rows can only be CHECKED (by the L lane, own segment 0)
+        // ---- direction mode of this trip (rare: every extra below sits behind the wave-uniform any_dirm).  The entering constraint
+        // q = (new_kind, new_idx) as a functional qgl' x'_qk + qgr' x'_{qk+1} of the OWN frame, in the lane that owns it (a box: e_0 on the
+        // right knot; the meeting knot's box: the L lane); qs = -+1 towards the violated side there, 0 in the other lane
+        const bool dm = GI && act && dirm;
+        const bool any_dirm = GI && __ballot(dm) != 0ull;
+        double qs = 0.0, qsg = 0.0;
+        int qk = -100;
+        if (any_dirm && dm) {
+            if (new_kind == 0) {
+                qsg = ((upper >> new_idx) & 1ull) ? -1.0 : 1.0;
+                const int jq = isR ? M - new_idx : new_idx;
+                if (jq >= 1 && (jq < mm || (jq == mm && !isR))) { qk = jq - 1; qs = qsg; }
+            } else {
+                unsigned long long rupq = rup[0];
+#pragma unroll
+                for (int j = 1; j < K; ++j) rupq = (new_kind - 1) == j ? rup[j] : rupq;
+                qsg = ((rupq >> new_idx) & 1ull) ? -1.0 : 1.0;
+                const int sq = isR ? M - 1 - new_idx : new_idx;
+                if (sq >= 0 && sq < mm) { qk = sq; qs = qsg; }
+            }
+        }
+        // the part of qs c_q that sits on own knot j (only ever called behind any_dirm: the functional is fetched again at each use --
+        // nothing of the rare path stays in registers over the sweeps)
+        auto qinj = [&](int j, double (&o)[R]) {
+#pragma unroll
+            for (int c = 0; c < R; ++c) o[c] = 0.0;
+            if (qs != 0.0 && (j == qk + 1 || (j == qk && j >= 1))) {
+                if (new_kind == 0) { o[0] = qs; }
+                else {
+                    double gl_[R], gr_[R];
+                    if (K == 1 || new_kind == 1) rowf(qk, 0, gl_, gr_);
+                    else rowf(qk, K - 1, gl_, gr_);
+#pragma unroll
+                    for (int c = 0; c < R; ++c) o[c] = qs * (j == qk + 1 ? gr_[c] : gl_[c]);
+                }
+            }
+        };
 
         // ================= forward sweep: own knots j = 1 .. m - 1 (slot m - j) =================
         FullBlocks<R> sa;                 // blocks of own segment j - 1
@@ -292,6 +344,10 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         double hprev[B];
 #pragma unroll
         for (int i = 0; i < B; ++i) hprev[i] = i < R ? x0[i] : 0.0;
+        if (any_dirm) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) hprev[i] = dm ? 0.0 : hprev[i];
+        }
         bool pprev = false;
         double zprev = 0.0;
         // own partial block of a knot: rows of own segment j - 1 (mu part), coupling to the previous block eliminated.
@@ -312,6 +368,11 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             f.bl = klo(jc); f.bh = khi(jc);
             const int jn = jc + 1 <= mm ? jc + 1 : jc;
             f.nl = klo(jn); f.nh = khi(jn);
+            if (any_dirm) {      // direction mode: the homogeneous system -- every bound and pinned value is 0
+                f.bl = dm ? 0.0 : f.bl; f.bh = dm ? 0.0 : f.bh; f.nl = dm ? 0.0 : f.nl; f.nh = dm ? 0.0 : f.nh;
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj) { f.rl[jj] = dm ? 0.0 : f.rl[jj]; f.rh[jj] = dm ? 0.0 : f.rh[jj]; }
+            }
         };
         // Known components need no case analysis (the steps stay single basic blocks):
         //   * an INACTIVE row has its functionals zeroed and a unit diagonal: its mu row / column is decoupled and solves to 0;
@@ -351,6 +412,12 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 for (int c = 0; c < R; ++c) D[R + jj][c] = gr[jj][c];
                 D[R + jj][R + jj] = racv[jj] ? 0.0 : 1.0;
                 rhs[R + jj] = rb[jj] - gl[jj][0] * zpm;
+            }
+            if (any_dirm) {
+                double qv[R];
+                qinj(j, qv);
+#pragma unroll
+                for (int i = 0; i < R; ++i) rhs[i] += qv[i];
             }
             if (full) {
                 const bool pnext = kbit(pin, j + 1);   // own knot j + 1 <= m: an interior knot (the meeting knot at the latest)
@@ -473,7 +540,8 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             }
             // the pinned meeting position (inactive rows of either side are decoupled unit rows already, see block())
             const bool pc = has && mm >= 1 && kbit(pin, mm) && korig(mm) >= 1 && korig(mm) <= M - 1;
-            const double zc = pc ? (kbit(upper, mm) ? khi(mm) : klo(mm)) : 0.0;
+            double zc = pc ? (kbit(upper, mm) ? khi(mm) : klo(mm)) : 0.0;
+            if (any_dirm) zc = dm ? 0.0 : zc;
 #pragma unroll
             for (int i = 1; i < BM; ++i) {
                 r7[i] -= C[i][0] * zc;
@@ -496,15 +564,19 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
 
         R2_CT(2);
         // ================= backward sweep + the decisions of this iteration (own constraints only) =================
-        double vmax = 0.0;           // most violated inactive constraint
+        double vmax = 0.0, vq_now = 0.0;   // most violated inactive constraint; the violation of (new_kind, new_idx) (a pending certificate's margin)
         int vkind = -1, vidx = NONE;
         bool vupper = false;
-        double tmin = 2.0;           // first multiplier to reach zero
+        double tmin = dm ? 1e300 : 2.0;   // first multiplier to reach zero (direction mode: along the dependency, unbounded)
+        double hz = 0.0, dymax = 0.0;     // direction mode: |H z|_inf by its diagonal part, largest rate of a multiplier of the working set
         int tkind = -1, tidx = NONE;
         bool inconsistent = false;
         double lam_meet = 0.0, mag_meet = 0.0;   // own half of the meeting knot's box multiplier
-        auto viol_cand = [&](double sc, int kind, int idx, bool up) {
+        const bool any_pend = GI && __ballot(act && pend_inf) != 0ull;
+        auto viol_cand = [&](double sc, double viol, int kind, int idx, bool up) {
+            if (any_dirm && dm) return;      // (no constraint is looked for: the one that enters is known)
             if (sc > 1e-12 && (sc > vmax || (sc == vmax && (kind < vkind || (kind == vkind && idx < vidx))))) { vmax = sc; vkind = kind; vidx = idx; vupper = up; }
+            if (any_pend && kind == new_kind && idx == new_idx) vq_now = viol;
         };
         auto step_cand = [&](double t, int kind, int idx) {
             if (t < tmin || (t == tmin && (kind < tkind || (kind == tkind && idx < tidx)))) { tmin = t; tkind = kind; tidx = idx; }
@@ -512,17 +584,34 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         // multiplier bookkeeping of one constraint: current value by the pending interpolation, ratio test; lc / ln: its stored current /
         // new multiplier in, the values to store out
         // (bad: the wrong-signed amount of lam_new, mag: scale of its rounding; rows add |current multiplier| to the scale as qp_rows.h does)
+        // (direction mode: lam_new is the RATE of the multiplier per unit step of q's; its "new" value is lc + rate, the ratio test is unbounded,
+        // the entering constraint itself stores the unit rate: + for a box multiplier towards the violated side, - for a row's (row convention))
         auto dual = [&](double& lc, double& ln, bool active, bool equality, bool was, double lam_new, double bad, double mag, bool add_lc, int kind, int idx) {
-            lc = was ? lc + tpend * (ln - lc) : 0.0;
-            const bool wrong = bad > 1e-13 * (mag + (add_lc ? fabs(lc) : 0.0)) && bad > 0.0;
+            if (!any_dirm) {      // the common path: a wave without a lane pair in direction mode
+                lc = was ? lc + tpend * (ln - lc) : 0.0;
+                const bool wrong = bad > 1e-13 * (mag + (add_lc ? fabs(lc) : 0.0)) && bad > 0.0;
+                if (active && !equality && wrong && !(new_kind == kind && new_idx == idx)) {
+                    const double den = lc - lam_new;
+                    double t = den != 0.0 ? lc * fast_rcp(den) : 0.0;   // (fast_rcp: full float64 accuracy for normal arguments, a third of the instructions of a division)
+                    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+                    step_cand(t, kind, idx);
+                }
+                lc = active ? lc : 0.0;
+                ln = active ? lam_new : 0.0;
+                return;
+            }
+            lc = was ? (tpend == 0.0 ? lc : lc + tpend * (ln - lc)) : 0.0;
+            const double lnew = dm ? lc + lam_new : lam_new;
+            const bool wrong = dm ? (bad > 1e-9 + (add_lc ? 0.0 : 1e-11 * mag)) : (bad > 1e-13 * (mag + (add_lc ? fabs(lc) : 0.0)) && bad > 0.0);
             if (active && !equality && wrong && !(new_kind == kind && new_idx == idx)) {
-                const double den = lc - lam_new;
-                double t = den != 0.0 ? lc * fast_rcp(den) : 0.0;   // (fast_rcp: full float64 accuracy for normal arguments, a third of the instructions of a division)
-                t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+                const double den = lc - lnew;
+                double t = den != 0.0 ? lc * fast_rcp(den) : 0.0;
+                t = t < 0.0 ? 0.0 : ((t > 1.0 && !dm) ? 1.0 : t);
                 step_cand(t, kind, idx);
             }
+            if (dm && active) dymax = fmax(dymax, fabs(lam_new));
             lc = active ? lc : 0.0;
-            ln = active ? lam_new : 0.0;
+            ln = active ? lnew : ((dm && new_kind == kind && new_idx == idx) ? (kind == 0 ? qsg : -qsg) : 0.0);
         };
         if (act && !single) {
             double yn[B], ynn[B];    // blocks of own knots j + 1, j + 2
@@ -556,6 +645,10 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     f.rh[jj] = rhi(j, jj);
                 }
                 f.bl = klo(j + 1); f.bh = khi(j + 1);
+                if (any_dirm) {
+#pragma unroll
+                    for (int jj = 0; jj < K; ++jj) { f.rl[jj] = dm ? 0.0 : f.rl[jj]; f.rh[jj] = dm ? 0.0 : f.rh[jj]; }
+                }
                 const int sl = mm - j - 1;
 #pragma unroll
                 for (int c = 0; c < NCN; ++c) { f.lc[c] = LC(sl, c); f.ln[c] = LN(sl, c); }
@@ -622,6 +715,10 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 } else {
 #pragma unroll
                     for (int i = 0; i < B; ++i) y[i] = i < R ? x0[i] : 0.0;
+                    if (any_dirm) {
+#pragma unroll
+                        for (int i = 0; i < R; ++i) y[i] = dm ? 0.0 : y[i];
+                    }
                 }
                 // ---- rows of own segment j: values (inactive: violation; active: must sit on the bound), multipliers (block j + 1)
                 double la = 0.0, ma = 0.0;   // own knot j + 1's box multiplier: the part of own segment j
@@ -642,7 +739,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                             const double l = rlv[jj], h = rhv[jj];
                             const double below = l - v, above = v - h;
                             const double viol = below > above ? below : above;
-                            viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), 1 + jj, os, above > below);
+                            viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), viol, 1 + jj, os, above > below);
                         }
                         const double mu = yn[R + jj];
                         const bool was = (pract[jj] >> (os & 63)) & 1ull;
@@ -659,6 +756,15 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     const double t1 = sn.B01[c][0] * y[c], t2 = sn.B11[0][c] * yn[c];
                     la += t1 + t2;
                     ma += fabs(t1) + fabs(t2);
+                }
+                if (any_dirm) {
+                    double qv[R];
+                    qinj(j + 1, qv);
+                    la -= qv[0];               // (the injected right-hand side is no part of the multiplier)
+                    if (dm) {
+#pragma unroll
+                        for (int c = 0; c < R; ++c) hz = fmax(hz, fabs((sn.B11[c][c] + (j + 1 == mm ? 0.0 : snn.B00(c, c))) * yn[c]));
+                    }
                 }
                 if (j + 1 == mm) {
                     lam_meet = la;     // own half of the meeting knot's multiplier: finished across the pair below
@@ -681,7 +787,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                         const double l = bl, h = bh, v = yn[0];
                         const double below = l - v, above = v - h;
                         const double viol = below > above ? below : above;
-                        viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), 0, kk, above > below);
+                        viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), viol, 0, kk, above > below);
                     }
                 }
                 // the block's multipliers back (the meeting knot's box -- slot 0, constraint 0 -- belongs to the pair step below)
@@ -714,7 +820,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     const double l = klo(mm), h = khi(mm), v = ym[0];
                     const double below = l - v, above = v - h;
                     const double viol = below > above ? below : above;
-                    viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), 0, kk, above > below);
+                    viol_cand(viol * fast_rcp(1.0 + fabs(below > above ? l : h)), viol, 0, kk, above > below);
                 }
             }
         }
@@ -738,6 +844,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 viol = viol || (l - v > 1e-9 * (1.0 + fabs(l))) || (v - h > 1e-9 * (1.0 + fabs(h)));
             }
             capped = viol;
+            fail = (int)UAVQP_PRIMAL_INFEASIBLE;      // (if capped: the only polynomial there is violates a row)
         }
         // ================= combine the halves' decisions (order-independent rules: identical in both lanes afterwards) =================
         {
@@ -748,6 +855,8 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             if (otk >= 0 && (tkind < 0 || ot < tmin || (ot == tmin && (otk < tkind || (otk == tkind && oti < tidx))))) { tmin = ot; tkind = otk; tidx = oti; }
             inconsistent = inconsistent || (oinc != 0);
             capped = capped || (ocap != 0);
+            if (any_dirm) { hz = fmax(hz, swap_pair(hz)); dymax = fmax(dymax, swap_pair(dymax)); }
+            if (any_pend) vq_now = fmax(vq_now, swap_pair(vq_now));
         }
         // ================= dual active-set step (as qp_rows.h) =================
         bool done = false;
@@ -761,16 +870,49 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 for (int j = 0; j < K; ++j) pract[j] = ract[j];
                 if (capped) {
                     finish = true;
-                } else if (inconsistent) {
-                    if (new_kind == 0) pin &= ~(1ull << new_idx);
-                    else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
-                    else {
-#pragma unroll
-                        for (int j = 0; j < K; ++j) ract[j] = req[j];
+                    // (a pending certificate is accepted as OSQP accepts one: the violation of q at this minimiser >= eps_prim_inf |dy|_inf)
+                    if (pend_inf && vq_now >= a.eps_prim_inf * dyn_keep) fail = (int)UAVQP_PRIMAL_INFEASIBLE;
+                } else if (dirm) {
+                    // ---- the direction-mode solve: rates of the multipliers of W along the dependency of q on W (qp_rows.h)
+                    dirm = false;
+                    const unsigned long long qbit = 1ull << new_idx;
+                    const double dyn = fmax(1.0, dymax);
+                    const bool dep = !inconsistent && hz <= fmax(a.eps_prim_inf, 1e-6) * dyn;     // (NaNs fail the test)
+                    if (!inconsistent && tkind >= 0) {
+                        tpend = tmin;
+                        if (tkind == 0) pin &= ~(1ull << tidx);
+                        else ract[tkind - 1] &= ~(1ull << tidx);
+                        if (new_kind == 0) { pin |= qbit; ppin |= qbit; }
+                        else { ract[new_kind - 1] |= qbit; pract[new_kind - 1] |= qbit; }
+                    } else {
+                        fail = (int)UAVQP_MAX_ITER_REACHED;
+                        pend_inf = dep;
+                        dyn_keep = dyn;
+                        tpend = 0.0;
+                        capped = true;
                     }
-                    new_kind = -1;
-                    tpend = 1.0;
-                    capped = true;
+                } else if (inconsistent && !GI) {
+                    redo = true;         // decided by the second pass
+                    finish = true;
+                } else if (inconsistent) {
+                    if (new_kind >= 0) {
+                        // the constraint that has just entered depends on the working set: out again, one solve for the direction
+                        if (new_kind == 0) pin &= ~(1ull << new_idx);
+                        else ract[new_kind - 1] &= ~(1ull << new_idx);
+                        dirm = true;
+                        tpend = 0.0;
+                    } else if (!restarted) {
+                        // a singular STARTING set: once more from the boxes' equalities alone (the equality rows enter like violated constraints)
+                        restarted = true;
+                        pin = eqmask; upper = 0ull; ppin = 0ull;
+#pragma unroll
+                        for (int j = 0; j < K; ++j) { ract[j] = 0ull; rup[j] = 0ull; pract[j] = 0ull; }
+                        tpend = 1.0;
+                    } else {
+                        tpend = 1.0;
+                        capped = true;
+                        fail = (int)UAVQP_MAX_ITER_REACHED;
+                    }
                 } else if (tkind >= 0) {
                     tpend = tmin;
                     if (tkind == 0) pin &= ~(1ull << tidx);
@@ -791,11 +933,16 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                         new_kind = vkind; new_idx = vidx;
                     }
                 }
-                if (!done && !finish && it >= a.max_iter) {
-                    if (new_kind == 0) pin &= ~(1ull << new_idx);
-                    else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
+                if (!done && !finish && !capped && it >= a.max_iter) {
+                    if (!dirm) {
+                        if (new_kind == 0) pin &= ~(1ull << new_idx);
+                        else if (new_kind > 0) ract[new_kind - 1] &= ~(1ull << new_idx);
+                    }
+                    dirm = false;
                     new_kind = -1;
                     capped = true;
+                    pend_inf = false;
+                    fail = (int)UAVQP_MAX_ITER_REACHED;
                 }
                 if (done) finish = true;
             }
@@ -805,7 +952,11 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         r2_acc[7] += 1;
 #endif
         // ================= hand-over: Hermite solution of the interior knots (original frame) =================
-        if (finish) {
+        if (finish && redo) {
+            if (!isR) aa.redo[atomicAdd(a.queue + 1, 1u)] = (unsigned int)g;
+            g = -1;
+            m = 0;
+        } else if (finish) {
             for (int j = 1; j <= mm; ++j) {
                 if (j == mm && isR) continue;      // the meeting knot is written by the L lane
                 const int kk = korig(j);
@@ -818,7 +969,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 }
             }
             if (!isR) {
-                if (capped) atomicMin(&a.status[b], (int32_t)UAVQP_MAX_ITER_REACHED);
+                if (capped) atomicMin(&a.status[b], (int32_t)fail);     // (UAVQP_PRIMAL_INFEASIBLE < UAVQP_MAX_ITER_REACHED: an infeasible axis decides)
                 if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
                 if (a.active) {
                     unsigned long long* o = a.active + (size_t)g * (2 + 2 * K);

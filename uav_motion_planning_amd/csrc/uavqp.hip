@@ -1709,6 +1709,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     uavqp::RowsArgs a;
     a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax;
     a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 12 * Mmax * (1 + K) + 30;
+    a.eps_prim_inf = ctx->settings.eps_prim_inf;
     a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
     a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.row_tau = d_row_tau; a.row_deriv = d_row_deriv; a.row_lo = d_row_lo; a.row_hi = d_row_hi;
     a.status = d_status_out; a.iters = d_iters_out; a.active = (unsigned long long*)d_active_out;
@@ -1734,7 +1735,8 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         const size_t b_lam = align256(sizeof(double) * (size_t)kown * 2 * NCN * (size_t)grid * 64);
         const long long total_seg = rows - n_traj;
         const size_t b_gfun = d_gfun_pre ? 0 : align256(sizeof(double) * (size_t)total_seg * K * 2 * r);
-        rc = ensure_ws(ctx, b_xsol + 256 + b_desc + b_order + b_state + b_lam + b_gfun);
+        const size_t b_redo = align256(sizeof(unsigned int) * (size_t)pairs);
+        rc = ensure_ws(ctx, b_xsol + 256 + b_desc + b_order + b_state + b_lam + b_gfun + b_redo);
         if (rc != UAVQP_OK) return rc;
         char* p = (char*)ctx->ws;
         a.xsol = (double*)p; p += b_xsol;
@@ -1759,6 +1761,8 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         a.ws = (double*)p; p += b_state;
         aa.lam = (double*)p; p += b_lam;
         aa.gfun = d_gfun_pre ? d_gfun_pre : (double*)p;
+        p += b_gfun;
+        aa.redo = (unsigned int*)p;
         aa.ws_knots = ws_knots;
         aa.lam_knots = kown;
         UAVQP_HIP(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
@@ -1770,12 +1774,19 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         long long ggrid = (total_seg * K + 255) / 256;
         if (ggrid > (long long)ctx->num_cus * 16) ggrid = (long long)ctx->num_cus * 16;
         if (ggrid < 1) ggrid = 1;
+        const long long grid2 = grid < (long long)ctx->num_cus ? grid : (long long)ctx->num_cus;     // (the redo list is short: one wave per CU at most)
 #define UAVQP_ROWS2(RR, KK)                                                                                                                  \
     do {                                                                                                                                     \
         hipLaunchKernelGGL((uavqp::rows_prep_kernel<RR, KK>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);                       \
         if (!d_gfun_pre) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<RR, KK>), dim3((unsigned)ggrid), dim3(256), 0, ctx->stream, aa, total_seg); \
-        if (ws_knots > 0) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);  \
-        else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);             \
+        /* first pass: every problem; second pass (Goldfarb-Idnani's dependent-constraint route): the few the first leaves on its redo list */ \
+        if (ws_knots > 0) {                                                                                                                 \
+            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);         \
+            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, true>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa);         \
+        } else {                                                                                                                            \
+            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);        \
+            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, true>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa);        \
+        }                                                                                                                                   \
     } while (0)
         if (r == 3 && K == 1) UAVQP_ROWS2(3, 1);
         else if (r == 3) UAVQP_ROWS2(3, 2);
