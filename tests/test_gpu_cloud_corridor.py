@@ -368,8 +368,8 @@ def test_pipeline_entry_rejects_bad_arguments_and_handles_empty_and_uniform_batc
 
 @pytest.mark.parametrize("axis_perm,scale", [((0, 1, 2), 1.0), ((1, 0, 2), 1.0), ((2, 1, 0), 1.0), ((0, 1, 2), 0.2)])
 def test_windowed_cloud_scan_gives_the_boxes_of_the_exhaustive_scan_bit_for_bit(gpu_ctx, axis_perm, scale):
-    """uavqp_settings.cloud_window: rows and points sorted along the cloud's longest axis, every block of neighbouring rows scans only the
-    points within reach = max(r, h) (1 + 3 h_max / min(r, h)) of its interval.  A point farther away cannot change a box, so the
+    """uavqp_settings.cloud_window = 1: rows and points sorted along the cloud's longest axis, every block of neighbouring rows scans only the
+    points within reach = max(r, h) (1 + 3 h_max / min(r, h)) of its interval; = 2: 2-D cell grid, rings of cells nearest first.  A point farther away cannot change a box, so the
     result must equal the exhaustive scan's BITWISE -- whichever axis is the longest (coordinates permuted), for a map smaller than the
     reach (scale 0.2: every window is the whole cloud), with rows far outside the cloud, a NaN point and duplicated points."""
     import torch
@@ -388,14 +388,17 @@ def test_windowed_cloud_scan_gives_the_boxes_of_the_exhaustive_scan_bit_for_bit(
     coef, st = gpu_ctx.solve_batch_host(r, so, wp, b["times"], b["bc"])
     d_so, d_wp, d_T, d_coef, d_obs = up(so.astype(np.int32)), up(wp), up(np.asarray(b["times"]).reshape(-1)), up(coef), up(obs)
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         gpu_ctx.set_settings(cloud_window=mode)
         lo = torch.full((rows, 3), np.nan, dtype=torch.float64, device=dev); hi = torch.full((rows, 3), np.nan, dtype=torch.float64, device=dev)
         gpu_ctx.corridor_from_cloud_device(r, n, 0, d_so, rows, d_wp, d_T, d_coef, d_obs, obs.shape[0], ROBOT_R, ROBOT_H, h_max, lo, hi, None)
         gpu_ctx.synchronize()
         res[mode] = (lo.cpu().numpy(), hi.cpu().numpy())
-    gpu_ctx.set_settings(cloud_window=1)
+    gpu_ctx.set_settings(cloud_window=2)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    # 2 (the default since round 5): points and rows by the cell of a 2-D grid, nearest cells first, stop when the clearance found bounds what
+    # the rest of the cloud could still change (cloud_grid2d.h)
+    assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
     width = res[1][1] - res[1][0]
     assert not np.isnan(width).any() and (width > 0).any() and (width.max(axis=1) == 0).any()     # a real mix, every row written
     assert np.allclose(width[1:so[1]], 2 * h_max)                                                 # the far-away rows: nothing in reach

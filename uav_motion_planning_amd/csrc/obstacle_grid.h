@@ -119,6 +119,7 @@ struct CorridorRow {
     double p[3];
     double qxx, qyy, qzz;                          // diagonal of Q = E^-T E^-1 = sum_j b_j b_j' / s_j^2 (box widths)
     double u00, u01, u02, u11, u12, u22, c0, c1, c2;   // Q = U'U, c = U p (the metric of the scan)
+    double b3v[3];                                 // body z axis: (Q^-1)_aa = r^2 - (r^2 - h^2) b3_a^2
     bool interior;
 
     // position, attitude (kino_astar.cpp:724-737) and quadratic form of waypoint row g
@@ -172,6 +173,7 @@ struct CorridorRow {
         double b1[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
         const double n1 = sqrt(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
         b1[0] /= n1; b1[1] /= n1; b1[2] /= n1;
+        b3v[0] = b3[0]; b3v[1] = b3[1]; b3v[2] = b3[2];
         const double wr = 1.0 / (a.robot_r * a.robot_r), wh = 1.0 / (a.robot_h * a.robot_h);
         qxx = (b1[0] * b1[0] + b2[0] * b2[0]) * wr + b3[0] * b3[0] * wh;
         qyy = (b1[1] * b1[1] + b2[1] * b2[1]) * wr + b3[1] * b3[1] * wh;
@@ -199,6 +201,21 @@ struct CorridorRow {
         const double y1 = fma(u11, oy, fma(u12, oz, -c1));
         const double y2 = fma(u22, oz, -c2);
         return fma(y0, y0, fma(y1, y1, y2 * y2));
+    }
+    // No point of a cloud inside the axis-aligned box [bb_lo, bb_hi] can change this row's box: for any offset d with d_a = t,
+    // d'Qd >= t^2 / (Q^-1)_aa (Cauchy-Schwarz), so the clearance is at least  g_lb = max_a dist_a(p, box) / sqrt((Q^-1)_aa),  and from
+    // g_cap = 1 + 3 h_max max_i sqrt(Q_ii) on every half-width is h_max whatever the clearance is.  Exact, with a relative slack of 1e-9.
+    __device__ __forceinline__ bool culled_by_box(const CloudCorridorArgs& a, const double (&bb_lo)[3], const double (&bb_hi)[3]) const {
+        const double r2 = a.robot_r * a.robot_r, h2 = a.robot_h * a.robot_h;
+        double glb2 = 0.0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const double d = fmax(fmax(bb_lo[ax] - p[ax], p[ax] - bb_hi[ax]), 0.0);
+            const double qi = r2 - (r2 - h2) * b3v[ax] * b3v[ax];
+            glb2 = fmax(glb2, d * d / qi);
+        }
+        const double gcap = 1.0 + 3.0 * a.h_max * sqrt(fmax(qxx, fmax(qyy, qzz)));
+        return glb2 >= gcap * gcap * (1.0 + 1e-9);      // (NaN anywhere: not culled)
     }
     // clearance g = sqrt(min metric^2) -> box and outputs
     __device__ __forceinline__ void emit(const CloudCorridorArgs& a, long long g, double min2) const {
@@ -264,6 +281,7 @@ struct CloudSort {
     int axis;
     double p_lo, p_inv;   // point bins over the cloud's extent along `axis`
     double r_lo, r_inv, r_w;   // row bins over [p_lo - reach, p_hi + reach], bin width r_w
+    double bb_lo[3], bb_hi[3]; // bounding box of the finite points: rows it proves capped (CorridorRow::culled_by_box) go to row bin CLOUD_ROW_BINS and are never scanned
 };
 __device__ __forceinline__ int cloud_bin(double v, double lo, double inv, int nb) {
     const double t = (v - lo) * inv;
@@ -294,7 +312,7 @@ __global__ __launch_bounds__(1024) void cloud_sort_setup_kernel(const double* __
         __syncthreads();
     }
     for (int i = threadIdx.x; i <= CLOUD_PT_BINS; i += 1024) pt_hist[i] = 0;
-    for (int i = threadIdx.x; i <= CLOUD_ROW_BINS; i += 1024) row_hist[i] = 0;
+    for (int i = threadIdx.x; i <= CLOUD_ROW_BINS + 1; i += 1024) row_hist[i] = 0;
     if (threadIdx.x == 0) {
         int axis = 0;
         double ext = -1.0;
@@ -310,29 +328,37 @@ __global__ __launch_bounds__(1024) void cloud_sort_setup_kernel(const double* __
         cs->r_lo = lo - reach;
         cs->r_w = (hi - lo + 2.0 * reach) / (double)CLOUD_ROW_BINS;
         cs->r_inv = 1.0 / cs->r_w;
+        for (int ax = 0; ax < 3; ++ax) { cs->bb_lo[ax] = s[0][ax]; cs->bb_hi[ax] = s[0][3 + ax]; }     // (+inf / -inf without a finite point: every row is culled -- no point, every box h_max)
     }
 }
 // histograms of the points and of the rows (one launch), bins at [1..]: hist[b + 1] counts bin b, so that the scan leaves starts.
 // Counted in LDS first (neighbouring rows share bins: global atomics on the same address serialise -- 77 us for 266 k keys), one
 // global add per block and non-empty bin.  Every block works on ONE contiguous slice of the keys, the same slice in the scatter.
-constexpr int CLOUD_BINS_ALL = CLOUD_PT_BINS + CLOUD_ROW_BINS;
+constexpr int CLOUD_BINS_ALL = CLOUD_PT_BINS + CLOUD_ROW_BINS + 1;     // (+ 1: the bin of the rows the cloud's bounding box proves capped)
 __device__ __forceinline__ void cloud_slice(long long total, long long& i0, long long& i1) {
     const long long per = (total + gridDim.x - 1) / gridDim.x;
     i0 = (long long)blockIdx.x * per;
     i1 = i0 + per < total ? i0 + per : total;
 }
-__global__ __launch_bounds__(256) void cloud_sort_hist_kernel(const double* __restrict__ obs, int n_obs, const double* __restrict__ wp, int n_rows,
-                                                              const CloudSort* __restrict__ cs, int32_t* __restrict__ pt_hist,
-                                                              int32_t* __restrict__ row_hist) {
+template <int R>
+__global__ __launch_bounds__(256) void cloud_sort_hist_kernel(CloudCorridorArgs a, const CloudSort* __restrict__ csp, int32_t* __restrict__ pt_hist,
+                                                              int32_t* __restrict__ row_hist, int32_t* __restrict__ row_bin) {
     __shared__ int s_h[CLOUD_BINS_ALL];
     for (int i = threadIdx.x; i < CLOUD_BINS_ALL; i += 256) s_h[i] = 0;
     __syncthreads();
-    const int axis = cs->axis;
+    const CloudSort cs = *csp;
+    const int axis = cs.axis, n_obs = a.n_obs;
     long long i0, i1;
-    cloud_slice((long long)n_obs + n_rows, i0, i1);
+    cloud_slice((long long)n_obs + a.n_rows, i0, i1);
     for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-        if (i < n_obs) atomicAdd(&s_h[cloud_bin(obs[(size_t)i * 3 + axis], cs->p_lo, cs->p_inv, CLOUD_PT_BINS)], 1);
-        else atomicAdd(&s_h[CLOUD_PT_BINS + cloud_bin(wp[(size_t)(i - n_obs) * 3 + axis], cs->r_lo, cs->r_inv, CLOUD_ROW_BINS)], 1);
+        if (i < n_obs) atomicAdd(&s_h[cloud_bin(a.obs[(size_t)i * 3 + axis], cs.p_lo, cs.p_inv, CLOUD_PT_BINS)], 1);
+        else {
+            CorridorRow<R> row;
+            row.setup(a, i - n_obs);
+            const int b = row.culled_by_box(a, cs.bb_lo, cs.bb_hi) ? CLOUD_ROW_BINS : cloud_bin(row.p[axis], cs.r_lo, cs.r_inv, CLOUD_ROW_BINS);
+            row_bin[i - n_obs] = b;
+            atomicAdd(&s_h[CLOUD_PT_BINS + b], 1);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < CLOUD_BINS_ALL; i += 256) {
@@ -362,12 +388,12 @@ __global__ __launch_bounds__(1024) void cloud_sort_scan_kernel(int32_t* __restri
         __syncthreads();
     };
     scan(pt_start, pt_cursor, CLOUD_PT_BINS);
-    scan(row_start, row_cursor, CLOUD_ROW_BINS);
+    scan(row_start, row_cursor, CLOUD_ROW_BINS + 1);
 }
 // scatter: the block counts its slice per bin in LDS again, reserves a range per non-empty bin with ONE global add, and hands out the
 // positions inside the ranges with LDS atomics (the order inside a bin is arbitrary: it decides which lane scans a row / where in a
 // tile a point sits, never a result -- the minimum over a set does not depend on the order)
-__global__ __launch_bounds__(256) void cloud_sort_scatter_kernel(const double* __restrict__ obs, int n_obs, const double* __restrict__ wp, int n_rows,
+__global__ __launch_bounds__(256) void cloud_sort_scatter_kernel(const double* __restrict__ obs, int n_obs, const int32_t* __restrict__ row_bin, int n_rows,
                                                                  const CloudSort* __restrict__ cs, int32_t* __restrict__ pt_cursor,
                                                                  int32_t* __restrict__ row_cursor, double* __restrict__ pts_sorted,
                                                                  int32_t* __restrict__ row_perm) {
@@ -378,8 +404,7 @@ __global__ __launch_bounds__(256) void cloud_sort_scatter_kernel(const double* _
     long long i0, i1;
     cloud_slice((long long)n_obs + n_rows, i0, i1);
     auto bin_of = [&](long long i) -> int {
-        return i < n_obs ? cloud_bin(obs[(size_t)i * 3 + axis], cs->p_lo, cs->p_inv, CLOUD_PT_BINS)
-                         : CLOUD_PT_BINS + cloud_bin(wp[(size_t)(i - n_obs) * 3 + axis], cs->r_lo, cs->r_inv, CLOUD_ROW_BINS);
+        return i < n_obs ? cloud_bin(obs[(size_t)i * 3 + axis], cs->p_lo, cs->p_inv, CLOUD_PT_BINS) : CLOUD_PT_BINS + row_bin[i - n_obs];
     };
     for (long long i = i0 + threadIdx.x; i < i1; i += 256) atomicAdd(&s_h[bin_of(i)], 1);
     __syncthreads();
@@ -408,15 +433,21 @@ __global__ __launch_bounds__(256) void cloud_window_kernel(CloudCorridorArgs a) 
     const long long n_round = ((long long)a.n_rows + 255) / 256 * 256;
     for (long long g0 = (long long)blockIdx.x * 256; g0 < n_round; g0 += (long long)gridDim.x * 256) {
         const long long g = g0 + threadIdx.x;
-        const bool live = g < a.n_rows;
-        const int rid = live ? a.row_perm[g] : 0;
+        const bool present = g < a.n_rows;
+        const int n_scan = a.row_start[CLOUD_ROW_BINS];          // rows [n_scan, n_rows): proven capped by the cloud's bounding box -- emitted without a scan
+        const bool live = present && g < n_scan;
+        const int rid = present ? a.row_perm[g] : 0;
         CorridorRow<R> row;
-        if (live) row.setup(a, rid);
+        if (present) row.setup(a, rid);
+        if (g0 >= n_scan) {                                       // (block-uniform: nothing of this block is scanned)
+            if (present) row.emit(a, rid, INFINITY);
+            continue;
+        }
         __syncthreads();   // (s_win of the previous round has been read by everybody)
         if (threadIdx.x == 0) {
             // the block's rows are consecutive in bin order: bins [kb_lo, kb_hi], found by binary search over the bin starts;
             // one bin of slack either side covers the rounding of the bin function, the outermost bins are open-ended
-            const int gl = (int)g0, gh = (int)((g0 + 255 < a.n_rows ? g0 + 255 : a.n_rows - 1));
+            const int gl = (int)g0, gh = (int)((g0 + 255 < n_scan ? g0 + 255 : n_scan - 1));
             auto bin_of = [&](int idx) -> int {   // largest b with row_start[b] <= idx
                 int lo_b = 0, hi_b = CLOUD_ROW_BINS - 1;
                 while (lo_b < hi_b) {
@@ -455,7 +486,7 @@ __global__ __launch_bounds__(256) void cloud_window_kernel(CloudCorridorArgs a) 
                 for (; i < nt; ++i) m0 = min_nn(m0, row.metric2(s_obs[3 * i], s_obs[3 * i + 1], s_obs[3 * i + 2]));
             }
         }
-        if (live) row.emit(a, rid, fmin(fmin(m0, m1), fmin(m2, m3)));
+        if (present) row.emit(a, rid, live ? fmin(fmin(m0, m1), fmin(m2, m3)) : INFINITY);
     }
 }
 

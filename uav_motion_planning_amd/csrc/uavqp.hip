@@ -697,6 +697,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 #include "qp_rows2.h"
 #include "qp_rows_dual.h"
 #include "obstacle_grid.h"
+#include "cloud_grid2d.h"
 
 namespace uavqp {
 // Specialised (R, M) instantiations of the register-resident kernel; everything else takes the generic one.
@@ -811,7 +812,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     ctx->settings.warm_start = st->warm_start ? 1 : 0;
     ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
     ctx->settings.corridor_initial_guess = st->corridor_initial_guess < 0 ? 0 : (st->corridor_initial_guess > 2 ? 2 : st->corridor_initial_guess);
-    ctx->settings.cloud_window = st->cloud_window ? 1 : 0;
+    ctx->settings.cloud_window = st->cloud_window < 0 ? 0 : (st->cloud_window > 2 ? 2 : st->cloud_window);
     ctx->settings.corridor_tail_shape = st->corridor_tail_shape ? 1 : 0;
     return UAVQP_OK;
 }
@@ -1545,6 +1546,16 @@ extern "C" int uavqp_debug_corridor_stamps(uavqp_ctx* ctx, long long* out7) {
 }
 #endif
 
+#ifdef UAVQP_CLOUD_STATS
+// probe build only (tools/cloud_phase_probe.py): blocks of the last cloud_grid2d_kernel launch that scanned ring 0 / 1 / 2
+extern "C" int uavqp_debug_cloud_phases(uavqp_ctx* ctx, unsigned int* out4) {
+    if (!ctx || !out4 || !ctx->dbg_queue) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    UAVQP_HIP(hipMemcpy(out4, ctx->dbg_queue, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return UAVQP_OK;
+}
+#endif
+
 #ifdef UAVQP_ROWS2_TIMING
 // probe build only (tools/rows_sections.py): cycles wave 0 of the last pair-kernel rows solve spent per section
 extern "C" int uavqp_debug_rows2_stamps(uavqp_ctx* ctx, long long* out8) {
@@ -2209,12 +2220,54 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
     // Large clouds, boxes only: rows and points sorted along the cloud's longest axis, every block scans the points within `reach`
     // of its rows (obstacle_grid.h, cloud_window_kernel) -- identical boxes, fewer pairs.  The clearance output needs the exhaustive min.
     const bool windowed = !d_clearance && n_obs >= 4096 && n_rows >= 4096 && ctx->settings.cloud_window != 0;
-    if (windowed) {
+    if (windowed && ctx->settings.cloud_window == 2) {
+        // Round 5: points and rows sorted by the cell of a 2-D grid; a block scans the cells around its rows nearest first and stops as soon
+        // as the clearance found bounds what farther points could still change (cloud_grid2d.h) -- identical boxes, a fraction of the pairs.
         const double rmax = robot_r > robot_h ? robot_r : robot_h, rmin = robot_r > robot_h ? robot_h : robot_r;
         a.reach = rmax * (1.0 + 3.0 * h_max / rmin) * (1.0 + 1e-9) + 1e-9;
-        const size_t b_cs = 256, b_ph = align256(sizeof(int32_t) * (uavqp::CLOUD_PT_BINS + 1)), b_rh = align256(sizeof(int32_t) * (uavqp::CLOUD_ROW_BINS + 1));
+        const size_t b_cg = 256, b_h = align256(sizeof(int32_t) * (uavqp::CLOUD2D_MAX_CELLS + 1));
         const size_t b_pts = align256(sizeof(double) * 3 * (size_t)n_obs), b_perm = align256(sizeof(int32_t) * (size_t)n_rows);
-        const int rc = ensure_ws(ctx, b_cs + 2 * b_ph + 2 * b_rh + b_pts + b_perm);
+        const int rc = ensure_ws(ctx, b_cg + 4 * b_h + b_pts + b_perm);
+        if (rc != UAVQP_OK) return rc;
+        char* p = (char*)ctx->ws;
+        uavqp::Cloud2D* d_cg = (uavqp::Cloud2D*)p;
+        unsigned int* d_phase = (unsigned int*)(p + 128); p += b_cg;
+        int32_t* d_pstart = (int32_t*)p; p += b_h;
+        int32_t* d_pcur = (int32_t*)p; p += b_h;
+        int32_t* d_rstart = (int32_t*)p; p += b_h;
+        int32_t* d_rcur = (int32_t*)p; p += b_h;
+        double* d_pts = (double*)p; p += b_pts;
+        int32_t* d_perm = (int32_t*)p;
+        long long sgrid = ((long long)n_obs + n_rows + 511) / 512;
+        if (sgrid > (long long)ctx->num_cus * 2) sgrid = (long long)ctx->num_cus * 2;
+#ifdef UAVQP_CLOUD_STATS
+        UAVQP_HIP(hipMemsetAsync(d_phase, 0, 16, ctx->stream));
+#endif
+        hipLaunchKernelGGL(uavqp::cloud2d_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_obstacles, n_obs, a.reach / 8.0, d_cg, d_pstart, d_rstart);
+        hipLaunchKernelGGL(uavqp::cloud2d_hist_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, d_waypoints, n_rows,
+                           (const uavqp::Cloud2D*)d_cg, d_pstart, d_rstart);
+        hipLaunchKernelGGL(uavqp::cloud2d_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uavqp::Cloud2D*)d_cg, d_pstart, d_pcur, d_rstart, d_rcur);
+        hipLaunchKernelGGL(uavqp::cloud2d_scatter_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, d_waypoints, n_rows,
+                           (const uavqp::Cloud2D*)d_cg, d_pcur, d_rcur, d_pts, d_perm);
+        a.row_perm = d_perm; a.pt_start = d_pstart; a.pts_sorted = d_pts;
+        uavqp::Cloud2DArgs ga;
+        ga.c = a; ga.grid = d_cg; ga.phase_count = nullptr;
+#ifdef UAVQP_CLOUD_STATS
+        ga.phase_count = d_phase;      // probe build (tools/cloud_phase_probe.py): blocks per ring
+        ctx->dbg_queue = d_phase;
+#else
+        (void)d_phase;
+#endif
+        if (r == 3)
+            hipLaunchKernelGGL(uavqp::cloud_grid2d_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ga);
+        else
+            hipLaunchKernelGGL(uavqp::cloud_grid2d_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ga);
+    } else if (windowed) {
+        const double rmax = robot_r > robot_h ? robot_r : robot_h, rmin = robot_r > robot_h ? robot_h : robot_r;
+        a.reach = rmax * (1.0 + 3.0 * h_max / rmin) * (1.0 + 1e-9) + 1e-9;
+        const size_t b_cs = 256, b_ph = align256(sizeof(int32_t) * (uavqp::CLOUD_PT_BINS + 1)), b_rh = align256(sizeof(int32_t) * (uavqp::CLOUD_ROW_BINS + 2));
+        const size_t b_pts = align256(sizeof(double) * 3 * (size_t)n_obs), b_perm = align256(sizeof(int32_t) * (size_t)n_rows);
+        const int rc = ensure_ws(ctx, b_cs + 2 * b_ph + 2 * b_rh + b_pts + 2 * b_perm);
         if (rc != UAVQP_OK) return rc;
         char* p = (char*)ctx->ws;
         uavqp::CloudSort* d_cs = (uavqp::CloudSort*)p; p += b_cs;
@@ -2223,14 +2276,16 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
         int32_t* d_rstart = (int32_t*)p; p += b_rh;
         int32_t* d_rcur = (int32_t*)p; p += b_rh;
         double* d_pts = (double*)p; p += b_pts;
-        int32_t* d_perm = (int32_t*)p;
+        int32_t* d_perm = (int32_t*)p; p += b_perm;
+        int32_t* d_rbin = (int32_t*)p;
         long long sgrid = ((long long)n_obs + n_rows + 511) / 512;   // every block: one contiguous slice of the keys, bins counted in LDS
         if (sgrid > (long long)ctx->num_cus * 2) sgrid = (long long)ctx->num_cus * 2;
         hipLaunchKernelGGL(uavqp::cloud_sort_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_obstacles, n_obs, a.reach, d_cs, d_pstart, d_rstart);
-        hipLaunchKernelGGL(uavqp::cloud_sort_hist_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, d_waypoints, n_rows,
-                           (const uavqp::CloudSort*)d_cs, d_pstart, d_rstart);
+        // (the histogram pass also computes every row's attitude: rows the cloud's bounding box proves capped go to an extra bin and are never scanned)
+        if (r == 3) hipLaunchKernelGGL(uavqp::cloud_sort_hist_kernel<3>, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, a, (const uavqp::CloudSort*)d_cs, d_pstart, d_rstart, d_rbin);
+        else hipLaunchKernelGGL(uavqp::cloud_sort_hist_kernel<4>, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, a, (const uavqp::CloudSort*)d_cs, d_pstart, d_rstart, d_rbin);
         hipLaunchKernelGGL(uavqp::cloud_sort_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_pstart, d_pcur, d_rstart, d_rcur);
-        hipLaunchKernelGGL(uavqp::cloud_sort_scatter_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, d_waypoints, n_rows,
+        hipLaunchKernelGGL(uavqp::cloud_sort_scatter_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, (const int32_t*)d_rbin, n_rows,
                            (const uavqp::CloudSort*)d_cs, d_pcur, d_rcur, d_pts, d_perm);
         a.sort = d_cs; a.row_perm = d_perm; a.row_start = d_rstart; a.pt_start = d_pstart; a.pts_sorted = d_pts;
         if (r == 3)
