@@ -133,6 +133,11 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *                          (default), 1 = one lane per problem, state in an HBM workspace (the round-2 kernel, kept for A/B).  Same result.
  *   corridor_tail_shape    1 (default): small batches of long r = 4 corridor problems run two waves per CU with twice the sweep state on
  *                          chip (shorter iterations: such a solve is as slow as its slowest problem); 0: always four waves per CU.  Same result.
+ *   corridor_prelude_lanes lanes per trajectory of the dual prelude of a cold corridor solve (corridor_initial_guess = 2): 0 (default) / 8 = groups of
+ *                          8 or 16 lanes (qp_corridor_dual.h); 1 = ONE lane per trajectory with its tableau in lane-private LDS, single precision
+ *                          (qp_corridor_lane.h; batches of at most 16 segments per trajectory, else the groups) -- built in round 5 to get rid of
+ *                          the replicated chain and the lockstep of eight, measured at parity on config 3 (330 vs 338 us: a per-lane pivot costs
+ *                          ~2.5 k instructions of selects per trip), kept as the independent cross-check of the prelude.  Same result.
  *   cloud_window           1 (default): uavqp_corridor_from_cloud_device sorts rows and points along the cloud's longest axis and scans,
  *                          per block of neighbouring rows, only the points that can still change a box (large clouds, no clearance
  *                          output); 0: always the exhaustive scan.  Identical boxes.
@@ -153,6 +158,7 @@ typedef struct uavqp_settings {
     int32_t corridor_pdas_rounds_warm;
     int32_t cloud_window;
     int32_t corridor_tail_shape;
+    int32_t corridor_prelude_lanes;   /* (sits in what was padding: sizeof(uavqp_settings) is unchanged) */
     double realloc_dead_band;
     double realloc_overshoot;
 } uavqp_settings;

@@ -454,3 +454,49 @@ def test_validation_inside_the_dual_prelude_matches_the_prep_kernel(gpu_ctx, r, 
     assert np.array_equal(res[2][0][sel], res[1][0][sel])           # bit for bit
     assert np.array_equal(res[2][3][ok], res[1][3][ok])
     assert np.all(res[2][2][st2 == U.UAVQP_INVALID_INPUT] == res[1][2][st2 == U.UAVQP_INVALID_INPUT])
+
+
+@pytest.mark.parametrize("r,ragged", [(3, False), (4, False), (3, True)])
+def test_one_lane_per_trajectory_prelude_gives_the_same_results(gpu_ctx, r, ragged):
+    """uavqp_settings.corridor_prelude_lanes = 1: the dual prelude with one lane per trajectory and a single-precision tableau in
+    lane-private LDS (qp_corridor_lane.h) instead of groups of eight lanes (qp_corridor_dual.h).  Neither decides a result: coefficients,
+    statuses and working sets are bit-identical; the rounding of the float tableau may cost a near-degenerate problem one more verifying
+    solve (config 3: 5 of 196 608 problems), never more.  Validation duties included: a bad duration, a bad box, a single segment."""
+    import torch
+    n = 700
+    if ragged:
+        b = W.ragged_batch(5, n, r, m_lo=1, m_hi=16, seed=99)
+        uni, mx = 0, 16
+    else:
+        b = W.uniform_batch(3, n, 16, r, time_mode="distance")
+        uni, mx = 16, 16
+    so = np.asarray(b["seg_offsets"])
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    lo, hi = np.asarray(lo).reshape(-1, 3).copy(), np.asarray(hi).reshape(-1, 3).copy()
+    T = np.asarray(b["times"]).reshape(-1).copy()
+    T[so[5]] = -1.0                                            # an invalid duration
+    k6 = int(so[6]) + 6 + 1
+    if so[7] - so[6] >= 2:
+        lo[k6, 1], hi[k6, 1] = 1.0, -1.0                        # lo > hi on one axis of one interior knot
+    k9 = int(so[9]) + 9 + 1
+    if so[10] - so[9] >= 2:
+        lo[k9] = hi[k9]                                        # an equality row
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d = [None if uni else up(so.astype(np.int32)), up(np.asarray(b["waypoints"]).reshape(-1, 3)), up(T), up(b["bc"]), up(lo), up(hi)]
+    res = {}
+    try:
+        for lanes in (8, 1):
+            gpu_ctx.set_settings(corridor_prelude_lanes=lanes)
+            out = torch.full((int(so[-1]) * 6 * r,), 7.0, dtype=torch.float64, device=dev)
+            st = torch.zeros(n, dtype=torch.int32, device=dev)
+            it = torch.zeros(n, dtype=torch.int32, device=dev)
+            act = torch.zeros((n, 3, 2), dtype=torch.int64, device=dev)
+            gpu_ctx.solve_corridor_device(r, n, uni, mx, d[0], d[1], d[2], d[3], d[4], d[5], out, st, it, act, False)
+            gpu_ctx.synchronize()
+            res[lanes] = (out.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), act.cpu().numpy())
+    finally:
+        gpu_ctx.set_settings(corridor_prelude_lanes=0)
+    assert np.array_equal(res[8][0], res[1][0]) and np.array_equal(res[8][1], res[1][1]) and np.array_equal(res[8][3], res[1][3])
+    assert res[8][1][5] == U.UAVQP_INVALID_INPUT and (res[8][1] == U.UAVQP_SOLVED).sum() >= n - 2
+    assert res[1][2].max() <= 3 and res[1][2][res[1][1] == U.UAVQP_SOLVED].mean() < 1.05 and res[8][2].max() <= 1

@@ -82,7 +82,7 @@ class Settings(ctypes.Structure):
                 ("generic_lanes_per_traj", ctypes.c_int32), ("generic_waves_per_cu", ctypes.c_int32),
                 ("corridor_pdas_rounds", ctypes.c_int32), ("corridor_initial_guess", ctypes.c_int32), ("rows_lanes_per_problem", ctypes.c_int32),
                 ("corridor_pdas_rounds_warm", ctypes.c_int32), ("cloud_window", ctypes.c_int32), ("corridor_tail_shape", ctypes.c_int32),
-                ("realloc_dead_band", ctypes.c_double),
+                ("corridor_prelude_lanes", ctypes.c_int32), ("realloc_dead_band", ctypes.c_double),
                 ("realloc_overshoot", ctypes.c_double)]
 
 

@@ -698,6 +698,7 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 #include "qp_rows_dual.h"
 #include "obstacle_grid.h"
 #include "cloud_grid2d.h"
+#include "qp_corridor_lane.h"
 
 namespace uavqp {
 // Specialised (R, M) instantiations of the register-resident kernel; everything else takes the generic one.
@@ -804,7 +805,8 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     if (!(st->eps_prim_inf >= 0.0) || !(st->realloc_dead_band >= 1.0) || !(st->realloc_overshoot >= 1.0) || !(st->realloc_dead_band < INFINITY) ||
         !(st->realloc_overshoot < INFINITY) || st->corridor_pdas_rounds < 0 || st->corridor_pdas_rounds > 64 || st->corridor_pdas_rounds_warm < 0 || st->corridor_pdas_rounds_warm > 64 ||
         (st->generic_lanes_per_traj != 0 && st->generic_lanes_per_traj != 1 && st->generic_lanes_per_traj != 2 && st->generic_lanes_per_traj != 3) || st->generic_waves_per_cu < 0 ||
-        st->generic_waves_per_cu > 32 || st->rows_lanes_per_problem < 0 || st->rows_lanes_per_problem > 2)
+        st->generic_waves_per_cu > 32 || st->rows_lanes_per_problem < 0 || st->rows_lanes_per_problem > 2 ||
+        (st->corridor_prelude_lanes != 0 && st->corridor_prelude_lanes != 1 && st->corridor_prelude_lanes != 8))
         return UAVQP_ERR_INVALID_ARG;
     const int rc = apply_variant(ctx, st->kernel_variant);
     if (rc != UAVQP_OK) return rc;
@@ -1401,7 +1403,12 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     const size_t b_guess = guess ? align256(sizeof(unsigned long long) * 6 * (size_t)n_traj) : 0;
     const bool masked = d_only_i32 || d_only_u8;
     const size_t b_compact = masked ? align256(sizeof(int32_t) * (size_t)n_traj) + 256 : 0;   // compacted dealing order + its length
-    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state + b_guess + b_compact);
+    // one lane per trajectory (qp_corridor_lane.h): batches of at most 16 segments per trajectory, G not cached across solves
+    const bool lane_prelude = dual && !(d_gcache && gcache_mode != 0) && Mmax - 1 <= uavqp::LANE_NV && ctx->settings.corridor_prelude_lanes == 1;
+    long long lgrid = ((long long)n_traj + 63) / 64;
+    if (lgrid > (long long)ctx->num_cus * 4) lgrid = (long long)ctx->num_cus * 4;     // (one wave per SIMD: the register file, not the 27 KB of LDS per wave, sets it)
+    const size_t b_lane = lane_prelude ? align256(sizeof(double) * (size_t)uavqp::lane_scratch_doubles(r) * (size_t)lgrid) : 0;
+    int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state + b_guess + b_compact + b_lane);
     if (rc != UAVQP_OK) return rc;
     a.guess = guess ? (unsigned long long*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order + b_state) : nullptr;
     a.coeff = d_coeff_out;
@@ -1466,6 +1473,10 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
             if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<3>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
             else hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<4>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
         }
+    } else if (lane_prelude) {
+        double* const d_lane = (double*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order + b_state + b_guess + b_compact);
+        if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_lane_kernel<3>), dim3((unsigned)lgrid), dim3(64), 0, ctx->stream, a, d_lane, ctx->dual_trips_extra);
+        else hipLaunchKernelGGL((uavqp::corridor_dual_lane_kernel<4>), dim3((unsigned)lgrid), dim3(64), 0, ctx->stream, a, d_lane, ctx->dual_trips_extra);
     } else if (dual) {
         // groups of 8 lanes (two tableau columns each) for the trajectories of up to 17 segments, whole DPP rows for the longer ones: a batch
         // of mixed lengths gets both launches, each skipping (per wave: the dealing order is by length) what the other one takes
@@ -1552,6 +1563,16 @@ extern "C" int uavqp_debug_cloud_phases(uavqp_ctx* ctx, unsigned int* out4) {
     if (!ctx || !out4 || !ctx->dbg_queue) return UAVQP_ERR_INVALID_ARG;
     UAVQP_HIP(hipStreamSynchronize(ctx->stream));
     UAVQP_HIP(hipMemcpy(out4, ctx->dbg_queue, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return UAVQP_OK;
+}
+#endif
+
+#ifdef UAVQP_LANE_TIMING
+// probe build only (tools/lane_sections.py): cycles block 0 of the last corridor_dual_lane_kernel launch spent per section
+extern "C" int uavqp_debug_lane_stamps(uavqp_ctx* ctx, long long* out8) {
+    if (!ctx || !out8 || !ctx->dbg_queue) return UAVQP_ERR_INVALID_ARG;
+    UAVQP_HIP(hipStreamSynchronize(ctx->stream));
+    UAVQP_HIP(hipMemcpy(out8, (char*)ctx->dbg_queue + 128, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return UAVQP_OK;
 }
 #endif
