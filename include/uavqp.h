@@ -128,7 +128,8 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *                          with (qp_corridor_dual.h, DESIGN.md section 5.13: inverse Hessian of the knot positions once per trajectory,
  *                          Goldfarb-Idnani on a swept tableau) -- the exact block solve then verifies it, one solve per problem instead of
  *                          ~12; trajectories of up to 33 segments, longer batches fall back to 1.  1: the knots whose boxes the end-state
- *                          polynomial misses (closed form, section 5.4).  0: the empty set.  Same result to the last bit whichever is used.
+ *                          polynomial misses (closed form, section 5.4).  0: the empty set.  Same result to the last bit whichever is used, for every
+ *                          problem that ends UAVQP_SOLVED (one that runs into max_iter hands back the iterate it stopped at, which depends on the start).
  *   rows_lanes_per_problem uavqp_solve_rows_batch_*: 0 auto / 2 = a lane pair per (trajectory, axis) problem with the sweep state in LDS
  *                          (default), 1 = one lane per problem, state in an HBM workspace (the round-2 kernel, kept for A/B).  Same result.
  *   corridor_tail_shape    1 (default): small batches of long r = 4 corridor problems run two waves per CU with twice the sweep state on

@@ -252,6 +252,9 @@ __global__ __launch_bounds__(64, 1) void solve_twisted_kernel(BatchArgs a) {
         }
 #pragma unroll
         for (int j = 1; j < mL; ++j) {
+#if defined(UAVQP_TW_SKIP_LAST_ELIM) && !defined(UAVQP_TIMING_BUILD)
+#error "UAVQP_TW_SKIP_LAST_ELIM produces WRONG results: timing harness only (tools/ubench/tw, built with -DUAVQP_TIMING_BUILD), never libuavqp.so"
+#endif
 #ifdef UAVQP_TW_SKIP_LAST_ELIM   // timing-only build (tools/ubench/tw: h_16s): the last elimination step takes its inputs from TWO knots back, so it no
             // longer waits for the step before it -- the same work on a dependent chain one level shorter, i.e. what a cyclic reduction could buy
             // AT MOST (its exchanges not counted); the results are wrong

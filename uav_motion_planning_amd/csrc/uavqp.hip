@@ -775,7 +775,10 @@ struct uavqp_ctx {
         }                                                                                        \
     } while (0)
 
-extern "C" const char* uavqp_version(void) { return "uavqp 0.4.0 (gfx950, float64)"; }
+#ifndef UAVQP_SRC_HASH
+#define UAVQP_SRC_HASH "unknown"
+#endif
+extern "C" const char* uavqp_version(void) { return "uavqp 0.5.0 (gfx950, float64, src " UAVQP_SRC_HASH ")"; }
 
 extern "C" void uavqp_default_settings(uavqp_settings* out) {
     if (!out) return;
@@ -1396,7 +1399,8 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
     const size_t b_queue = 256;
     const size_t b_desc = align256(sizeof(unsigned long long) * 3 * (size_t)n_traj);
-    const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort && !d_order_ready;
+    // (a caller that hands over a compacted dealing order -- the rows solve's box phase, the pipeline -- has decided the order: no window sort nobody reads)
+    const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort && !d_order_ready && !(d_compact_ready && d_n_active_ready);
     const size_t b_order = deal_by_length ? length_order_bytes(n_traj) : 0;   // order + histogram + cursors
     const size_t b_state = sizeof(double) * (size_t)ws_knots * F * (size_t)grid * 64;
     const bool guess = gmode != 0;     // cold start from a starting set (closed form: prep kernel; dual method: corridor_dual_kernel)
