@@ -25,7 +25,7 @@ with U.Context(0) as ctx:
     need = np.minimum(gg, 25.0) * 0.4
     print("clearance g percentiles 10/50/90/99:", np.percentile(gg, [10, 50, 90, 99]))
     print("needed radius [m] percentiles 10/50/90/99:", np.percentile(need, [10, 50, 90, 99]), " share <= 2.5 m:", (need <= 2.5).mean(), " <= 5 m:", (need <= 5.0).mean())
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         ctx.set_settings(cloud_window=mode)
         for _ in range(3):
             ctx.corridor_from_cloud_device(r, n, 0, d_so, rows, d_wp, d_T, d_coef, d_obs, obs.shape[0], 0.4, 0.1, 0.8, lo, hi, None)

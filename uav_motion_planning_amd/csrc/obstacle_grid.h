@@ -424,15 +424,20 @@ __global__ __launch_bounds__(256) void cloud_sort_scatter_kernel(const double* _
     }
 }
 
-template <int R>
+// PS waves share the rows of a block and split the points of every tile between them (PS = 2: 128 rows per 256-thread block): the number of
+// waves of the launch is rows / 64 x PS -- config 5 has only ~2200 row-waves for 1024 SIMDs, two per SIMD, too few to hide the LDS round trip
+// in front of every four points (48 % of the FP64 peak); the partial minima meet in LDS at the end.  Same pairs, same arithmetic per pair.
+template <int R, int PS = 2>
 __global__ __launch_bounds__(256) void cloud_window_kernel(CloudCorridorArgs a) {
-    constexpr int TILE = 1024;
+    constexpr int TILE = 1024, RPB = 256 / PS;      // rows per block
     __shared__ double s_obs[TILE * 3];
+    __shared__ double s_min[256];
     __shared__ int s_win[2];
     const CloudSort cs = *a.sort;
-    const long long n_round = ((long long)a.n_rows + 255) / 256 * 256;
-    for (long long g0 = (long long)blockIdx.x * 256; g0 < n_round; g0 += (long long)gridDim.x * 256) {
-        const long long g = g0 + threadIdx.x;
+    const int rl = threadIdx.x % RPB, part = threadIdx.x / RPB;      // row of the block, share of the points
+    const long long n_round = ((long long)a.n_rows + RPB - 1) / RPB * RPB;
+    for (long long g0 = (long long)blockIdx.x * RPB; g0 < n_round; g0 += (long long)gridDim.x * RPB) {
+        const long long g = g0 + rl;
         const bool present = g < a.n_rows;
         const int n_scan = a.row_start[CLOUD_ROW_BINS];          // rows [n_scan, n_rows): proven capped by the cloud's bounding box -- emitted without a scan
         const bool live = present && g < n_scan;
@@ -440,14 +445,14 @@ __global__ __launch_bounds__(256) void cloud_window_kernel(CloudCorridorArgs a) 
         CorridorRow<R> row;
         if (present) row.setup(a, rid);
         if (g0 >= n_scan) {                                       // (block-uniform: nothing of this block is scanned)
-            if (present) row.emit(a, rid, INFINITY);
+            if (present && part == 0) row.emit(a, rid, INFINITY);
             continue;
         }
-        __syncthreads();   // (s_win of the previous round has been read by everybody)
+        __syncthreads();   // (s_win / s_min of the previous round have been read by everybody)
         if (threadIdx.x == 0) {
             // the block's rows are consecutive in bin order: bins [kb_lo, kb_hi], found by binary search over the bin starts;
             // one bin of slack either side covers the rounding of the bin function, the outermost bins are open-ended
-            const int gl = (int)g0, gh = (int)((g0 + 255 < n_scan ? g0 + 255 : n_scan - 1));
+            const int gl = (int)g0, gh = (int)((g0 + RPB - 1 < n_scan ? g0 + RPB - 1 : n_scan - 1));
             auto bin_of = [&](int idx) -> int {   // largest b with row_start[b] <= idx
                 int lo_b = 0, hi_b = CLOUD_ROW_BINS - 1;
                 while (lo_b < hi_b) {
@@ -475,18 +480,26 @@ __global__ __launch_bounds__(256) void cloud_window_kernel(CloudCorridorArgs a) 
             for (int i = threadIdx.x; i < nt * 3; i += 256) s_obs[i] = a.pts_sorted[(size_t)o0 * 3 + i];
             __syncthreads();
             if (live) {
-                int i = 0;
-                for (; i + 3 < nt; i += 4) {
+                int i = 4 * part;                                 // groups of four points, dealt round-robin to the PS shares
+                for (; i + 3 < nt; i += 4 * PS) {
                     const double* o = s_obs + 3 * i;
                     m0 = min_nn(m0, row.metric2(o[0], o[1], o[2]));
                     m1 = min_nn(m1, row.metric2(o[3], o[4], o[5]));
                     m2 = min_nn(m2, row.metric2(o[6], o[7], o[8]));
                     m3 = min_nn(m3, row.metric2(o[9], o[10], o[11]));
                 }
-                for (; i < nt; ++i) m0 = min_nn(m0, row.metric2(s_obs[3 * i], s_obs[3 * i + 1], s_obs[3 * i + 2]));
+                if (part == 0)
+                    for (int j = nt & ~3; j < nt; ++j) m0 = min_nn(m0, row.metric2(s_obs[3 * j], s_obs[3 * j + 1], s_obs[3 * j + 2]));
             }
         }
-        if (present) row.emit(a, rid, live ? fmin(fmin(m0, m1), fmin(m2, m3)) : INFINITY);
+        double mm = fmin(fmin(m0, m1), fmin(m2, m3));
+        if (PS > 1) {
+            s_min[threadIdx.x] = mm;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PS; ++q) mm = fmin(mm, s_min[q * RPB + rl]);
+        }
+        if (present && part == 0) row.emit(a, rid, live ? mm : INFINITY);
     }
 }
 

@@ -817,7 +817,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     ctx->settings.warm_start = st->warm_start ? 1 : 0;
     ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
     ctx->settings.corridor_initial_guess = st->corridor_initial_guess < 0 ? 0 : (st->corridor_initial_guess > 2 ? 2 : st->corridor_initial_guess);
-    ctx->settings.cloud_window = st->cloud_window < 0 ? 0 : (st->cloud_window > 2 ? 2 : st->cloud_window);
+    ctx->settings.cloud_window = st->cloud_window < 0 ? 0 : (st->cloud_window > 3 ? 3 : st->cloud_window);
     ctx->settings.corridor_tail_shape = st->corridor_tail_shape ? 1 : 0;
     return UAVQP_OK;
 }
@@ -2245,7 +2245,52 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
     // Large clouds, boxes only: rows and points sorted along the cloud's longest axis, every block scans the points within `reach`
     // of its rows (obstacle_grid.h, cloud_window_kernel) -- identical boxes, fewer pairs.  The clearance output needs the exhaustive min.
     const bool windowed = !d_clearance && n_obs >= 4096 && n_rows >= 4096 && ctx->settings.cloud_window != 0;
-    if (windowed && ctx->settings.cloud_window == 2) {
+    if (windowed && ctx->settings.cloud_window >= 3) {
+        // Round 5, two passes on the 2-D cell grid (cloud_grid2d.h): the rows the bounding box does not cull scan the ring next to them; the ones whose
+        // clearance so far does not bound what farther points could change are re-sorted by the radius it implies and scan exactly that -- identical boxes.
+        const double rmax = robot_r > robot_h ? robot_r : robot_h, rmin = robot_r > robot_h ? robot_h : robot_r;
+        a.reach = rmax * (1.0 + 3.0 * h_max / rmin) * (1.0 + 1e-9) + 1e-9;
+        const size_t b_cg = 256, b_h = align256(sizeof(int32_t) * (uavqp::CLOUD2D_MAX_CELLS + 2));
+        const size_t b_h2 = align256(sizeof(int32_t) * ((size_t)uavqp::CLOUD2D_BUCKETS * uavqp::CLOUD2D_MAX_CELLS + 2));
+        const size_t b_pts = align256(sizeof(double) * 3 * (size_t)n_obs), b_perm = align256(sizeof(int32_t) * (size_t)n_rows), b_m = align256(sizeof(double) * (size_t)n_rows);
+        const int rc = ensure_ws(ctx, b_cg + 4 * b_h + 2 * b_h2 + b_pts + 4 * b_perm + b_m);
+        if (rc != UAVQP_OK) return rc;
+        char* p = (char*)ctx->ws;
+        uavqp::Cloud2D* d_cg = (uavqp::Cloud2D*)p; p += b_cg;
+        int32_t* d_pstart = (int32_t*)p; p += b_h;
+        int32_t* d_pcur = (int32_t*)p; p += b_h;
+        int32_t* d_rstart = (int32_t*)p; p += b_h;
+        int32_t* d_rcur = (int32_t*)p; p += b_h;
+        int32_t* d_hist2 = (int32_t*)p; p += b_h2;
+        int32_t* d_cur2 = (int32_t*)p; p += b_h2;
+        double* d_pts = (double*)p; p += b_pts;
+        int32_t* d_perm = (int32_t*)p; p += b_perm;
+        int32_t* d_rbin = (int32_t*)p; p += b_perm;
+        int32_t* d_rkey = (int32_t*)p; p += b_perm;
+        int32_t* d_perm2 = (int32_t*)p; p += b_perm;
+        double* d_rm = (double*)p;
+        long long sgrid = ((long long)n_obs + n_rows + 511) / 512;
+        if (sgrid > (long long)ctx->num_cus * 2) sgrid = (long long)ctx->num_cus * 2;
+        UAVQP_HIP(hipMemsetAsync(d_hist2, 0, b_h2, ctx->stream));
+        hipLaunchKernelGGL(uavqp::cloud2d_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_obstacles, n_obs, a.reach / 8.0, d_cg, d_pstart, d_rstart);
+        if (r == 3) hipLaunchKernelGGL(uavqp::cloud2d_hist_cull_kernel<3>, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, a, (const uavqp::Cloud2D*)d_cg, d_pstart, d_rstart, d_rbin);
+        else hipLaunchKernelGGL(uavqp::cloud2d_hist_cull_kernel<4>, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, a, (const uavqp::Cloud2D*)d_cg, d_pstart, d_rstart, d_rbin);
+        hipLaunchKernelGGL(uavqp::cloud2d_scan_n_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uavqp::Cloud2D*)d_cg, 1, 1, d_pstart, d_pcur, d_rstart, d_rcur);
+        hipLaunchKernelGGL(uavqp::cloud2d_scatter_bin_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, (const int32_t*)d_rbin, n_rows,
+                           (const uavqp::Cloud2D*)d_cg, d_pcur, d_rcur, d_pts, d_perm);
+        a.row_perm = d_perm; a.pt_start = d_pstart; a.pts_sorted = d_pts;
+        uavqp::Cloud2PArgs pa;
+        pa.c = a; pa.grid = d_cg; pa.row_start = d_rstart; pa.row_key = d_rkey; pa.row_m = d_rm; pa.hist2 = d_hist2; pa.perm2 = d_perm2;
+        if (r == 3) hipLaunchKernelGGL(uavqp::cloud2d_pass1_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pa);
+        else hipLaunchKernelGGL(uavqp::cloud2d_pass1_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pa);
+        hipLaunchKernelGGL(uavqp::cloud2d_scan_n_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uavqp::Cloud2D*)d_cg, 0, uavqp::CLOUD2D_BUCKETS, (int32_t*)nullptr,
+                           (int32_t*)nullptr, d_hist2, d_cur2);
+        long long g2 = ((long long)n_rows + 255) / 256;
+        if (g2 > (long long)ctx->num_cus * 8) g2 = (long long)ctx->num_cus * 8;
+        hipLaunchKernelGGL(uavqp::cloud2d_scatter2_kernel, dim3((unsigned)g2), dim3(256), 0, ctx->stream, (const int32_t*)d_rkey, n_rows, d_cur2, d_perm2);
+        if (r == 3) hipLaunchKernelGGL(uavqp::cloud2d_pass2_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pa);
+        else hipLaunchKernelGGL(uavqp::cloud2d_pass2_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, pa);
+    } else if (windowed && ctx->settings.cloud_window == 2) {
         // Round 5: points and rows sorted by the cell of a 2-D grid; a block scans the cells around its rows nearest first and stops as soon
         // as the clearance found bounds what farther points could still change (cloud_grid2d.h) -- identical boxes, a fraction of the pairs.
         const double rmax = robot_r > robot_h ? robot_r : robot_h, rmin = robot_r > robot_h ? robot_h : robot_r;
@@ -2313,10 +2358,12 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
         hipLaunchKernelGGL(uavqp::cloud_sort_scatter_kernel, dim3((unsigned)sgrid), dim3(256), 0, ctx->stream, d_obstacles, n_obs, (const int32_t*)d_rbin, n_rows,
                            (const uavqp::CloudSort*)d_cs, d_pcur, d_rcur, d_pts, d_perm);
         a.sort = d_cs; a.row_perm = d_perm; a.row_start = d_rstart; a.pt_start = d_pstart; a.pts_sorted = d_pts;
+        long long wgrid = ((long long)n_rows + 127) / 128;        // 128 rows per block: two waves share a row and split the points (four: no further gain)
+        if (wgrid > (long long)ctx->num_cus * 24) wgrid = (long long)ctx->num_cus * 24;
         if (r == 3)
-            hipLaunchKernelGGL(uavqp::cloud_window_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL((uavqp::cloud_window_kernel<3, 2>), dim3((unsigned)wgrid), dim3(256), 0, ctx->stream, a);
         else
-            hipLaunchKernelGGL(uavqp::cloud_window_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL((uavqp::cloud_window_kernel<4, 2>), dim3((unsigned)wgrid), dim3(256), 0, ctx->stream, a);
     } else if (r == 3)
         hipLaunchKernelGGL(uavqp::cloud_corridor_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
     else
