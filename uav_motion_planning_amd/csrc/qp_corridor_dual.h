@@ -95,7 +95,12 @@ typedef double2 __attribute__((may_alias)) double2_a;
 // LDS of one group, in doubles.  Slots of RS doubles: the chain record of knot k (S_k^-1: NE numbers, E_k: R R) sits in slot k - 1,
 // row i of G in slot i -- the backward pass reads record k first and then writes rows >= k - 1 of G over the records it no
 // longer needs (slots >= k - 1), so G and the chain records share their memory.  Then the column buffer and 8 scalars.
-constexpr int corridor_dual_slot(int R, int NRW) { return NRW > ((R * (R + 1) / 2 + R * R + 1) & ~1) ? NRW : ((R * (R + 1) / 2 + R * R + 1) & ~1); }
+// r = 4: E_k is NOT kept (26 doubles per knot would make the slot 28 doubles wide for a G of 16: 31.5 KB per wave, five waves per CU): the backward pass
+// re-makes it as S_k^-1 X_k from the duration of segment k -- ~125 instructions per knot for 19 KB per wave, eight waves per CU (config 5's first
+// prelude: the batches of both shapes fit two rounds instead of three)
+constexpr bool corridor_dual_keeps_E(int R) { return R != 4; }
+constexpr int corridor_dual_rec(int R) { return ((R * (R + 1) / 2 + (corridor_dual_keeps_E(R) ? R * R : 0) + 1) & ~1); }
+constexpr int corridor_dual_slot(int R, int NRW) { return NRW > corridor_dual_rec(R) ? NRW : corridor_dual_rec(R); }
 constexpr int corridor_dual_lds_doubles(int R, int L, int NRW) {
     return NRW * corridor_dual_slot(R, NRW) + 2 * (NRW + 2) + 8;
 }
@@ -342,7 +347,7 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
                         E[i][c] = v;
                     }
                 }
-                if (l == 0) {
+                if (corridor_dual_keeps_E(R) && l == 0) {
                     double* const rec = ES(k - 1);
 #pragma unroll
                     for (int i = 0; i < R; ++i)
@@ -375,7 +380,7 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
             lprev = ldl;
             sa = sb;
         }
-        if (l == 0 && !reuse) {   // E of the last chain knot: nothing behind it
+        if (corridor_dual_keeps_E(R) && l == 0 && !reuse) {   // E of the last chain knot: nothing behind it
             double* const rec = ES(kmax);
 #pragma unroll
             for (int i = 0; i < R * R; ++i) rec[NE + i] = 0.0;
@@ -400,10 +405,26 @@ __device__ __forceinline__ void corridor_dual_body(const CorridorArgs& a, int n_
                 for (int i = 0; i < R; ++i)
 #pragma unroll
                     for (int c = 0; c <= i; ++c) { Si[i][c] = rec[f]; Si[c][i] = Si[i][c]; ++f; }
+                if constexpr (corridor_dual_keeps_E(R)) {
 #pragma unroll
-                for (int i = 0; i < R; ++i)
+                    for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int c = 0; c < R; ++c) E[i][c] = rec[NE + i * R + c];
+                        for (int c = 0; c < R; ++c) E[i][c] = rec[NE + i * R + c];
+                } else {
+                    // E_k = S_k^-1 X_k, X_k = the start/end block of segment k (it couples knots k and k + 1; none behind the last variable)
+                    FullBlocks<R> sx;
+                    sx.build(ldT(min(k, M - 1)));
+                    const double cplx = (k + 1 <= n) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int c = 0; c < R; ++c) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int q = 0; q < R; ++q) v += Si[i][q] * sx.B01[q][c];
+                            E[i][c] = v * cplx;
+                        }
+                }
             }
             lds_publish();    // (the record is in registers before rows of G are written over this and older slots)
             double P[R][R], Zkk[R][R];
