@@ -512,76 +512,170 @@ struct EllipsoidGridArgs {
     double t0, dt, robot_r, robot_h;
     int32_t* first_hit;
     uint8_t* flags;
+    const unsigned long long* tmax_bits;   // optional: dt = (double with these bits) / (n_samples - 1) instead of the field above
 };
 
-// One lane per (trajectory, sample), as ellipsoid_kernel; the candidates come from the cells overlapping the
-// axis-aligned box of half-width robot_r + 0.1 around the sample.
+// One lane per (trajectory, sample), as ellipsoid_kernel; the candidates come from the cells overlapping the axis-aligned box of
+// half-width robot_r + 0.1 around the sample.  One wave per workgroup, and the wave POOLS its candidates: a lane next to a pillar has
+// 40-odd points to test while the average lane has 2 (measured on BASELINE config 5, tools/ellipsoid_probe.py), and a loop per lane
+// costs the wave its longest list.  So every lane leaves its frame (sample position, body axes) and its <= 9 point ranges in LDS, the
+// list lengths are scanned across the wave, and the (lane, point) pairs are tested 64 at a time by whichever lane comes by -- the
+// verdict of a sample is an OR over its candidates, so neither the order nor the tester matters.  (No early exit inside a list; the
+// work saved by it was less than the lanes it idled.)
 template <int R>
-__global__ __launch_bounds__(256) void ellipsoid_grid_kernel(EllipsoidGridArgs a) {
+__global__ __launch_bounds__(64) void ellipsoid_grid_kernel(EllipsoidGridArgs a) {
     constexpr int NC = 2 * R;
+    __shared__ double s_frame[12][64];            // [p, b1, b2, b3][lane]
+    __shared__ int s_rb[9][64], s_cum[9][64];     // first point of the x-row ranges of a lane, running sum of their lengths
+    __shared__ int s_off[64], s_hit[64];          // candidates of the lanes before this one; verdict
+    const int lane = threadIdx.x;
     const long long total = (long long)a.n_traj * a.n_samples;
-    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-        const int b = (int)(g / a.n_samples);
-        const int s = (int)(g - (long long)b * a.n_samples);
-        int s0, M;
-        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
-        if (M < 1) {  // zero-segment trajectory (flagged invalid by the solver): nothing to sample, reported collision-free
-            if (a.flags) a.flags[g] = 0;
-            continue;
+    const long long total_round = (total + 63) / 64 * 64;                           // whole waves take part in the shuffles
+    const double dt = a.tmax_bits ? __longlong_as_double((long long)*a.tmax_bits) / (double)(a.n_samples - 1) : a.dt;
+    const double rad = a.robot_r + 1e-1, rad2 = rad * rad;
+    const double ir = 1.0 / a.robot_r, ih = 1.0 / a.robot_h;
+    auto inside = [&](const double* q, const double* f) -> bool {                   // f = p, b1, b2, b3
+        const double dx = q[0] - f[0], dy = q[1] - f[1], dz = q[2] - f[2];
+        if (dx * dx + dy * dy + dz * dz <= rad2) {  // the reference's radius search (r + 0.1)
+            const double e1 = (f[3] * dx + f[4] * dy + f[5] * dz) * ir;
+            const double e2 = (f[6] * dx + f[7] * dy + f[8] * dz) * ir;
+            const double e3 = (f[9] * dx + f[10] * dy + f[11] * dz) * ih;
+            return e1 * e1 + e2 * e2 + e3 * e3 <= 1.0;  // |E^-1 d| <= 1
+        }
+        return false;
+    };
+    for (long long g0 = (long long)blockIdx.x * 64; g0 < total_round; g0 += (long long)gridDim.x * 64) {
+        const long long g = g0 + lane;
+        const bool live = g < total;
+        const int b = live ? (int)(g / a.n_samples) : 0;
+        const int s = live ? (int)(g - (long long)b * a.n_samples) : 0;
+        int s0 = 0, M = 0;
+        if (live) {
+            if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
         }
         const double* __restrict__ T = a.times + s0;
-        double t = a.t0 + s * a.dt;
+        double t = a.t0 + s * dt;
         int idx = 0;
         while (idx < M && t > T[idx] + 1e-4) { t -= T[idx]; ++idx; }
-        if (idx == M) { --idx; t = T[idx]; }
-        double p[3], acc[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            const double* ca = a.coeff + (size_t)3 * NC * s0 + ((size_t)ax * M + idx) * NC;
-            double pv = 0.0, av = 0.0;
-#pragma unroll
-            for (int j = NC - 1; j >= 0; --j) pv = fma(pv, t, ca[j]);
-#pragma unroll
-            for (int j = NC - 1; j >= 2; --j) av = fma(av, t, (double)(j * (j - 1)) * ca[j]);
-            p[ax] = pv;
-            acc[ax] = av;
-        }
-        // kino_astar.cpp:724-727
-        const double n3 = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + (acc[2] + 9.81) * (acc[2] + 9.81));
-        const double b3[3] = {acc[0] / n3, acc[1] / n3, (acc[2] + 9.81) / n3};
-        const double c2[3] = {0.0, b3[2], -b3[1]};  // b3 x (1,0,0)
-        const double n2 = sqrt(c2[1] * c2[1] + c2[2] * c2[2]);
-        const double b2[3] = {0.0, c2[1] / n2, c2[2] / n2};
-        const double c1[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
-        const double n1 = sqrt(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
-        const double b1[3] = {c1[0] / n1, c1[1] / n1, c1[2] / n1};
-        const double rad = a.robot_r + 1e-1, rad2 = rad * rad;
-        const double ir = 1.0 / a.robot_r, ih = 1.0 / a.robot_h;
-        int lo_c[3], hi_c[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            lo_c[ax] = grid_coord(a.grid, p[ax] - rad, ax);
-            hi_c[ax] = grid_coord(a.grid, p[ax] + rad, ax);
-        }
+        // Past the end the sample is the end point.  All trajectories are sampled on one grid (the pipeline's dt comes from the LONGEST of
+        // the batch), so a trajectory of average length has most of its samples there -- and every one after the first repeats that
+        // one's verdict at a larger index: it cannot lower first_hit.  Left out when no per-sample flags are asked for.  (Whether the
+        // previous sample is past the end is its lane's own finding, one lane down; lane 0 has nobody to ask and is simply tested.)
+        const int past = (M >= 1 && idx == M) ? 1 : 0;
+        const int past_prev = __shfl_up(past, 1, 64);
+        const bool repeats = !a.flags && past && s > 0 && lane > 0 && past_prev;
+        const bool act = live && M >= 1 && !repeats;   // (M < 1: zero-segment trajectory, flagged invalid by the solver: reported collision-free)
         bool hit = false;
-        for (int cz = lo_c[2]; cz <= hi_c[2] && !hit; ++cz)
-            for (int cy = lo_c[1]; cy <= hi_c[1] && !hit; ++cy) {
-                // the cells of one x-row are consecutive: one contiguous range of sorted points
-                const int row = (cz * a.grid.dim[1] + cy) * a.grid.dim[0];
-                const int beg = a.grid.cell_start[row + lo_c[0]], end = a.grid.cell_start[row + hi_c[0] + 1];
-                for (int i = beg; i < end; ++i) {
-                    const double dx = a.grid.pts[(size_t)i * 3] - p[0], dy = a.grid.pts[(size_t)i * 3 + 1] - p[1],
-                                 dz = a.grid.pts[(size_t)i * 3 + 2] - p[2];
-                    if (dx * dx + dy * dy + dz * dz <= rad2) {  // the reference's radius search (r + 0.1)
-                        const double e1 = (b1[0] * dx + b1[1] * dy + b1[2] * dz) * ir;
-                        const double e2 = (b2[0] * dx + b2[1] * dy + b2[2] * dz) * ir;
-                        const double e3 = (b3[0] * dx + b3[1] * dy + b3[2] * dz) * ih;
-                        if (e1 * e1 + e2 * e2 + e3 * e3 <= 1.0) { hit = true; break; }  // |E^-1 d| <= 1
-                    }
-                }
+        int cnt = 0;
+        if (act) {
+            if (idx == M) { --idx; t = T[idx]; }
+            double f[12], acc[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double* ca = a.coeff + (size_t)3 * NC * s0 + ((size_t)ax * M + idx) * NC;
+                double pv = 0.0, av = 0.0;
+#pragma unroll
+                for (int j = NC - 1; j >= 0; --j) pv = fma(pv, t, ca[j]);
+#pragma unroll
+                for (int j = NC - 1; j >= 2; --j) av = fma(av, t, (double)(j * (j - 1)) * ca[j]);
+                f[ax] = pv;
+                acc[ax] = av;
             }
-        if (a.flags) a.flags[g] = hit ? 1 : 0;
-        if (hit) atomicMin(&a.first_hit[b], s);
+            // kino_astar.cpp:724-727
+            const double n3 = sqrt(acc[0] * acc[0] + acc[1] * acc[1] + (acc[2] + 9.81) * (acc[2] + 9.81));
+            const double b3[3] = {acc[0] / n3, acc[1] / n3, (acc[2] + 9.81) / n3};
+            const double c2[3] = {0.0, b3[2], -b3[1]};  // b3 x (1,0,0)
+            const double n2 = sqrt(c2[1] * c2[1] + c2[2] * c2[2]);
+            const double b2[3] = {0.0, c2[1] / n2, c2[2] / n2};
+            const double c1[3] = {b2[1] * b3[2] - b2[2] * b3[1], b2[2] * b3[0] - b2[0] * b3[2], b2[0] * b3[1] - b2[1] * b3[0]};
+            const double n1 = sqrt(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                f[3 + ax] = c1[ax] / n1;
+                f[6 + ax] = b2[ax];
+                f[9 + ax] = b3[ax];
+            }
+            int lo_c[3], hi_c[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                lo_c[ax] = grid_coord(a.grid, f[ax] - rad, ax);
+                hi_c[ax] = grid_coord(a.grid, f[ax] + rad, ax);
+            }
+            if (hi_c[2] - lo_c[2] <= 2 && hi_c[1] - lo_c[1] <= 2) {
+                // (the usual case: cells no smaller than the search radius, so the box meets at most 3 x 3 x-rows; the cells of one
+                // x-row are consecutive: one contiguous range of sorted points)
+                int rb[9], re[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int cz = lo_c[2] + k / 3, cy = lo_c[1] + k % 3;
+                    const bool valid = cz <= hi_c[2] && cy <= hi_c[1];
+                    const int row = (cz * a.grid.dim[1] + cy) * a.grid.dim[0];
+                    rb[k] = valid ? a.grid.cell_start[row + lo_c[0]] : 0;
+                    re[k] = valid ? a.grid.cell_start[row + hi_c[0] + 1] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    cnt += re[k] - rb[k];
+                    s_rb[k][lane] = rb[k];
+                    s_cum[k][lane] = cnt;
+                }
+#pragma unroll
+                for (int c = 0; c < 12; ++c) s_frame[c][lane] = f[c];
+            } else {
+                // finer cells than the radius: this lane walks its rows itself
+                for (int cz = lo_c[2]; cz <= hi_c[2] && !hit; ++cz)
+                    for (int cy = lo_c[1]; cy <= hi_c[1] && !hit; ++cy) {
+                        const int row = (cz * a.grid.dim[1] + cy) * a.grid.dim[0];
+                        const int beg = a.grid.cell_start[row + lo_c[0]], end = a.grid.cell_start[row + hi_c[0] + 1];
+                        for (int i = beg; i < end; ++i)
+                            if (inside(a.grid.pts + (size_t)i * 3, f)) { hit = true; break; }
+                    }
+            }
+        }
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += v;
+        }
+        const int W = __shfl(inc, 63, 64);
+        s_off[lane] = inc - cnt;
+        s_hit[lane] = 0;
+        wave_lds_sync();
+        for (int w0 = 0; w0 < W; w0 += 64) {
+            const int item = w0 + lane;
+            if (item < W) {
+                // owner: the last lane whose offset is <= item (lanes without candidates share the offset of the owner behind them)
+                int lo = 0, hi = 63;
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_off[mid] <= item) lo = mid; else hi = mid - 1;
+                }
+                const int L = lo, j = item - s_off[L];
+                int k = 0, prev = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = s_cum[q][L];
+                    if (c <= j) { k = q + 1; prev = c; }
+                }
+                const int i = s_rb[k][L] + (j - prev);
+                double f[12];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) f[c] = s_frame[c][L];
+                if (inside(a.grid.pts + (size_t)i * 3, f)) s_hit[L] = 1;
+            }
+        }
+        wave_lds_sync();
+        hit = act && (hit || s_hit[lane] != 0);
+        if (live && a.flags) a.flags[g] = hit ? 1 : 0;
+        // one atomic per trajectory and wave: the lanes are in (trajectory, sample) order, so the lowest hit lane of a trajectory holds
+        // its lowest hit sample of this wave
+        const unsigned long long hits = __ballot(hit);
+        const int first_lane = lane - s > 0 ? lane - s : 0;                       // where this trajectory's samples start in the wave
+        const unsigned long long below = ((1ull << lane) - 1ull) & ~((1ull << first_lane) - 1ull);
+        if (hit && (hits & below) == 0ull) atomicMin(&a.first_hit[b], s);
+        wave_lds_sync();                                                           // the next trip overwrites the LDS records
     }
 }
 

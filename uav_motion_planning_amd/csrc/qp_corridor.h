@@ -111,10 +111,6 @@ struct FullBlocks {
     __device__ __forceinline__ double B00(int i, int c) const { return ((i + c) & 1) ? -B11[i][c] : B11[i][c]; }
 };
 
-__global__ void fill_f64_kernel(double* p, int n, double v) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -128,19 +124,58 @@ __device__ __forceinline__ bool corridor_takes_part(const int32_t* only_i32, con
 // order is by segment count: waves keep trajectories of similar length), and their number.  One workgroup: a block scan over n_traj flags.
 __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __restrict__ order, int n_traj, const int32_t* __restrict__ only_i32,
                                                              const unsigned char* __restrict__ only_u8, int32_t* __restrict__ out, int* __restrict__ n_out,
-                                                             const unsigned int* __restrict__ none_if_zero = nullptr) {
+                                                             const unsigned int* __restrict__ none_if_zero = nullptr,
+                                                             const int* __restrict__ n_dev = nullptr) {
     // (a caller that counted the participating trajectories while it flagged them passes the count: nothing to scan when it is zero --
     // the rows solve, whose prelude usually takes every trajectory and leaves the box phase none)
     if (none_if_zero && *none_if_zero == 0u) {
         if (threadIdx.x == 0) *n_out = 0;
         return;
     }
+    // (n_dev: `order` is itself a compacted list whose length is on the device -- the pipeline's later rounds compact the previous
+    // round's list, not the whole batch; `out` must then be another buffer)
+    if (n_dev) n_traj = *n_dev;
     // wave w takes the contiguous slice [w per, (w + 1) per) in sub-chunks of 64 (all loads of a lane in flight together: two round trips
     // per pass of 16 sub-chunks, not one per element), ranks by ballot; the 16 wave totals are scanned through LDS
     __shared__ int s_tot[16];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int per = ((n_traj + 15) / 16 + 63) / 64 * 64, w0 = w * per, w1 = min(w0 + per, n_traj);
     constexpr int CH = 16;
+    if (per <= 64 * CH) {
+        // the whole slice of a wave is one chunk (n_traj <= 16384): indices and flags stay in registers between counting and writing
+        int bidx[CH];
+        bool keep[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = w0 + 64 * c + lane;
+            bidx[c] = i < w1 ? (order ? order[i] : i) : -1;
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) keep[c] = bidx[c] >= 0 && corridor_takes_part(only_i32, only_u8, bidx[c]);
+        unsigned long long m[CH];
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            m[c] = __ballot(keep[c]);
+            cnt += __popcll(m[c]);
+        }
+        if (lane == 0) s_tot[w] = cnt;
+        __syncthreads();
+        int base = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int t = s_tot[k];
+            base += k < w ? t : 0;
+            all += t;
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (keep[c]) out[base + __popcll(m[c] & ((1ull << lane) - 1ull))] = bidx[c];
+            base += __popcll(m[c]);
+        }
+        if (threadIdx.x == 0) *n_out = all;
+        return;
+    }
     int tot = 0;
     for (int pass = 0; pass < 2; ++pass) {      // pass 0: count, pass 1: write
         int base = 0;

@@ -625,6 +625,8 @@ struct ReallocArgs {
     double dead_band, overshoot;  // uavqp_settings.realloc_dead_band / realloc_overshoot
     int32_t* changed;
     double* scale_acc;            // optional [n_traj]: multiplied by the factor applied (the pipeline's record of how far a trajectory was stretched)
+    const int32_t* list;          // optional: only these trajectories, *n_list of them (the pipeline's later rounds: a trajectory the last round
+    const int* n_list;            // did not stretch was not re-solved -- its peaks, and so its verdict, are what they were)
 };
 
 template <int R>
@@ -636,12 +638,12 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
     // then scales its own segments.
     constexpr int NC = 2 * R, LPT = 8;
     const int sub = threadIdx.x % LPT;
-    const long long n_lanes = (long long)a.n_traj * LPT;
+    const long long n_lanes = (long long)(a.list ? *a.n_list : a.n_traj) * LPT;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long n_round = (n_lanes + stride - 1) / stride * stride;  // whole waves take part in the shuffles
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n_round; g += stride) {
         const bool live = g < n_lanes;
-        const int b = live ? (int)(g / LPT) : 0;
+        const int b = live ? (a.list ? a.list[g / LPT] : (int)(g / LPT)) : 0;
         int s0 = 0, M = 0;
         if (live) {
             if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
@@ -2020,7 +2022,8 @@ extern "C" int uavqp_solve_rows_batch_host(uavqp_ctx* ctx, int r, int n_traj, in
 
 static int time_reallocate_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
                                 double* d_times, const double* d_coeff, double v_max, double a_max,
-                                int samples_per_seg, double max_stretch, int32_t* d_changed_out, double* d_scale_acc);
+                                int samples_per_seg, double max_stretch, int32_t* d_changed_out, double* d_scale_acc,
+                                const int32_t* d_list = nullptr, const int* d_n_list = nullptr);
 extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
                                             double* d_times, const double* d_coeff, double v_max, double a_max,
                                             int samples_per_seg, double max_stretch, int32_t* d_changed_out) {
@@ -2028,7 +2031,8 @@ extern "C" int uavqp_time_reallocate_device(uavqp_ctx* ctx, int r, int n_traj, i
 }
 static int time_reallocate_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
                                 double* d_times, const double* d_coeff, double v_max, double a_max,
-                                int samples_per_seg, double max_stretch, int32_t* d_changed_out, double* d_scale_acc) {
+                                int samples_per_seg, double max_stretch, int32_t* d_changed_out, double* d_scale_acc,
+                                const int32_t* d_list, const int* d_n_list) {
     if (!ctx || (r != 3 && r != 4) || n_traj < 0 || uniform_segments < 0 || !(v_max > 0.0) || !(a_max > 0.0) ||
         samples_per_seg < 1 || !(max_stretch > 1.0))
         return UAVQP_ERR_INVALID_ARG;
@@ -2039,6 +2043,7 @@ static int time_reallocate_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_s
     a.n_traj = n_traj; a.uniform = uniform_segments; a.samples = samples_per_seg;
     a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.v_max = v_max; a.a_max = a_max;
     a.max_stretch = max_stretch; a.changed = d_changed_out; a.scale_acc = d_scale_acc;
+    a.list = d_list; a.n_list = d_list ? d_n_list : nullptr;
     a.dead_band = ctx->settings.realloc_dead_band; a.overshoot = ctx->settings.realloc_overshoot;
     long long grid_ll = ((long long)n_traj * 8 + 63) / 64;  // 8 lanes per trajectory
     if (grid_ll > (long long)ctx->num_cus * 32) grid_ll = (long long)ctx->num_cus * 32;
@@ -2196,29 +2201,43 @@ fail:
 #undef UAVQP_GRID_HIP
 }
 
+// (d_tmax_bits: the pipeline's form -- dt = [the double whose bits are *d_tmax_bits] / (n_samples - 1), formed by the kernel, and
+// d_first_hit already holds n_samples: the host neither waits for the longest duration nor launches the fill)
+static int ellipsoid_check_grid_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                     const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
+                                     const unsigned long long* d_tmax_bits, const uavqp_grid* grid, double robot_r, double robot_h,
+                                     int32_t* d_first_hit, uint8_t* d_flags);
 extern "C" int uavqp_ellipsoid_check_grid_device(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
                                                  const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
                                                  const uavqp_grid* grid, double robot_r, double robot_h, int32_t* d_first_hit,
                                                  uint8_t* d_flags) {
+    return ellipsoid_check_grid_impl(ctx, r, n_traj, uniform_segments, d_seg_offsets, d_times, d_coeff, n_samples, t0, dt, nullptr, grid, robot_r,
+                                     robot_h, d_first_hit, d_flags);
+}
+static int ellipsoid_check_grid_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segments, const int32_t* d_seg_offsets,
+                                     const double* d_times, const double* d_coeff, int n_samples, double t0, double dt,
+                                     const unsigned long long* d_tmax_bits, const uavqp_grid* grid, double robot_r, double robot_h,
+                                     int32_t* d_first_hit, uint8_t* d_flags) {
     if (!ctx || !grid || (r != 3 && r != 4) || n_traj < 0 || n_samples < 0 || uniform_segments < 0 || !(robot_r > 0.0) || !(robot_h > 0.0))
         return UAVQP_ERR_INVALID_ARG;
     if (n_traj == 0) return UAVQP_OK;
     if (!d_times || !d_coeff || !d_first_hit || (uniform_segments == 0 && !d_seg_offsets) || grid->device != ctx->device)
         return UAVQP_ERR_INVALID_ARG;
     UAVQP_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_first_hit, n_traj, (int32_t)n_samples);
+    if (!d_tmax_bits) hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_first_hit, n_traj, (int32_t)n_samples);
     if (n_samples == 0) return UAVQP_OK;
     uavqp::EllipsoidGridArgs a;
+    a.tmax_bits = d_tmax_bits;
     a.n_traj = n_traj; a.uniform = uniform_segments; a.n_samples = n_samples;
     a.seg_offsets = d_seg_offsets; a.times = d_times; a.coeff = d_coeff; a.grid = grid->view;
     a.t0 = t0; a.dt = dt; a.robot_r = robot_r; a.robot_h = robot_h; a.first_hit = d_first_hit; a.flags = d_flags;
     const long long total = (long long)n_traj * n_samples;
-    long long grid_dim = (total + 255) / 256;
-    if (grid_dim > (long long)ctx->num_cus * 32) grid_dim = (long long)ctx->num_cus * 32;
+    long long grid_dim = (total + 63) / 64;                    // one wave per workgroup (the wave pools its candidates through LDS)
+    if (grid_dim > (long long)ctx->num_cus * 64) grid_dim = (long long)ctx->num_cus * 64;
     if (r == 3)
-        hipLaunchKernelGGL(uavqp::ellipsoid_grid_kernel<3>, dim3((unsigned)grid_dim), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(uavqp::ellipsoid_grid_kernel<3>, dim3((unsigned)grid_dim), dim3(64), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(uavqp::ellipsoid_grid_kernel<4>, dim3((unsigned)grid_dim), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(uavqp::ellipsoid_grid_kernel<4>, dim3((unsigned)grid_dim), dim3(64), 0, ctx->stream, a);
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
 }

@@ -33,6 +33,13 @@ __global__ void pipe_zero_kernel(PipeCounters* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *c = PipeCounters{};
 }
 
+// head of a pipeline call: the stretch record starts at 1 (optional), the counter block at zero (nothing touches it before the check)
+__global__ __launch_bounds__(256) void pipe_begin_kernel(double* __restrict__ scale, int n, PipeCounters* c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (scale && i < n) scale[i] = 1.0;
+    if (i == 0) *c = PipeCounters{};
+}
+
 // changed[b] > 0 / status[b] != SOLVED counts (either pointer may be null)
 __global__ __launch_bounds__(256) void pipe_count_kernel(const int32_t* __restrict__ changed, const int32_t* __restrict__ status, int n, PipeCounters* c) {
     int nc = 0, nu = 0;
@@ -51,44 +58,67 @@ __global__ __launch_bounds__(256) void pipe_count_kernel(const int32_t* __restri
     }
 }
 
-// total duration per trajectory -> max over the batch (the check samples every trajectory on ONE grid: dt = max total / (samples - 1))
-__global__ __launch_bounds__(256) void pipe_total_time_kernel(int n, int uniform, const int32_t* __restrict__ seg_offsets, const double* __restrict__ times, PipeCounters* c) {
+// What the check needs per trajectory, in one launch, eight lanes per trajectory (sub-lane j takes segments j, j + 8, ...; three
+// xor-shuffles combine): the total duration -> max over the batch (all trajectories are sampled on ONE grid: dt = max total /
+// (samples - 1), which the check kernel reads from the counter block -- the host does not wait for it), first_hit = "none", and on the
+// first pass roomy[b] (null afterwards: a repair has shrunk the boxes since).  Was: three kernels, a copy and a stream synchronisation.
+__global__ __launch_bounds__(256) void pipe_check_prep_kernel(int n, int uniform, const int32_t* __restrict__ seg_offsets, const double* __restrict__ times,
+                                                              const double* __restrict__ lo, const double* __restrict__ hi, uint8_t* __restrict__ roomy,
+                                                              int32_t* __restrict__ first_hit, int n_samples, PipeCounters* c) {
+    constexpr int LPT = 8;
+    const int sub = threadIdx.x % LPT;
+    const long long n_lanes = (long long)n * LPT, stride = (long long)gridDim.x * 256;
+    const long long n_round = (n_lanes + stride - 1) / stride * stride;
     double mx = 0.0;
-    for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) {
-        int s0, M;
-        if (uniform > 0) { M = uniform; s0 = b * M; } else { s0 = seg_offsets[b]; M = seg_offsets[b + 1] - s0; }
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n_round; g += stride) {
+        const bool live = g < n_lanes;
+        const int b = live ? (int)(g / LPT) : 0;
+        int s0 = 0, M = 0;
+        if (live) {
+            if (uniform > 0) { M = uniform; s0 = b * M; } else { s0 = seg_offsets[b]; M = seg_offsets[b + 1] - s0; }
+        }
+        // (the partial sums of the eight sub-lanes are added in a fixed tree: the same bits on every run; dt only places the samples)
         double t = 0.0;
-        for (int i = 0; i < M; ++i) t += times[s0 + i];
-        if (t > mx && t < INFINITY) mx = t;
+        for (int i = sub; i < M; i += LPT) t += times[s0 + i];
+        int ok = 1;
+        if (roomy) {
+            const size_t row0 = (size_t)s0 + b;
+            for (int i = sub; i < M; i += LPT) {
+                if (i == 0) continue;            // interior waypoint rows only
+                const double* l = lo + 3 * (row0 + i);
+                const double* h = hi + 3 * (row0 + i);
+                const double w = fmin(fmin(h[0] - l[0], h[1] - l[1]), h[2] - l[2]);
+                ok &= (w > 0.0) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < LPT; d <<= 1) {
+            t += __shfl_xor(t, d, 64);
+            ok &= __shfl_xor(ok, d, 64);
+        }
+        if (live && sub == 0) {
+            if (roomy) roomy[b] = (uint8_t)ok;
+            first_hit[b] = n_samples;
+            if (t > mx && t < INFINITY) mx = t;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&c->tmax_bits, (unsigned long long)__double_as_longlong(mx));
-}
-
-// roomy[b] = 0 when an INTERIOR waypoint row of trajectory b has a degenerate box (min over axes of hi - lo <= 0): the searcher's
-// waypoint itself is within the robot's reach of an obstacle, narrower boxes cannot help
-__global__ __launch_bounds__(256) void pipe_roomy_kernel(int n, int uniform, const int32_t* __restrict__ seg_offsets, const double* __restrict__ lo,
-                                                         const double* __restrict__ hi, uint8_t* __restrict__ roomy) {
-    for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) {
-        int s0, M;
-        if (uniform > 0) { M = uniform; s0 = b * M; } else { s0 = seg_offsets[b]; M = seg_offsets[b + 1] - s0; }
-        const size_t row0 = (size_t)s0 + b;
-        bool ok = true;
-        for (int i = 1; i < M; ++i) {
-            const double* l = lo + 3 * (row0 + i);
-            const double* h = hi + 3 * (row0 + i);
-            const double w = fmin(fmin(h[0] - l[0], h[1] - l[1]), h[2] - l[2]);
-            ok = ok && (w > 0.0);
-        }
-        roomy[b] = ok ? 1 : 0;
+    // one atomic per workgroup (2048 waves on one address cost more than the rest of the kernel)
+    __shared__ double s_mx[4];
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3]));
+        if (mx > 0.0) atomicMax(&c->tmax_bits, (unsigned long long)__double_as_longlong(mx));
     }
 }
 
-// flag[b] = trajectory b collides (first_hit < n_samples) AND is roomy; counts for the host
+// flag[b] = trajectory b collides (first_hit < n_samples) AND is roomy; counts for the host -- with the number of trajectories whose
+// status is not UAVQP_SOLVED (status may be null): when no repair follows, this block is the call's summary
 __global__ __launch_bounds__(256) void pipe_hits_kernel(int n, const int32_t* __restrict__ first_hit, int n_samples, const uint8_t* __restrict__ roomy,
-                                                        uint8_t* __restrict__ flag, PipeCounters* c) {
-    int nh = 0, nb = 0, nr = 0;
+                                                        uint8_t* __restrict__ flag, const int32_t* __restrict__ status, PipeCounters* c) {
+    int nh = 0, nb = 0, nr = 0, nu = 0;
     for (int b = blockIdx.x * 256 + threadIdx.x; b < n; b += gridDim.x * 256) {
         const bool hit = first_hit[b] < n_samples;
         const bool rm = roomy[b] != 0;
@@ -96,17 +126,25 @@ __global__ __launch_bounds__(256) void pipe_hits_kernel(int n, const int32_t* __
         nh += hit;
         nb += hit && !rm;
         nr += hit && rm;
+        if (status && status[b] != UAVQP_SOLVED) ++nu;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         nh += __shfl_xor(nh, d, 64);
         nb += __shfl_xor(nb, d, 64);
         nr += __shfl_xor(nr, d, 64);
+        nu += __shfl_xor(nu, d, 64);
     }
+    __shared__ int s_n[4][4];
     if ((threadIdx.x & 63) == 0) {
-        if (nh) atomicAdd(&c->hit, (unsigned)nh);
-        if (nb) atomicAdd(&c->hit_blocked, (unsigned)nb);
-        if (nr) atomicAdd(&c->hit_repairable, (unsigned)nr);
+        int* q = s_n[threadIdx.x >> 6];
+        q[0] = nh; q[1] = nb; q[2] = nr; q[3] = nu;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {      // one atomic per counter and workgroup
+        const int k = threadIdx.x, v = s_n[0][k] + s_n[1][k] + s_n[2][k] + s_n[3][k];
+        unsigned int* dst = k == 0 ? &c->hit : k == 1 ? &c->hit_blocked : k == 2 ? &c->hit_repairable : &c->unsolved;
+        if (v) atomicAdd(dst, (unsigned)v);
     }
 }
 
@@ -203,7 +241,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     // G of the dual prelude across the rounds (the re-allocation multiplies all durations of a trajectory by one factor: G only rescales)
     const bool g_across = ctx->settings.corridor_initial_guess == 2 && mx - 1 <= 24 && mx >= 2;
     const size_t o_cp = o_or + (deal_by_length ? length_order_bytes(n) : 0);          // compacted dealing order of the next re-solve + its count
-    const size_t o_sc = o_cp + align256(sizeof(int32_t) * (size_t)n) + 256;
+    const size_t o_sc = o_cp + 2 * align256(sizeof(int32_t) * (size_t)n) + 256;       // (two lists: round k compacts round k - 1's into the other one)
     const size_t o_gc = o_sc + (g_across ? align256(sizeof(double) * (size_t)n) : 0);
     const size_t need = o_gc + (g_across ? align256(sizeof(double) * (size_t)n * uavqp::corridor_gcache_stride) : 0);
     int rc = ensure_pipe_ws(ctx, need);
@@ -214,8 +252,9 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     int32_t* d_changed = (int32_t*)(base + o_ch);
     int32_t* d_fh = d_first_hit ? d_first_hit : (int32_t*)(base + o_fh);
     uint64_t* d_active = (uint64_t*)(base + o_as);
-    int32_t* d_cp = (int32_t*)(base + o_cp);
-    int* d_na = (int*)(base + o_cp + align256(sizeof(int32_t) * (size_t)n));
+    int32_t* const d_cp2[2] = {(int32_t*)(base + o_cp), (int32_t*)(base + o_cp + align256(sizeof(int32_t) * (size_t)n))};
+    int* const d_na2[2] = {(int*)(base + o_cp + 2 * align256(sizeof(int32_t) * (size_t)n)), (int*)(base + o_cp + 2 * align256(sizeof(int32_t) * (size_t)n)) + 32};
+    int cur_list = 0;                                                                  // the list the next re-solve takes
     double* d_scale = g_across ? (double*)(base + o_sc) : nullptr;     // factor by which every trajectory was stretched since its G was stored
     double* d_gcache = g_across ? (double*)(base + o_gc) : nullptr;
     int solves_done = 0;
@@ -243,6 +282,8 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     // solve) a re-solve is a cold solve; with the other settings it is warm-started from the previous round as before.
     const bool cold_rounds = ctx->settings.corridor_initial_guess == 2 && (uni > 0 ? uni : mx) - 1 <= 32;
     auto corridor_solve = [&](int warm, const int32_t* only_i32 = nullptr, const unsigned char* only_u8 = nullptr, bool precompacted = false) {
+        const int32_t* d_cp = d_cp2[cur_list];
+        const int* d_na = d_na2[cur_list];
         // first solve: every trajectory takes part, its G is stored; later solves load it and rescale by the stretch since then
         const int gmode = (g_across && cold_rounds) ? (solves_done == 0 ? 1 : 2) : 0;
         ++solves_done;
@@ -259,7 +300,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
         return read_counters();
     };
 
-    if (d_scale) hipLaunchKernelGGL(uavqp::fill_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_scale, n, 1.0);
+    hipLaunchKernelGGL(uavqp::pipe_begin_kernel, dim3(d_scale ? (n + 255) / 256 : 1), dim3(256), 0, s, d_scale, n, d_cnt);
     // 1. the reference's equality problem, 2. boxes from the cloud with the attitude of that solve
     rc = uavqp_solve_batch_device(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_coeff_out, d_status_out);
     if (rc != UAVQP_OK) return rc;
@@ -272,6 +313,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     // extra round re-solves nobody and stretches nobody (same bytes everywhere), at the price of a few empty launches.  Was: copy +
     // stream synchronisation + 25-30 us of idle device per round.
     int rounds = 0, still = 0;
+    bool cap_solve_enqueued = false;
     {
         for (int k = 0; k < 4; ++k)
             if (!ctx->pipe_ev[k]) UAVQP_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[k], hipEventDisableTiming));
@@ -279,20 +321,35 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
         auto enqueue_round = [&](int rnd) -> int {
             int rc_ = corridor_solve(rnd > 0 ? 2 : 0, rnd > 0 ? (const int32_t*)d_changed : nullptr, nullptr, rnd > 0);
             if (rc_ != UAVQP_OK) return rc_;
+            // rounds after the first look only at the trajectories that round re-solved (the list of the previous compaction): the others
+            // have the coefficients and durations the previous re-allocation already accepted (their flag in d_changed is 0 and stays 0)
+            const int32_t* d_prev = rnd > 0 ? d_cp2[cur_list] : nullptr;
+            const int* d_nprev = rnd > 0 ? d_na2[cur_list] : nullptr;
             rc_ = time_reallocate_impl(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.v_max, P.a_max, P.samples_per_seg,
-                                       P.max_stretch, d_changed, d_scale);
+                                       P.max_stretch, d_changed, d_scale, d_prev, d_nprev);
             if (rc_ != UAVQP_OK) return rc_;
             // the dealing order of the trajectories it stretched, for the re-solve of the next round -- and their number, which is the
             // round's counter (was: a zeroing kernel, a counting kernel, and the compaction at the head of the next solve)
-            hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, s, d_order, n, (const int32_t*)d_changed, (const unsigned char*)nullptr, d_cp, d_na);
-            UAVQP_HIP(hipMemcpyAsync(&h_ring[rnd & 3].changed, d_na, sizeof(int), hipMemcpyDeviceToHost, s));
+            const int nxt = rnd > 0 ? cur_list ^ 1 : cur_list;
+            hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, s, rnd > 0 ? d_prev : d_order, n, (const int32_t*)d_changed,
+                               (const unsigned char*)nullptr, d_cp2[nxt], d_na2[nxt], (const unsigned int*)nullptr, d_nprev);
+            cur_list = nxt;
+            UAVQP_HIP(hipMemcpyAsync(&h_ring[rnd & 3].changed, d_na2[nxt], sizeof(int), hipMemcpyDeviceToHost, s));
             UAVQP_HIP(hipEventRecord(ctx->pipe_ev[rnd & 3], s));
+            if (rnd + 1 == P.max_rounds) {
+                // the cap: the trajectories this last re-allocation stretched need one more solve so that their coefficients belong to
+                // d_times -- enqueued behind the compaction without waiting for its count (an empty list solves nobody)
+                rc_ = corridor_solve(2, (const int32_t*)d_changed, nullptr, true);
+                if (rc_ != UAVQP_OK) return rc_;
+                cap_solve_enqueued = true;
+            }
             return UAVQP_OK;
         };
         int enq = 0, exam = 0;
         unsigned int last = 0;
         for (;;) {
-            while (enq < P.max_rounds && (enq <= exam || (enq == exam + 1 && exam >= 1 && (long long)last * 64 > (long long)n))) {
+            // (round 1 is enqueued unseen too: a batch that comes here for a re-allocation normally has something to stretch in round 0)
+            while (enq < P.max_rounds && (enq <= exam || (enq == exam + 1 && (exam == 0 || (long long)last * 64 > (long long)n)))) {
                 rc = enqueue_round(enq);
                 if (rc != UAVQP_OK) return rc;
                 ++enq;
@@ -307,13 +364,13 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
         }
         // (a speculative round may still be in flight: everything that follows is ordered behind it on the same stream)
     }
-    if (still != 0) {
+    if (still != 0 && !cap_solve_enqueued) {
         // cap reached with durations changed by the last re-allocation: one more solve so that the coefficients match d_times
         rc = corridor_solve(2, (const int32_t*)d_changed, nullptr, true);
         if (rc != UAVQP_OK) return rc;
     }
     // 4. check + repair
-    int repairs = 0, before = -1, blocked = 0, after = 0;
+    int repairs = 0, before = -1, blocked = 0, after = 0, summary_unsolved = -1;
     double check_dt = 0.0;
     uavqp_grid* own_grid = nullptr;
     if (checking) {
@@ -323,23 +380,24 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
             if (rc != UAVQP_OK) return rc;
             grid = own_grid;
         }
-        hipLaunchKernelGGL(uavqp::pipe_roomy_kernel, dim3(cgrid), dim3(256), 0, s, n, uni, d_seg_offsets, (const double*)d_corr_lo,
-                           (const double*)d_corr_hi, d_roomy);
-        for (;;) {
-            hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
-            hipLaunchKernelGGL(uavqp::pipe_total_time_kernel, dim3(cgrid), dim3(256), 0, s, n, uni, d_seg_offsets, (const double*)d_times, d_cnt);
+        int pgrid = (int)(((long long)n * 8 + 255) / 256);
+        if (pgrid > ctx->num_cus * 2) pgrid = ctx->num_cus * 2;
+        for (int pass = 0;; ++pass) {
+            // (the counter block is zero: pipe_begin_kernel, nothing since -- after a repair the zeroing kernel below)
+            if (pass > 0) hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
+            hipLaunchKernelGGL(uavqp::pipe_check_prep_kernel, dim3(pgrid), dim3(256), 0, s, n, uni, d_seg_offsets, (const double*)d_times,
+                               (const double*)d_corr_lo, (const double*)d_corr_hi, pass == 0 ? d_roomy : (uint8_t*)nullptr, d_fh, P.check_samples, d_cnt);
+            rc = ellipsoid_check_grid_impl(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.check_samples, 0.0, 0.0, &d_cnt->tmax_bits, grid,
+                                           chk_r, chk_h, d_fh, nullptr);
+            if (rc != UAVQP_OK) break;
+            hipLaunchKernelGGL(uavqp::pipe_hits_kernel, dim3(cgrid), dim3(256), 0, s, n, (const int32_t*)d_fh, P.check_samples, (const uint8_t*)d_roomy, d_flag,
+                               (const int32_t*)d_status_out, d_cnt);
             rc = read_counters();
             if (rc != UAVQP_OK) break;
             double tmax;
             std::memcpy(&tmax, &h_cnt->tmax_bits, sizeof(double));
-            check_dt = tmax / (double)(P.check_samples - 1);
-            rc = uavqp_ellipsoid_check_grid_device(ctx, r, n, uni, d_seg_offsets, d_times, d_coeff_out, P.check_samples, 0.0, check_dt, grid,
-                                                   chk_r, chk_h, d_fh, nullptr);
-            if (rc != UAVQP_OK) break;
-            hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
-            hipLaunchKernelGGL(uavqp::pipe_hits_kernel, dim3(cgrid), dim3(256), 0, s, n, (const int32_t*)d_fh, P.check_samples, (const uint8_t*)d_roomy, d_flag, d_cnt);
-            rc = read_counters();
-            if (rc != UAVQP_OK) break;
+            check_dt = tmax / (double)(P.check_samples - 1);          // the quotient the check kernel formed from the same bits
+            summary_unsolved = (int)h_cnt->unsolved;
             after = (int)h_cnt->hit;
             if (before < 0) {
                 before = (int)h_cnt->hit;
@@ -348,6 +406,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
             if (h_cnt->hit_repairable == 0 || repairs >= P.repair_rounds) break;
             // halve the boxes of the flagged trajectories towards their waypoints (last round: the waypoint equalities), re-solve
             // warm-started, re-allocate once (the durations only ever stretch) and solve again if that changed anything
+            summary_unsolved = -1;                                     // statuses change below: the summary is counted again
             const double shrink = (repairs + 1 == P.repair_rounds) ? 0.0 : 0.5;
             hipLaunchKernelGGL(uavqp::pipe_shrink_kernel, dim3(n < ctx->num_cus * 32 ? n : ctx->num_cus * 32), dim3(64), 0, s, n, uni, d_seg_offsets,
                                d_waypoints, d_corr_lo, d_corr_hi, (const uint8_t*)d_flag, shrink);
@@ -365,11 +424,14 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
         if (own_grid) (void)uavqp_obstacle_grid_destroy(ctx, own_grid);
         if (rc != UAVQP_OK) return rc;
     }
-    // 5. summary
-    hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
-    hipLaunchKernelGGL(uavqp::pipe_count_kernel, dim3(cgrid), dim3(256), 0, s, (const int32_t*)nullptr, (const int32_t*)d_status_out, n, d_cnt);
-    rc = read_counters();
-    if (rc != UAVQP_OK) return rc;
+    // 5. summary (the last check pass counted the statuses along with its hits unless a repair re-solved something after it)
+    if (summary_unsolved < 0) {
+        hipLaunchKernelGGL(uavqp::pipe_zero_kernel, dim3(1), dim3(64), 0, s, d_cnt);
+        hipLaunchKernelGGL(uavqp::pipe_count_kernel, dim3(cgrid), dim3(256), 0, s, (const int32_t*)nullptr, (const int32_t*)d_status_out, n, d_cnt);
+        rc = read_counters();
+        if (rc != UAVQP_OK) return rc;
+        summary_unsolved = (int)h_cnt->unsolved;
+    }
     UAVQP_HIP(hipGetLastError());
     if (result) {
         result->rounds = rounds;
@@ -378,7 +440,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
         result->colliding_before_repair = before < 0 ? 0 : before;
         result->colliding_with_blocked_waypoints = blocked;
         result->colliding_after = after;
-        result->unsolved = (int32_t)h_cnt->unsolved;
+        result->unsolved = (int32_t)summary_unsolved;
         result->check_dt = check_dt;
     }
     return UAVQP_OK;
