@@ -141,7 +141,12 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *                          ~2.5 k instructions of selects per trip), kept as the independent cross-check of the prelude.  Same result.
  *   cloud_window           1 (default): uavqp_corridor_from_cloud_device sorts rows and points along the cloud's longest axis and scans,
  *                          per block of neighbouring rows, only the points that can still change a box (large clouds, no clearance
- *                          output); 0: always the exhaustive scan.  Identical boxes.
+ *                          output); rows whose distance to the cloud's bounding box already exceeds the cap of the clearance are
+ *                          not scanned at all (an exact bound: Cauchy-Schwarz on the robot ellipsoid's metric); 0: always the
+ *                          exhaustive scan.  2 / 3: the two experiments of round 5 on a 2-D grid over the cloud (rings of cells
+ *                          around a row; a near pass + a far pass over rows bucketed by the radius they still need) -- both measured
+ *                          slower than 1 on BASELINE config 5 (1.23 / 1.25 ms against 0.61 ms per call), kept as cross-checks.
+ *                          Identical boxes with every value.
  *   realloc_dead_band      uavqp_time_reallocate_device stretches only when the limit ratio exceeds this (default 1.01)
  *   realloc_overshoot      ... and then by overshoot * ratio (default 1.02) */
 typedef struct uavqp_settings {
@@ -392,9 +397,13 @@ int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  *   one re-allocation, re-solve if that stretched anything, check again).  A colliding trajectory with an interior waypoint whose box
  *   is degenerate (the cloud leaves no room around the searcher's waypoint) cannot be helped by narrower boxes: counted, not repaired.
  * Loop control is data dependent: the number of trajectories a round stretched travels to the host behind an event (the host waits for
- * the event, not for the stream; while rounds still stretch more than n_traj / 64 trajectories the next round is enqueued before the
- * count is looked at -- a round that turns out to be unnecessary changes no byte); the check and the summary read their counters with a
- * stream synchronisation each, and the call returns with the stream idle (SYNCHRONOUS).
+ * the event, not for the stream; round 1, and later rounds while they still stretch more than n_traj / 64 trajectories, are enqueued
+ * before the previous count is looked at, and so is the extra solve at the cap -- a round that turns out to be unnecessary works on an
+ * empty list and changes no byte).  From the second round on, re-allocation and compaction only visit the trajectories the previous
+ * round re-solved.  The check needs no host round trip of its own: the longest duration stays on the device (the check kernel forms dt
+ * from it), and ONE counter block read after the check carries hits, blocked waypoints, unsolved trajectories and that duration; the
+ * call returns with the stream idle (SYNCHRONOUS).  The check itself does not test samples beyond a trajectory's end more than once
+ * (they all are its end point and could only repeat the first one's verdict at a larger index).
  *   total_segments      sum_b M_b (the host knows it: it sized the buffers); uniform batches: n_traj * uniform_segments
  *   d_times             [total_segments] IN / OUT: stretched in place by the re-allocation (never shrunk)
  *   grid                uniform grid over d_obstacles with cell = check radius + 0.1 (uavqp_obstacle_grid_build_device), or NULL: built

@@ -200,13 +200,16 @@ def test_config5_pipeline_cloud_corridors_then_corridor_solve_and_reallocation(o
     assert n_wide > 50
 
 
-@pytest.mark.parametrize("cell", [0.5, 0.17, 3.0])
-def test_grid_ellipsoid_check_is_identical_to_the_exhaustive_scan(gpu_ctx, cell):
+@pytest.mark.parametrize("cell,ns,dt", [(0.5, 80, 0.06), (0.17, 80, 0.06), (3.0, 80, 0.06), (0.5, 24, 0.3), (0.5, 7, 1.0), (0.17, 150, 0.1)])
+def test_grid_ellipsoid_check_is_identical_to_the_exhaustive_scan(gpu_ctx, cell, ns, dt):
     """uavqp_obstacle_grid_build_device + uavqp_ellipsoid_check_grid_device against uavqp_ellipsoid_check_device (itself
     checked against the restated KinoAstar::isCollisionFree): same candidate set, same arithmetic per candidate, so the
-    flags and first-hit indices must be IDENTICAL -- for the natural cell size (robot_r + 0.1), a finer and a coarser one."""
+    flags and first-hit indices must be IDENTICAL -- for the natural cell size (robot_r + 0.1), a finer and a coarser one; with more and
+    with fewer samples per trajectory than a wave has lanes (several trajectories share a wave: one first_hit update per trajectory and
+    wave), and with time grids that run far past the end of most trajectories (the repeated end-point samples the grid kernel leaves out
+    when no flags are asked for)."""
     import torch
-    r, n, ns, dt = 4, 96, 80, 0.06
+    r, n = 4, 96
     b = W.ragged_batch(5, n, r, m_lo=2, m_hi=14)
     so = b["seg_offsets"]
     obs = W.pillar_cloud(5, n_pillars=120, resolution=0.2)
@@ -227,7 +230,7 @@ def test_grid_ellipsoid_check_is_identical_to_the_exhaustive_scan(gpu_ctx, cell)
         gpu_ctx.synchronize()
         assert torch.equal(f_ex, f_gr) and torch.equal(h_ex, h_gr)
         hits = int(f_ex.sum().item())
-        assert 0.01 * n * ns < hits < 0.9 * n * ns
+        assert 0.01 * n * ns < hits < 0.95 * n * ns
         # without the per-sample flags
         gpu_ctx.ellipsoid_check_grid_device(r, n, 0, d_so, d_T, d_coef, ns, 0.0, dt, grid, ROBOT_R, ROBOT_H, h_gr, None)
         gpu_ctx.synchronize()

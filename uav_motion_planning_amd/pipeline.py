@@ -39,7 +39,17 @@ def corridor_pipeline_device(ctx, r, seg_offsets, waypoints, times, bc, obstacle
                                        max_rounds=int(max_rounds), samples_per_seg=int(samples_per_seg), max_stretch=max_stretch,
                                        check_samples=int(check_samples), repair_rounds=int(repair_rounds), check_robot_r=float(chk[0]),
                                        check_robot_h=float(chk[1]))
-    return dict(coeff=coeff, status=status, corr_lo=lo, corr_hi=hi, first_hit=first_hit, collision_free=first_hit >= check_samples,
-                colliding_before_repair=res["colliding_before_repair"], colliding_with_blocked_waypoints=res["colliding_with_blocked_waypoints"],
-                repairs=res["repairs"], rounds=res["rounds"], still_stretching=res["still_stretching"], check_dt=res["check_dt"],
-                all_solved=res["unsolved"] == 0)
+    return _PipelineResult(coeff=coeff, status=status, corr_lo=lo, corr_hi=hi, first_hit=first_hit, check_samples=int(check_samples),
+                           colliding_before_repair=res["colliding_before_repair"], colliding_with_blocked_waypoints=res["colliding_with_blocked_waypoints"],
+                           repairs=res["repairs"], rounds=res["rounds"], still_stretching=res["still_stretching"], check_dt=res["check_dt"],
+                           all_solved=res["unsolved"] == 0)
+
+
+class _PipelineResult(dict):
+    """The result dict; `collision_free` (first_hit >= check_samples, a torch comparison = one more launch) is formed when it is asked for."""
+
+    def __missing__(self, key):
+        if key == "collision_free":
+            self[key] = self["first_hit"] >= self["check_samples"]
+            return self[key]
+        raise KeyError(key)
