@@ -125,11 +125,17 @@ __device__ __forceinline__ bool corridor_takes_part(const int32_t* only_i32, con
 __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __restrict__ order, int n_traj, const int32_t* __restrict__ only_i32,
                                                              const unsigned char* __restrict__ only_u8, int32_t* __restrict__ out, int* __restrict__ n_out,
                                                              const unsigned int* __restrict__ none_if_zero = nullptr,
-                                                             const int* __restrict__ n_dev = nullptr) {
+                                                             const int* __restrict__ n_dev = nullptr, volatile unsigned long long* host_slot = nullptr,
+                                                             unsigned int host_seq = 0u) {
+    // (host_slot: a word of host-coherent pinned memory that receives (host_seq << 32 | count) in one store -- the pipeline's host loop
+    // polls it for the sequence number of the round: no copy command and no event packet between the kernels of two rounds)
     // (a caller that counted the participating trajectories while it flagged them passes the count: nothing to scan when it is zero --
     // the rows solve, whose prelude usually takes every trajectory and leaves the box phase none)
     if (none_if_zero && *none_if_zero == 0u) {
-        if (threadIdx.x == 0) *n_out = 0;
+        if (threadIdx.x == 0) {
+            *n_out = 0;
+            if (host_slot) { *host_slot = (unsigned long long)host_seq << 32; __threadfence_system(); }
+        }
         return;
     }
     // (n_dev: `order` is itself a compacted list whose length is on the device -- the pipeline's later rounds compact the previous
@@ -173,7 +179,10 @@ __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __re
             if (keep[c]) out[base + __popcll(m[c] & ((1ull << lane) - 1ull))] = bidx[c];
             base += __popcll(m[c]);
         }
-        if (threadIdx.x == 0) *n_out = all;
+        if (threadIdx.x == 0) {
+            *n_out = all;
+            if (host_slot) { *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
+        }
         return;
     }
     int tot = 0;
@@ -209,6 +218,7 @@ __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __re
         int all = 0;
         for (int k = 0; k < 16; ++k) all += s_tot[k];
         *n_out = all;
+        if (host_slot) { *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
     }
 }
 __global__ void corridor_reset_kernel(int32_t* status, int32_t* iters, int n, const int32_t* only_i32, const unsigned char* only_u8) {

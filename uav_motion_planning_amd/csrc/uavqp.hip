@@ -765,7 +765,7 @@ struct uavqp_ctx {
     void* d_pipe = nullptr;
     size_t pipe_bytes = 0;
     void* h_pipe = nullptr;
-    hipEvent_t pipe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // "the counters of round k have landed" (uavqp_pipeline.h: a ring of four, two in flight at most)
+    unsigned int pipe_seq = 0;   // sequence number of the last pipeline round enqueued (uavqp_pipeline.h: tags the count a round reports to the host)
 };
 
 #define UAVQP_HIP(expr)                                                                          \
@@ -904,7 +904,6 @@ extern "C" int uavqp_destroy(uavqp_ctx* ctx) {
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_pipe) (void)hipFree(ctx->d_pipe);
     if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
-    for (int k = 0; k < 4; ++k) if (ctx->pipe_ev[k]) (void)hipEventDestroy(ctx->pipe_ev[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return UAVQP_OK;

@@ -29,6 +29,12 @@ struct PipeCounters {
 };
 static_assert(sizeof(PipeCounters) == 64, "counter block is one 64-byte record");
 
+// one word for the host through a host-coherent page: (seq << 32 | *p), see await_word in the pipeline entry
+__global__ void pipe_probe_kernel(const int32_t* __restrict__ p, volatile unsigned long long* slot, unsigned int seq) {
+    *slot = ((unsigned long long)seq << 32) | (unsigned int)*p;
+    __threadfence_system();
+}
+
 __global__ void pipe_zero_kernel(PipeCounters* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *c = PipeCounters{};
 }
@@ -168,7 +174,11 @@ __global__ __launch_bounds__(64) void pipe_shrink_kernel(int n, int uniform, con
 }  // namespace uavqp
 
 static int ensure_pipe_ws(uavqp_ctx* ctx, size_t bytes) {
-    if (!ctx->h_pipe) UAVQP_HIP(hipHostMalloc(&ctx->h_pipe, 1024, hipHostMallocDefault));   // counter block [0] + the ring of per-round blocks [4..7]
+    // counter block [0] + the ring of per-round words [at 256 bytes]; host-coherent: the device writes a round's word while the stream runs on
+    if (!ctx->h_pipe) {
+        UAVQP_HIP(hipHostMalloc(&ctx->h_pipe, 1024, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(ctx->h_pipe, 0, 1024);
+    }
     if (bytes <= ctx->pipe_bytes) return UAVQP_OK;
     UAVQP_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->d_pipe) UAVQP_HIP(hipFree(ctx->d_pipe));
@@ -218,18 +228,30 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     UAVQP_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int n = n_traj, uni = uniform_segments, mx = uni > 0 ? uni : max_segments;
-    if (uni == 0) {
-        // every workspace below is sized from the caller's total_segments: check it against the last CSR offset on the device before
-        // anything is launched (4 bytes through the pinned page, one synchronisation in a call that has one per round anyway -- ADVICE r3)
-        if (!ctx->h_pipe) { const int rc0 = ensure_pipe_ws(ctx, 256); if (rc0 != UAVQP_OK) return rc0; }
-        int32_t* h_last = (int32_t*)ctx->h_pipe;
-        UAVQP_HIP(hipMemcpyAsync(h_last, d_seg_offsets + n_traj, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        UAVQP_HIP(hipStreamSynchronize(s));
-        if (*h_last != total_segments) {
-            g_last_error = "uavqp_corridor_pipeline_device: total_segments does not match seg_offsets[n_traj]";
-            return UAVQP_ERR_INVALID_ARG;
+    // every workspace below is sized from the caller's total_segments: it is checked against the last CSR offset on the device
+    // before anything that depends on it is launched.  The word travels through the host-coherent page (await_word below) while the
+    // kernels that only look at seg_offsets[0..n] -- the dealing order, the counter reset -- already run.
+    if (!ctx->h_pipe) { const int rc0 = ensure_pipe_ws(ctx, 256); if (rc0 != UAVQP_OK) return rc0; }
+    volatile unsigned long long* const h_words = (volatile unsigned long long*)((char*)ctx->h_pipe + 256);   // [0..3] round counts, [4] this check
+    unsigned long long* d_words = nullptr;
+    UAVQP_HIP(hipHostGetDevicePointer((void**)&d_words, (void*)h_words, 0));
+    auto await_word = [&](int slot, unsigned int want, unsigned int* value) -> int {
+        // (bounded: a device fault would otherwise spin here for ever -- the stream is asked every 65 536 polls)
+        unsigned long long word = h_words[slot];
+        for (long long spin = 0; (unsigned int)(word >> 32) != want; ++spin) {
+            if ((spin & 0xFFFF) == 0xFFFF) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady) { g_last_error = "uavqp_corridor_pipeline_device: the stream failed while a word from the device was awaited"; return UAVQP_ERR_HIP; }
+                if (q == hipSuccess && (unsigned int)(h_words[slot] >> 32) != want) { g_last_error = "uavqp_corridor_pipeline_device: a word from the device never arrived"; return UAVQP_ERR_HIP; }
+            }
+            __builtin_ia32_pause();
+            word = h_words[slot];
         }
-    }
+        *value = (unsigned int)(word & 0xFFFFFFFFull);
+        return UAVQP_OK;
+    };
+    unsigned int probe_seq = 0u;
+    if (uni == 0) hipLaunchKernelGGL(uavqp::pipe_probe_kernel, dim3(1), dim3(1), 0, s, d_seg_offsets + n_traj, (volatile unsigned long long*)(d_words + 4), probe_seq = ++ctx->pipe_seq);
     const int n_rows = total_segments + n_traj;
     const bool checking = P.check_samples > 0;
 
@@ -301,6 +323,16 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     };
 
     hipLaunchKernelGGL(uavqp::pipe_begin_kernel, dim3(d_scale ? (n + 255) / 256 : 1), dim3(256), 0, s, d_scale, n, d_cnt);
+    if (uni == 0) {
+        unsigned int last_offset = 0u;
+        rc = await_word(4, probe_seq, &last_offset);
+        if (rc != UAVQP_OK) return rc;
+        if ((int32_t)last_offset != total_segments) {
+            g_last_error = "uavqp_corridor_pipeline_device: total_segments does not match seg_offsets[n_traj]";
+            (void)hipStreamSynchronize(s);
+            return UAVQP_ERR_INVALID_ARG;
+        }
+    }
     // 1. the reference's equality problem, 2. boxes from the cloud with the attitude of that solve
     rc = uavqp_solve_batch_device(ctx, r, n, uni, mx, d_seg_offsets, d_waypoints, d_times, d_bc, d_coeff_out, d_status_out);
     if (rc != UAVQP_OK) return rc;
@@ -315,9 +347,11 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     int rounds = 0, still = 0;
     bool cap_solve_enqueued = false;
     {
-        for (int k = 0; k < 4; ++k)
-            if (!ctx->pipe_ev[k]) UAVQP_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[k], hipEventDisableTiming));
-        uavqp::PipeCounters* const h_ring = (uavqp::PipeCounters*)ctx->h_pipe + 4;
+        // A round's count reaches the host through a word of pinned, host-coherent memory that the compaction kernel writes itself, tagged
+        // with the round's sequence number: the host polls the word (was: a 4-byte copy + an event per round -- a copy kernel and ~6 us of
+        // idle device behind the event packet, per round).
+        unsigned long long* const d_ring = d_words;
+        unsigned int seq_of[4] = {0u, 0u, 0u, 0u};
         auto enqueue_round = [&](int rnd) -> int {
             int rc_ = corridor_solve(rnd > 0 ? 2 : 0, rnd > 0 ? (const int32_t*)d_changed : nullptr, nullptr, rnd > 0);
             if (rc_ != UAVQP_OK) return rc_;
@@ -332,10 +366,9 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
             // round's counter (was: a zeroing kernel, a counting kernel, and the compaction at the head of the next solve)
             const int nxt = rnd > 0 ? cur_list ^ 1 : cur_list;
             hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, s, rnd > 0 ? d_prev : d_order, n, (const int32_t*)d_changed,
-                               (const unsigned char*)nullptr, d_cp2[nxt], d_na2[nxt], (const unsigned int*)nullptr, d_nprev);
+                               (const unsigned char*)nullptr, d_cp2[nxt], d_na2[nxt], (const unsigned int*)nullptr, d_nprev,
+                               (volatile unsigned long long*)&d_ring[rnd & 3], seq_of[rnd & 3] = ++ctx->pipe_seq);
             cur_list = nxt;
-            UAVQP_HIP(hipMemcpyAsync(&h_ring[rnd & 3].changed, d_na2[nxt], sizeof(int), hipMemcpyDeviceToHost, s));
-            UAVQP_HIP(hipEventRecord(ctx->pipe_ev[rnd & 3], s));
             if (rnd + 1 == P.max_rounds) {
                 // the cap: the trajectories this last re-allocation stretched need one more solve so that their coefficients belong to
                 // d_times -- enqueued behind the compaction without waiting for its count (an empty list solves nobody)
@@ -355,8 +388,8 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
                 ++enq;
             }
             if (exam >= enq) break;
-            UAVQP_HIP(hipEventSynchronize(ctx->pipe_ev[exam & 3]));
-            last = h_ring[exam & 3].changed;
+            rc = await_word(exam & 3, seq_of[exam & 3], &last);
+            if (rc != UAVQP_OK) return rc;
             ++exam;
             ++rounds;
             still = (int)last;
