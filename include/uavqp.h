@@ -396,10 +396,10 @@ int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  *   are halved towards its waypoints -- in the last repair round collapsed onto them: the reference's equality rows --, warm re-solve,
  *   one re-allocation, re-solve if that stretched anything, check again).  A colliding trajectory with an interior waypoint whose box
  *   is degenerate (the cloud leaves no room around the searcher's waypoint) cannot be helped by narrower boxes: counted, not repaired.
- * Loop control is data dependent: the number of trajectories a round stretched travels to the host behind an event (the host waits for
- * the event, not for the stream; round 1, and later rounds while they still stretch more than n_traj / 64 trajectories, are enqueued
- * before the previous count is looked at, and so is the extra solve at the cap -- a round that turns out to be unnecessary works on an
- * empty list and changes no byte).  From the second round on, re-allocation and compaction only visit the trajectories the previous
+ * Loop control is data dependent: the number of trajectories a round stretched reaches the host through a word of pinned,
+ * host-coherent memory that the round's last kernel writes and the host polls (no copy, no event, no stream stop between rounds; round
+ * 1, and later rounds while they still stretch more than n_traj / 64 trajectories, are enqueued before the previous count is looked
+ * at, and so is the extra solve at the cap -- a round that turns out to be unnecessary works on an empty list and changes no byte).  From the second round on, re-allocation and compaction only visit the trajectories the previous
  * round re-solved.  The check needs no host round trip of its own: the longest duration stays on the device (the check kernel forms dt
  * from it), and ONE counter block read after the check carries hits, blocked waypoints, unsolved trajectories and that duration; the
  * call returns with the stream idle (SYNCHRONOUS).  The check itself does not test samples beyond a trajectory's end more than once

@@ -10,9 +10,10 @@
 //
 // The reference has no such loop (constant 1.0 s per segment, test_minimum_jerk.cpp:65-71; every row an equality,
 // minimum_control.cpp:98-125): nothing to mirror, parity is per inner solve (SURVEY.md section 8-a').
-// Loop control is data dependent (did any duration change? does anything still collide?): per round the device sums what the
-// host needs into a 64-byte counter block that is copied to a pinned page -- one small D2H copy and one stream synchronisation per
-// round; everything else stays in device buffers.
+// Loop control is data dependent (did any duration change? does anything still collide?).  Per outer round the host needs ONE number:
+// the compaction kernel writes it, tagged with the round's sequence number, into a word of pinned host-coherent memory that the host
+// polls -- no copy command, no event, no stream stop between rounds.  What the check finds goes into a 64-byte counter block that is
+// copied to the pinned page with the call's one stream synchronisation; everything else stays in device buffers.
 #pragma once
 
 namespace uavqp {
@@ -28,12 +29,6 @@ struct PipeCounters {
     unsigned long long pad2_[3];
 };
 static_assert(sizeof(PipeCounters) == 64, "counter block is one 64-byte record");
-
-// one word for the host through a host-coherent page: (seq << 32 | *p), see await_word in the pipeline entry
-__global__ void pipe_probe_kernel(const int32_t* __restrict__ p, volatile unsigned long long* slot, unsigned int seq) {
-    *slot = ((unsigned long long)seq << 32) | (unsigned int)*p;
-    __threadfence_system();
-}
 
 __global__ void pipe_zero_kernel(PipeCounters* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *c = PipeCounters{};
@@ -236,22 +231,10 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     unsigned long long* d_words = nullptr;
     UAVQP_HIP(hipHostGetDevicePointer((void**)&d_words, (void*)h_words, 0));
     auto await_word = [&](int slot, unsigned int want, unsigned int* value) -> int {
-        // (bounded: a device fault would otherwise spin here for ever -- the stream is asked every 65 536 polls)
-        unsigned long long word = h_words[slot];
-        for (long long spin = 0; (unsigned int)(word >> 32) != want; ++spin) {
-            if ((spin & 0xFFFF) == 0xFFFF) {
-                const hipError_t q = hipStreamQuery(s);
-                if (q != hipSuccess && q != hipErrorNotReady) { g_last_error = "uavqp_corridor_pipeline_device: the stream failed while a word from the device was awaited"; return UAVQP_ERR_HIP; }
-                if (q == hipSuccess && (unsigned int)(h_words[slot] >> 32) != want) { g_last_error = "uavqp_corridor_pipeline_device: a word from the device never arrived"; return UAVQP_ERR_HIP; }
-            }
-            __builtin_ia32_pause();
-            word = h_words[slot];
-        }
-        *value = (unsigned int)(word & 0xFFFFFFFFull);
-        return UAVQP_OK;
+        return await_host_word(s, h_words + slot, want, value, "uavqp_corridor_pipeline_device");
     };
     unsigned int probe_seq = 0u;
-    if (uni == 0) hipLaunchKernelGGL(uavqp::pipe_probe_kernel, dim3(1), dim3(1), 0, s, d_seg_offsets + n_traj, (volatile unsigned long long*)(d_words + 4), probe_seq = ++ctx->pipe_seq);
+    if (uni == 0) hipLaunchKernelGGL(uavqp::host_word_kernel, dim3(1), dim3(1), 0, s, (const int32_t*)(d_seg_offsets + n_traj), (volatile unsigned long long*)(d_words + 4), probe_seq = ++ctx->pipe_seq);
     const int n_rows = total_segments + n_traj;
     const bool checking = P.check_samples > 0;
 
@@ -339,11 +322,11 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     rc = uavqp_corridor_from_cloud_device(ctx, r, n, uni, d_seg_offsets, n_rows, d_waypoints, d_times, d_coeff_out, d_obstacles, n_obs,
                                           P.robot_r, P.robot_h, P.h_max, d_corr_lo, d_corr_hi, nullptr);
     if (rc != UAVQP_OK) return rc;
-    // 3. outer loop.  The host only needs a round's counter to know whether ANOTHER round is due, so it does not stop the stream for it:
-    // the counter block of round k goes to its own pinned slot behind an event, and while the last examined round still stretched
-    // many trajectories (> n / 64) round k + 1 is enqueued before round k's counter is looked at -- if that one then reports zero, the
-    // extra round re-solves nobody and stretches nobody (same bytes everywhere), at the price of a few empty launches.  Was: copy +
-    // stream synchronisation + 25-30 us of idle device per round.
+    // 3. outer loop.  The host only needs a round's count to know whether ANOTHER round is due, so it does not stop the stream for it:
+    // the count of round k arrives in its own word of the host-coherent page (below), and round 1 -- later rounds while the last examined
+    // one still stretched many trajectories (> n / 64) -- is enqueued before the previous count is looked at: if that one then reports
+    // zero, the extra round re-solves nobody and stretches nobody (same bytes everywhere), at the price of a few empty launches.  Was
+    // (round 3): copy + stream synchronisation + 25-30 us of idle device per round.
     int rounds = 0, still = 0;
     bool cap_solve_enqueued = false;
     {
