@@ -848,10 +848,28 @@ def config1_latency():
     for i in range(N):
         ok = to.solve() and ok
     three = (time.perf_counter() - t0) / N
+    # the same three axis calls straight through the C ABI (what a C++ caller of MinimumControl::solve pays: uavqp_solve_axis_host with
+    # prepared pointers; a ctypes call adds about a microsecond) -- tools/ubench/axis_latency.cpp is the version without Python
+    import ctypes
+    lib, ctx = U.lib(), opt._ctx
+    pos = [np.ascontiguousarray(wp[:, ax]) for ax in range(3)]
+    tv, bv, ba, bj = np.ascontiguousarray(T, dtype=np.float64), np.array([0.0, 0.0]), np.zeros(2), np.zeros(2)
+    coef, st = np.zeros(8 * 7), ctypes.c_int32(0)
+    fn = lib.uavqp_solve_axis_host            # (argument types as _lib.py declares them: raw addresses)
+    cargs = [(ctx._h, 4, 7, pos[ax].ctypes.data, bv.ctypes.data, ba.ctypes.data, bj.ctypes.data, tv.ctypes.data, coef.ctypes.data, ctypes.byref(st))
+             for ax in range(3)]
+    for _ in range(20):
+        fn(*cargs[0])
+    t0 = time.perf_counter()
+    for i in range(N):
+        for ax in range(3):
+            ok = (fn(*cargs[ax]) == 0 and st.value == U.UAVQP_SOLVED) and ok
+    c_three = (time.perf_counter() - t0) / N
     return {"workload": "configs[0]: single 8-waypoint / 7-segment 3-axis min-snap QP from host pointers (plumbing)", "all_solved": bool(ok),
             "minimum_control_solve_us_per_axis_call": one * 1e6, "three_axis_calls_us": 3 * one * 1e6,
-            "traj_optimizer_solve_us_three_axes": three * 1e6, "value": 1.0 / three, "unit": "trajectories/s",
-            "note": "wall time per synchronous call incl. H2D / D2H through one pinned page; mean of 300 calls after 20 warm-up calls"}
+            "traj_optimizer_solve_us_three_axes": three * 1e6, "c_abi_three_axis_calls_us": c_three * 1e6, "value": 1.0 / three, "unit": "trajectories/s",
+            "note": "wall time per synchronous call through one pinned, device-mapped page (no copies; completion = a word the device writes "
+                    "into that page, polled); mean of 300 calls after 20 warm-up calls; the first three figures include the numpy facades"}
 
 
 def other_configs(args):
