@@ -441,3 +441,40 @@ def test_pipeline_wave_prelude_against_the_batch_preludes(r, m_hi):
     for tag in ("2", "1"):
         for a, c in zip(out[tag], out["0"]):
             assert np.array_equal(a, c, equal_nan=True) if isinstance(a, np.ndarray) else a == c, tag
+
+
+@pytest.mark.gpu
+def test_pipeline_on_a_batch_beyond_one_compaction_workgroup():
+    """More than 16 384 trajectories: the per-round compaction of the re-solve list runs as several workgroups in two launches
+    (compact_order_blocks_kernel).  Trajectories do not interact in the pipeline (the collision check's common time grid aside: switched
+    off here), so the big batch must reproduce, bit for bit, what its four quarters give when each goes through the pipeline alone
+    (quarters of 10 000: the one-workgroup path) -- a lost or duplicated list entry is a trajectory that misses a re-solve."""
+    import torch
+    from uav_motion_planning_amd import pipeline as P
+    r, n, q = 4, 40000, 10000
+    b = W.ragged_batch(5, n, r, m_lo=2, m_hi=5, seed=77)
+    so = np.asarray(b["seg_offsets"])
+    wp = np.asarray(b["waypoints"]).reshape(-1, 3)
+    T0 = np.asarray(b["times"]).reshape(-1)
+    obs = W.pillar_cloud(5, n_pillars=20, resolution=0.4)
+    dev = torch.device("cuda", 0)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+    def run(lo_b, hi_b):
+        s0, s1 = int(so[lo_b]), int(so[hi_b])
+        so_ = (so[lo_b:hi_b + 1] - s0).astype(np.int32)
+        with U.Context(0) as ctx:
+            d_T = up(T0[s0:s1])
+            res = P.corridor_pipeline_device(ctx, r, up(so_), up(wp[s0 + lo_b:s1 + hi_b]), d_T, up(b["bc"][lo_b:hi_b]), up(obs), max_segments=5,
+                                             check_samples=0)
+            ctx.synchronize()
+            return (res["coeff"].cpu().numpy(), d_T.cpu().numpy(), res["status"].cpu().numpy(), res["corr_lo"].cpu().numpy(),
+                    res["corr_hi"].cpu().numpy(), res["rounds"], res["still_stretching"])
+
+    whole = run(0, n)
+    assert whole[5] >= 3, "the batch needs several rounds for this test to mean anything"
+    parts = [run(k, k + q) for k in range(0, n, q)]
+    for j in range(5):
+        assert np.array_equal(whole[j], np.concatenate([p[j] for p in parts]), equal_nan=True), j
+    assert whole[5] == max(p[5] for p in parts) and whole[6] == sum(p[6] for p in parts if p[5] == whole[5])
+    assert (whole[2] == U.UAVQP_SOLVED).mean() > 0.99

@@ -221,6 +221,76 @@ __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __re
         if (host_slot) { *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
     }
 }
+// The same compaction for lists beyond one workgroup's reach (16 384 entries): block b takes entries [16384 b, 16384 (b + 1)) -- phase 0
+// leaves the number it keeps in block_counts[b], phase 1 (a second launch of the same grid) writes them behind those of the blocks before it.
+// Order preserved; block 0 of phase 1 reports the total.  (one workgroup walked a million flags per pipeline round.)
+constexpr int COMPACT_BLOCK = 16384;
+__global__ __launch_bounds__(1024) void compact_order_blocks_kernel(const int32_t* __restrict__ order, int n_traj, const int32_t* __restrict__ only_i32,
+                                                                    const unsigned char* __restrict__ only_u8, int32_t* __restrict__ out, int* __restrict__ n_out,
+                                                                    const int* __restrict__ n_dev, int* __restrict__ block_counts, int phase,
+                                                                    volatile unsigned long long* host_slot, unsigned int host_seq) {
+    if (n_dev) n_traj = *n_dev;
+    __shared__ int s_tot[16], s_before[16], s_all[16];
+    constexpr int CH = 16;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w0 = (int)blockIdx.x * COMPACT_BLOCK + w * 64 * CH, w1 = min(w0 + 64 * CH, n_traj);
+    int bidx[CH];
+    bool keep[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = w0 + 64 * c + lane;
+        bidx[c] = i < w1 ? (order ? order[i] : i) : -1;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) keep[c] = bidx[c] >= 0 && corridor_takes_part(only_i32, only_u8, bidx[c]);
+    unsigned long long m[CH];
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        m[c] = __ballot(keep[c]);
+        cnt += __popcll(m[c]);
+    }
+    if (lane == 0) s_tot[w] = cnt;
+    if (phase == 1) {
+        // what the blocks before this one keep, and what all keep (the grid has at most 1024 blocks: one count per thread)
+        int before = 0, all = 0;
+        if (threadIdx.x < gridDim.x) {
+            const int v = block_counts[threadIdx.x];
+            all = v;
+            before = (int)threadIdx.x < (int)blockIdx.x ? v : 0;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            before += __shfl_xor(before, d, 64);
+            all += __shfl_xor(all, d, 64);
+        }
+        if (lane == 0) { s_before[w] = before; s_all[w] = all; }
+    }
+    __syncthreads();
+    if (phase == 0) {
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int k = 0; k < 16; ++k) t += s_tot[k];
+            block_counts[blockIdx.x] = t;
+        }
+        return;
+    }
+    int base = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        base += s_before[k] + (k < w ? s_tot[k] : 0);
+        all += s_all[k];
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if (keep[c]) out[base + __popcll(m[c] & ((1ull << lane) - 1ull))] = bidx[c];
+        base += __popcll(m[c]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *n_out = all;
+        if (host_slot) { *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
+    }
+}
 __global__ void corridor_reset_kernel(int32_t* status, int32_t* iters, int n, const int32_t* only_i32, const unsigned char* only_u8) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && corridor_takes_part(only_i32, only_u8, i)) {

@@ -1450,7 +1450,9 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     const bool guess = gmode != 0;     // cold start from a starting set (closed form: prep kernel; dual method: corridor_dual_kernel)
     const size_t b_guess = guess ? align256(sizeof(unsigned long long) * 6 * (size_t)n_traj) : 0;
     const bool masked = d_only_i32 || d_only_u8;
-    const size_t b_compact = masked ? align256(sizeof(int32_t) * (size_t)n_traj) + 256 : 0;   // compacted dealing order + its length
+    // compacted dealing order + its length -- reserved whether this solve is masked or not (4 bytes per trajectory): the first masked solve of a
+    // pipeline call must not grow the workspace, i.e. stop the stream and re-allocate, in the middle of the loop
+    const size_t b_compact = align256(sizeof(int32_t) * (size_t)n_traj) + 256;
     // one lane per trajectory (qp_corridor_lane.h): batches of at most 16 segments per trajectory, G not cached across solves
     const bool lane_prelude = dual && !(d_gcache && gcache_mode != 0) && Mmax - 1 <= uavqp::LANE_NV && ctx->settings.corridor_prelude_lanes == 1;
     long long lgrid = ((long long)n_traj + 63) / 64;

@@ -246,7 +246,10 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     // G of the dual prelude across the rounds (the re-allocation multiplies all durations of a trajectory by one factor: G only rescales)
     const bool g_across = ctx->settings.corridor_initial_guess == 2 && mx - 1 <= 24 && mx >= 2;
     const size_t o_cp = o_or + (deal_by_length ? length_order_bytes(n) : 0);          // compacted dealing order of the next re-solve + its count
-    const size_t o_sc = o_cp + 2 * align256(sizeof(int32_t) * (size_t)n) + 256;       // (two lists: round k compacts round k - 1's into the other one)
+    const int cblocks = (n + uavqp::COMPACT_BLOCK - 1) / uavqp::COMPACT_BLOCK;           // workgroups of a compaction (more than one: two launches)
+    if (cblocks > 1024) { g_last_error = "uavqp_corridor_pipeline_device: more than 16 777 216 trajectories in one call"; return UAVQP_ERR_INVALID_ARG; }
+    // (two lists: round k compacts round k - 1's into the other one; then their two counts and the per-workgroup counts of a large compaction)
+    const size_t o_sc = o_cp + 2 * align256(sizeof(int32_t) * (size_t)n) + 256 + align256(sizeof(int) * (size_t)cblocks);
     const size_t o_gc = o_sc + (g_across ? align256(sizeof(double) * (size_t)n) : 0);
     const size_t need = o_gc + (g_across ? align256(sizeof(double) * (size_t)n * uavqp::corridor_gcache_stride) : 0);
     int rc = ensure_pipe_ws(ctx, need);
@@ -259,6 +262,7 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
     uint64_t* d_active = (uint64_t*)(base + o_as);
     int32_t* const d_cp2[2] = {(int32_t*)(base + o_cp), (int32_t*)(base + o_cp + align256(sizeof(int32_t) * (size_t)n))};
     int* const d_na2[2] = {(int*)(base + o_cp + 2 * align256(sizeof(int32_t) * (size_t)n)), (int*)(base + o_cp + 2 * align256(sizeof(int32_t) * (size_t)n)) + 32};
+    int* const d_cblk = (int*)(base + o_cp + 2 * align256(sizeof(int32_t) * (size_t)n) + 256);
     int cur_list = 0;                                                                  // the list the next re-solve takes
     double* d_scale = g_across ? (double*)(base + o_sc) : nullptr;     // factor by which every trajectory was stretched since its G was stored
     double* d_gcache = g_across ? (double*)(base + o_gc) : nullptr;
@@ -348,9 +352,16 @@ extern "C" int uavqp_corridor_pipeline_device(uavqp_ctx* ctx, int r, int n_traj,
             // the dealing order of the trajectories it stretched, for the re-solve of the next round -- and their number, which is the
             // round's counter (was: a zeroing kernel, a counting kernel, and the compaction at the head of the next solve)
             const int nxt = rnd > 0 ? cur_list ^ 1 : cur_list;
-            hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, s, rnd > 0 ? d_prev : d_order, n, (const int32_t*)d_changed,
-                               (const unsigned char*)nullptr, d_cp2[nxt], d_na2[nxt], (const unsigned int*)nullptr, d_nprev,
-                               (volatile unsigned long long*)&d_ring[rnd & 3], seq_of[rnd & 3] = ++ctx->pipe_seq);
+            seq_of[rnd & 3] = ++ctx->pipe_seq;
+            if (cblocks == 1)
+                hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, s, rnd > 0 ? d_prev : d_order, n, (const int32_t*)d_changed,
+                                   (const unsigned char*)nullptr, d_cp2[nxt], d_na2[nxt], (const unsigned int*)nullptr, d_nprev,
+                                   (volatile unsigned long long*)&d_ring[rnd & 3], seq_of[rnd & 3]);
+            else
+                for (int phase = 0; phase < 2; ++phase)
+                    hipLaunchKernelGGL(uavqp::compact_order_blocks_kernel, dim3(cblocks), dim3(1024), 0, s, rnd > 0 ? d_prev : d_order, n,
+                                       (const int32_t*)d_changed, (const unsigned char*)nullptr, d_cp2[nxt], d_na2[nxt], d_nprev, d_cblk, phase,
+                                       (volatile unsigned long long*)&d_ring[rnd & 3], seq_of[rnd & 3]);
             cur_list = nxt;
             if (rnd + 1 == P.max_rounds) {
                 // the cap: the trajectories this last re-allocation stretched need one more solve so that their coefficients belong to
