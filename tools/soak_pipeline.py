@@ -24,7 +24,9 @@ for it in range(draws):
     r = int(rng.choice([3, 4]))
     m_hi = int(rng.integers(3, 25))
     m_lo = int(rng.integers(1, m_hi + 1))
-    n = int(rng.choice([1, 2, 3, 63, 64, 65, 257, 1000, 4097]))
+    n = int(rng.choice([1, 2, 3, 63, 64, 65, 257, 1000, 4097, 16385, 33000]))      # (beyond 16 384: the compaction of a round in several workgroups)
+    if n > 16384:
+        m_hi = min(m_hi, 6); m_lo = min(m_lo, m_hi)
     b = W.ragged_batch(5, n, r, m_lo=m_lo, m_hi=m_hi, seed=int(rng.integers(1 << 30)))
     so = b["seg_offsets"]
     obs = W.pillar_cloud(5, n_pillars=int(rng.integers(5, 80)), resolution=0.25)
