@@ -11,6 +11,10 @@ for rep in 1 2; do
   for L in "$A" "$B"; do
     rm -rf /tmp/kt_ab
     UAVQP_LIB_PATH=$(realpath $R/$L 2>/dev/null || echo $L) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_ab -o x -- python $R/bench.py "$@" --inner --repeats 1 --cpu-sample 0 > /dev/null 2>&1
-    echo "== $L"; grep -E "$PAT" $(find /tmp/kt_ab -name "*kernel_stats.csv" | head -1) | cut -d, -f1-2,4
+    echo "== $L"; python3 -c "
+import csv, re, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if re.search(sys.argv[2], r['Name']): print('   %-90s calls %4s  avg %10.1f us' % (r['Name'][:90], r['Calls'], float(r['AverageNs']) / 1e3))
+" $(find /tmp/kt_ab -name "*kernel_stats.csv" | head -1) "$PAT" 
   done
 done

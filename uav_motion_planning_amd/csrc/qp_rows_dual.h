@@ -32,7 +32,9 @@ struct RowsDualArgs {
     unsigned char* need_phase1;      // [n_traj]: 1 = not handled here
     unsigned int* n_phase1;          // their number (zeroed by the host)
     const double* gfun;              // [segment][K][2 R]: g_l, g_r of every row (rows_gfun_kernel, launched before this kernel)
-    const double* kd;                // [segment][rows_chain_doubles(R)]: the chain records of rows_chain_kernel (launched before this kernel)
+    const double* kdF;               // the chain records of rows_chain_kernel (launched before this kernel), one array per half, knot-major:
+    const double* kdB;               // half h of knot k of trajectory b at kd_h + (k - 1) * kd_plane + b * rows_chain_half_mem(R)
+    long long kd_plane;
 #ifdef UAVQP_DUAL_DEBUG
     double* dbg;
 #endif
@@ -48,72 +50,119 @@ struct RowsDualArgs {
 #define RD_T(k) do {} while (0)
 #endif
 
-constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 / 2 + 32 * (2 * (R * (R + 1) / 2) + 2 * R * R) + 48 * 2 * R + 34 + 8 + 64; }   // G (lower triangle), chain records (rows_chain_doubles), functionals, durations, masks, int tables
+// G (lower triangle), chain records of knots 1..31 (two halves of rows_chain_half_mem doubles: the DMA's 16-byte pieces), functionals, durations,
+// masks, int tables.  r = 3: 2560 doubles = 20 480 bytes, eight of them are exactly the 160 KB of a CU.
+constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 / 2 + 31 * 2 * ((R * (R + 1) / 2 + R * R + 1) & ~1) + 48 * 2 * R + 34 + 6 + 64; }
 
 // What the prelude needs of the block LDL' chain of a trajectory is the same in all 64 lanes of the wave that solves it (one trajectory
 // per wave: 48 columns): computing it THERE repeats every 3 x 3 recursion 64 times -- a third of the kernel's instructions.
 // rows_chain_kernel computes it once, one LANE per trajectory (forward: S_k^-1 and E_{k-1}; backward: Z_kk = S_k^-1 + E_k Z_{k+1,k+1} E_k' and the
-// last block column Z_kn), and leaves per knot k = 1..M-1 the record {S_k^-1 (lower triangle), E_{k-1}, Z_kk (lower triangle), Z_kn} at
-// kd + (first segment + k - 1) * rows_chain_doubles(R); rows_dual_kernel copies the run of its trajectory into LDS by DMA.
-constexpr int rows_chain_doubles(int R) { return 2 * (R * (R + 1) / 2) + 2 * R * R; }
+// last block column Z_kn).  Per knot k = 1..M-1 a record has two halves, {S_k^-1 (lower triangle), E_{k-1}} and {Z_kk (lower triangle), Z_kn};
+// rows_dual_kernel copies the records of its trajectory into LDS by DMA.
+// Layout in HBM (round 5): two arrays, one per half, KNOT-major -- half h of knot k of trajectory b at kd_h + (k - 1) * plane + b * rows_chain_half_mem(R)
+// -- so that what the 64 lanes of a wave produce for one knot is ONE contiguous run (r = 3: 64 x 128 bytes): the lanes hand their values over
+// through LDS and the wave stores whole lines; a half is padded to 16 bytes so that the prelude's DMA moves it in 16-byte pieces.
+// Was: trajectory-major records, every lane writing its own 16 bytes at a time 3840 bytes from its neighbour's -- each store instruction 64
+// partial lines, read back the same way: the kernel sat at the memory system's request rate (0.54 GB moved, 165-172 us; more waves per SIMD
+// made it slower, asking for its loads a knot ahead changed nothing).  Now 65 us.  (Complete records written trajectory-major by the backward
+// pass, 15 lanes per record: 111 us; halves in knot-major planes but packed, fetched by the prelude dword-wise: prelude + 60 us.)
+constexpr int rows_chain_doubles(int R) { return 2 * (R * (R + 1) / 2) + 2 * R * R; }      // a whole record (the LDS layout of rows_dual_kernel)
+constexpr int rows_chain_half(int R) { return R * (R + 1) / 2 + R * R; }
+constexpr int rows_chain_half_mem(int R) { return (rows_chain_half(R) + 1) & ~1; }         // padded to 16 bytes (r = 3: 16 doubles = one 128-byte line)
 
 template <int R>
-__global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __restrict__ kd) {
-    constexpr int NE = R * (R + 1) / 2, NF = rows_chain_doubles(R);
+__global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __restrict__ kdF, double* __restrict__ kdB, long long plane) {
+    constexpr int NH = rows_chain_half(R), NHM = rows_chain_half_mem(R);
     using Inv = SmallLDL<R>;
-    for (long long bq = (long long)blockIdx.x * 64 + threadIdx.x; bq < a.n_traj; bq += (long long)gridDim.x * 64) {
-        const int b = (int)bq;
-        int s0, M;
-        if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
-        if (!(M >= 2 && M <= 32 && (a.uniform > 0 || M <= a.max_segments))) continue;      // (not a trajectory the prelude takes)
-        const int n = M - 1;
+    __shared__ __attribute__((aligned(16))) double s_t[64 * NHM];
+    const int lane = threadIdx.x;
+    const long long n_waves = ((long long)a.n_traj + 63) / 64;
+    // the wave's rows of one knot: LDS (row = lane) <-> one contiguous run of HBM, 16 bytes per lane and instruction
+    auto rows_out = [&](double* dst, const double (&v)[NH]) __attribute__((always_inline)) {
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < NH; ++q) s_t[lane * NHM + q] = v[q];
+        if (NHM > NH) s_t[lane * NHM + NH] = 0.0;
+        wave_lds_sync();
+#pragma unroll
+        for (int p = 0; p < NHM / 2; ++p) {
+            const int i = p * 64 + lane;
+            *reinterpret_cast<double2_a*>(dst + 2 * i) = *reinterpret_cast<const double2_a*>(s_t + 2 * i);
+        }
+    };
+    auto rows_in = [&](const double* src, double (&v)[NH]) __attribute__((always_inline)) {
+        wave_lds_sync();
+#pragma unroll
+        for (int p = 0; p < NHM / 2; ++p) {
+            const int i = p * 64 + lane;
+            *reinterpret_cast<double2_a*>(s_t + 2 * i) = *reinterpret_cast<const double2_a*>(src + 2 * i);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < NH; ++q) v[q] = s_t[lane * NHM + q];
+    };
+    for (long long wv = blockIdx.x; wv < n_waves; wv += gridDim.x) {
+        const long long b0 = wv * 64;
+        const bool present = b0 + lane < a.n_traj;
+        const int b = present ? (int)(b0 + lane) : 0;
+        int s0 = 0, M = 0;
+        if (present) {
+            if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
+        }
+        const bool taken = present && M >= 2 && M <= 32 && (a.uniform > 0 || M <= a.max_segments);      // (a trajectory the prelude takes)
+        const int n = taken ? M - 1 : 0;
+        int nmax = n;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+
         const double* const T = a.times + s0;
-        double* const out = kd + (size_t)s0 * NF;
         FullBlocks<R> sa;
-        sa.build(T[0]);
+        sa.build(taken ? T[0] : 1.0);
         Inv lprev;
         LDLPack<R>::zero(lprev);
 #pragma unroll 1
-        for (int k = 1; k <= n; ++k) {
-            FullBlocks<R> sb;
-            sb.build(T[k]);
-            double D[R][R], Yp[R][R], Zp[R][R], E[R][R];
+        for (int k = 1; k <= nmax; ++k) {
+            double fw[NH];
 #pragma unroll
-            for (int i = 0; i < R; ++i)
+            for (int q = 0; q < NH; ++q) fw[q] = 0.0;
+            if (k <= n) {
+                FullBlocks<R> sb;
+                sb.build(T[k]);
+                double D[R][R], Yp[R][R], Zp[R][R], E[R][R];
 #pragma unroll
-                for (int q = 0; q < R; ++q) { D[i][q] = sa.B11[i][q] + sb.B00(i, q); E[i][q] = 0.0; }
+                for (int i = 0; i < R; ++i)
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                double col[R];
+                    for (int q = 0; q < R; ++q) { D[i][q] = sa.B11[i][q] + sb.B00(i, q); E[i][q] = 0.0; }
 #pragma unroll
-                for (int i = 0; i < R; ++i) col[i] = sa.B01[i][q];
-                lprev.forward(col);
+                for (int q = 0; q < R; ++q) {
+                    double col[R];
 #pragma unroll
-                for (int i = 0; i < R; ++i) { Yp[i][q] = col[i]; Zp[i][q] = col[i] * lprev.dinv[i]; }
-            }
+                    for (int i = 0; i < R; ++i) col[i] = sa.B01[i][q];
+                    lprev.forward(col);
 #pragma unroll
-            for (int i = 0; i < R; ++i)
+                    for (int i = 0; i < R; ++i) { Yp[i][q] = col[i]; Zp[i][q] = col[i] * lprev.dinv[i]; }
+                }
 #pragma unroll
-                for (int q = 0; q < R; ++q)
+                for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int cc = 0; cc <= i; ++cc) D[i][cc] -= Yp[q][i] * Zp[q][cc];
-            if (k >= 2) {    // E_{k-1} = S_{k-1}^-1 X_{k-1} = L^-T (D^-1 L^-1 X): back-substitution of Zp
+                    for (int q = 0; q < R; ++q)
 #pragma unroll
-                for (int cc = 0; cc < R; ++cc) {
+                        for (int cc = 0; cc <= i; ++cc) D[i][cc] -= Yp[q][i] * Zp[q][cc];
+                if (k >= 2) {    // E_{k-1} = S_{k-1}^-1 X_{k-1} = L^-T (D^-1 L^-1 X): back-substitution of Zp
 #pragma unroll
-                    for (int i = R - 1; i >= 0; --i) {
-                        double v = Zp[i][cc];
+                    for (int cc = 0; cc < R; ++cc) {
 #pragma unroll
-                        for (int q = i + 1; q < R; ++q) v -= lprev.l[q][i] * E[q][cc];
-                        E[i][cc] = v;
+                        for (int i = R - 1; i >= 0; --i) {
+                            double v = Zp[i][cc];
+#pragma unroll
+                            for (int q = i + 1; q < R; ++q) v -= lprev.l[q][i] * E[q][cc];
+                            E[i][cc] = v;
+                        }
                     }
                 }
-            }
-            Inv ldl;
-            ldl.factor(D);
-            double* const rec = out + (size_t)(k - 1) * NF;
-            {
-                double Si[R][R], fw[NE + R * R + 1];
+                Inv ldl;
+                ldl.factor(D);
+                double Si[R][R];
 #pragma unroll
                 for (int cc = 0; cc < R; ++cc) {
                     double col[R];
@@ -132,13 +181,10 @@ __global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __re
                 for (int i = 0; i < R; ++i)
 #pragma unroll
                     for (int cc = 0; cc < R; ++cc) fw[f++] = E[i][cc];
-                // (16-byte stores: the lanes of a wave write records 240 bytes and more apart -- every store instruction is 64 separate pieces)
-#pragma unroll
-                for (int q = 0; q + 1 < NE + R * R; q += 2) *reinterpret_cast<double2_a*>(rec + q) = make_double2(fw[q], fw[q + 1]);
-                if ((NE + R * R) & 1) rec[NE + R * R - 1] = fw[NE + R * R - 1];
+                lprev = ldl;
+                sa = sb;
             }
-            lprev = ldl;
-            sa = sb;
+            rows_out(kdF + (size_t)(k - 1) * plane + (size_t)b0 * NHM, fw);
         }
         double Zk1[R][R], Zkn[R][R], Ek[R][R];
 #pragma unroll
@@ -146,14 +192,13 @@ __global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __re
 #pragma unroll
             for (int q = 0; q < R; ++q) { Zk1[i][q] = 0.0; Zkn[i][q] = 0.0; Ek[i][q] = 0.0; }
 #pragma unroll 1
-        for (int k = n; k >= 1; --k) {
-            double* const rec = out + (size_t)(k - 1) * NF;
-            double Si[R][R], Em[R][R];
-            {
-                double fw[NE + R * R + 1];
+        for (int k = nmax; k >= 1; --k) {
+            double fw[NH], bw[NH];
+            rows_in(kdF + (size_t)(k - 1) * plane + (size_t)b0 * NHM, fw);
 #pragma unroll
-                for (int q = 0; q + 1 < NE + R * R; q += 2) { const double2 t2 = *reinterpret_cast<const double2_a*>(rec + q); fw[q] = t2.x; fw[q + 1] = t2.y; }
-                if ((NE + R * R) & 1) fw[NE + R * R - 1] = rec[NE + R * R - 1];
+            for (int q = 0; q < NH; ++q) bw[q] = 0.0;
+            if (k <= n) {
+                double Si[R][R], Em[R][R];
                 int f = 0;
 #pragma unroll
                 for (int i = 0; i < R; ++i)
@@ -163,48 +208,44 @@ __global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __re
                 for (int i = 0; i < R; ++i)
 #pragma unroll
                     for (int q = 0; q < R; ++q) Em[i][q] = fw[f++];
-            }
-            double P[R][R], Zkk[R][R];
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int q = 0; q < R; ++q) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int p = 0; p < R; ++p) t += Ek[i][p] * Zk1[p][q];
-                    P[i][q] = t;
-                }
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int q = 0; q <= i; ++q) {
-                    double t = Si[i][q];
-#pragma unroll
-                    for (int p = 0; p < R; ++p) t += P[i][p] * Ek[q][p];
-                    Zkk[i][q] = t;
-                    Zkk[q][i] = t;
-                }
-            {
-                const double dn = (k == n) ? 1.0 : 0.0;
-                double Zn[R][R];
+                double P[R][R], Zkk[R][R];
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
                     for (int q = 0; q < R; ++q) {
-                        double t = dn * Zkk[i][q];
+                        double t = 0.0;
 #pragma unroll
-                        for (int p = 0; p < R; ++p) t -= Ek[i][p] * Zkn[p][q];
-                        Zn[i][q] = t;
+                        for (int p = 0; p < R; ++p) t += Ek[i][p] * Zk1[p][q];
+                        P[i][q] = t;
                     }
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q < R; ++q) Zkn[i][q] = Zn[i][q];
-            }
-            {
-                constexpr int F0 = NE + R * R;
-                double bw[NE + R * R + 1];
-                int f = 0;
+                    for (int q = 0; q <= i; ++q) {
+                        double t = Si[i][q];
+#pragma unroll
+                        for (int p = 0; p < R; ++p) t += P[i][p] * Ek[q][p];
+                        Zkk[i][q] = t;
+                        Zkk[q][i] = t;
+                    }
+                {
+                    const double dn = (k == n) ? 1.0 : 0.0;
+                    double Zn[R][R];
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int q = 0; q < R; ++q) {
+                            double t = dn * Zkk[i][q];
+#pragma unroll
+                            for (int p = 0; p < R; ++p) t -= Ek[i][p] * Zkn[p][q];
+                            Zn[i][q] = t;
+                        }
+#pragma unroll
+                    for (int i = 0; i < R; ++i)
+#pragma unroll
+                        for (int q = 0; q < R; ++q) Zkn[i][q] = Zn[i][q];
+                }
+                f = 0;
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -213,15 +254,12 @@ __global__ __launch_bounds__(64) void rows_chain_kernel(RowsArgs a, double* __re
                 for (int i = 0; i < R; ++i)
 #pragma unroll
                     for (int q = 0; q < R; ++q) bw[f++] = Zkn[i][q];
-                if (F0 & 1) rec[F0] = bw[0];
 #pragma unroll
-                for (int q = (F0 & 1); q + 1 < NE + R * R + (F0 & 1) && q + 1 < NE + R * R; q += 2) *reinterpret_cast<double2_a*>(rec + F0 + q) = make_double2(bw[q], bw[q + 1]);
-                if (!(F0 & 1) && ((NE + R * R) & 1)) rec[F0 + NE + R * R - 1] = bw[NE + R * R - 1];
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int q = 0; q < R; ++q) { Zk1[i][q] = Zkk[i][q]; Ek[i][q] = Em[i][q]; }
             }
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-#pragma unroll
-                for (int q = 0; q < R; ++q) { Zk1[i][q] = Zkk[i][q]; Ek[i][q] = Em[i][q]; }
+            rows_out(kdB + (size_t)(k - 1) * plane + (size_t)b0 * NHM, bw);
         }
     }
 }
@@ -232,8 +270,8 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
     // G is symmetric: only its lower triangle is kept (entry (i, c) at max (max + 1) / 2 + min; 9.4 KB instead of 18.8), next to the chain
     // records -- 16.4 KB per wave in all, so that the register file (256 VGPRs: two waves per SIMD), not LDS, sets the 8 waves per CU.
     // (First version: full rows with the records aliased underneath, 22 KB: 7 waves per CU, one SIMD of four with a single wave.)
-    constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, RS = rows_chain_doubles(R);
-    constexpr int O_ER = NRW * (NRW + 1) / 2, O_GF = O_ER + 32 * RS, O_TB = O_GF + NRW * 2 * R, O_MK = O_TB + 34, O_IT = O_MK + 8;
+    constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, HB = rows_chain_half_mem(R), RS = 2 * HB;    // (record in LDS: the second half starts at HB)
+    constexpr int O_ER = NRW * (NRW + 1) / 2, O_GF = O_ER + 31 * RS, O_TB = O_GF + NRW * 2 * R, O_MK = O_TB + 34, O_IT = O_MK + 6;
     static_assert(O_ER % 2 == 0 && O_GF % 2 == 0 && O_TB % 2 == 0 && O_IT % 2 == 0, "16-byte functionals, 8-byte tables on even offsets");
     __shared__ __attribute__((aligned(16))) double sg[rows_dual_lds_doubles(R)];
     const int lane = threadIdx.x, c = lane;
@@ -261,11 +299,16 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         // the chain records of this trajectory (rows_chain_kernel): HBM -> LDS by DMA, 16 bytes per lane and instruction; they land while the
         // functionals are prepared
         {
-            const double* const src = aa.kd + (size_t)s0 * RS;
+            // (16-byte piece pp of the trajectory's n records = piece `w` of knot kk + 1: the first HB / 2 of a record come from the array of
+            // the forward halves, the others from that of the backward halves)
             const int pieces = n * (RS / 2);
             for (int p0 = 0; p0 < pieces; p0 += 64) {
                 const int pp = p0 + lane;
-                if (pp < pieces) __builtin_amdgcn_global_load_lds((gas_ptr)(src + 2 * pp), (las_ptr)(sg + O_ER + 2 * p0), 16, 0, 0);
+                if (pp < pieces) {
+                    const int kk = pp / (RS / 2), w = pp - kk * (RS / 2), hf = w >= HB / 2 ? 1 : 0;
+                    const double* const src = (hf ? aa.kdB : aa.kdF) + (size_t)kk * aa.kd_plane + (size_t)b * HB + 2 * (w - hf * (HB / 2));
+                    __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(sg + O_ER + 2 * p0), 16, 0, 0);
+                }
             }
         }
         // ---------------- lane s prepares segment s: the functionals of its rows ----------------
@@ -396,11 +439,11 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q <= i; ++q) { Si[i][q] = o.Si[f]; Si[q][i] = o.Si[f]; Zkk[i][q] = rec[NE + R * R + f]; Zkk[q][i] = Zkk[i][q]; ++f; }
+                    for (int q = 0; q <= i; ++q) { Si[i][q] = o.Si[f]; Si[q][i] = o.Si[f]; Zkk[i][q] = rec[HB + f]; Zkk[q][i] = Zkk[i][q]; ++f; }
 #pragma unroll
                 for (int i = 0; i < R; ++i)
 #pragma unroll
-                    for (int q = 0; q < R; ++q) Zkn[i][q] = rec[2 * NE + R * R + i * R + q];
+                    for (int q = 0; q < R; ++q) Zkn[i][q] = rec[HB + NE + i * R + q];
             }
             lds_publish();
             // this lane's column

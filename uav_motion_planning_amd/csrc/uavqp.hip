@@ -1705,7 +1705,10 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     if (prelude) {
         const size_t b_wr = align256(sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_), b_np = align256((size_t)n_traj);
         const size_t b_gf = align256(sizeof(double) * (size_t)(rows - n_traj) * K_ * 2 * r);     // row functionals: made here, used by the prelude AND the rows kernel
-        const size_t b_kd = align256(sizeof(double) * (size_t)(rows - n_traj) * uavqp::rows_chain_doubles(r));   // chain records per segment (rows_chain_kernel)
+        // chain records (rows_chain_kernel): two halves, knot-major planes of n_traj (padded to whole waves) rows each, knots 1 .. Mmax - 1 <= 31
+        const int kd_planes = Mmax - 1 < 1 ? 1 : (Mmax - 1 > 31 ? 31 : Mmax - 1);
+        const long long kd_plane = ((long long)n_traj + 63) / 64 * 64 * uavqp::rows_chain_half_mem(r);
+        const size_t b_kd = 2 * align256(sizeof(double) * (size_t)kd_planes * (size_t)kd_plane);
         const size_t b_cp = align256(sizeof(int32_t) * (size_t)n_traj) + 256;     // compacted order of the box phase + its count
         const size_t need = b_wr + b_np + 256 + b_gf + b_kd + b_cp;
         if (need > ctx->rows_warm2_bytes) {
@@ -1744,12 +1747,12 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         da.r.corr_lo = d_corr_lo; da.r.corr_hi = d_corr_hi; da.r.row_tau = d_row_tau; da.r.row_deriv = d_row_deriv; da.r.row_lo = d_row_lo; da.r.row_hi = d_row_hi;
         da.order = nullptr;
         da.warm_box = (unsigned long long*)ctx->rows_warm; da.warm_rows = d_warm_rows; da.need_phase1 = d_need_phase1; da.gfun = d_gfun_pre;
-        da.kd = d_kd; da.n_phase1 = d_n_phase1;
+        da.kdF = d_kd; da.kdB = (const double*)((const char*)d_kd + b_kd / 2); da.kd_plane = kd_plane; da.n_phase1 = d_n_phase1;
         {   // the chain of every trajectory once, one lane each (the prelude's waves would each repeat it in 64 lanes)
             long long cg = ((long long)n_traj + 63) / 64;
             if (cg > (long long)ctx->num_cus * 16) cg = (long long)ctx->num_cus * 16;
-            if (r == 3) hipLaunchKernelGGL((uavqp::rows_chain_kernel<3>), dim3((unsigned)cg), dim3(64), 0, ctx->stream, da.r, d_kd);
-            else hipLaunchKernelGGL((uavqp::rows_chain_kernel<4>), dim3((unsigned)cg), dim3(64), 0, ctx->stream, da.r, d_kd);
+            if (r == 3) hipLaunchKernelGGL((uavqp::rows_chain_kernel<3>), dim3((unsigned)cg), dim3(64), 0, ctx->stream, da.r, d_kd, (double*)((char*)d_kd + b_kd / 2), kd_plane);
+            else hipLaunchKernelGGL((uavqp::rows_chain_kernel<4>), dim3((unsigned)cg), dim3(64), 0, ctx->stream, da.r, d_kd, (double*)((char*)d_kd + b_kd / 2), kd_plane);
         }
 #ifdef UAVQP_DUAL_DEBUG
         {
