@@ -106,7 +106,15 @@ def test_bench_defaults_follow_the_contract():
     assert re.search(r'"--batch", type=int, default=0', src) and "if args.batch > 0 else (4096 if args.config == 2 else 65536)" in src and re.search(r'"--segments", type=int, default=8', src)
     assert re.search(r'"--config", type=int, default=2', src)      # BASELINE.json configs[1]: the configuration the metric is quoted on
     assert re.search(r'"--order", type=int, default=4', src)
-    assert "oracle" not in re.sub(r"def cpu_baseline.*?\n\n\n", "", src, flags=re.S).replace("oracle/osqp_port.c", "")  # oracle only in cpu_baseline
+    # the oracle is a checker: imported only inside cpu_baseline* / parity_* (function-local imports), and run() calls those only after
+    # the timed K-step block (the loop that fills `evt`)
+    rest = re.sub(r"def (cpu_baseline|parity_)\w*\(.*?\n\n\n", "", src, flags=re.S)
+    assert not re.search(r"^\s*(from oracle|import oracle)", rest, flags=re.M)
+    body = src[src.index("def run(args):"):]
+    timed_end = body.index("evt.append(e0.elapsed_time(e1) * 1e-3)")
+    for call in ("cpu_baseline(", "cpu_baseline_corridor(", "parity_exact(", "parity_certificate("):
+        assert call in body and body.index(call) > timed_end, call
+    assert '"parity": parity' in src and 'out[key]["parity"] = rec.get("parity")' in src
 
 
 def test_bench_spawns_its_ranks_and_appends_the_other_configs():

@@ -21,43 +21,15 @@ BIG = 1e300
 
 
 def mono_row(r, M, seg, t, d):
-    """Row of the reference formulation: p_seg^(d)(t) on the 2r M monomial coefficients (ascending powers)."""
-    a = np.zeros(2 * r * M)
-    for k in range(d, 2 * r):
-        a[2 * r * seg + k] = math.prod(range(k - d + 1, k + 1)) * t ** (k - d)
-    return a
+    from oracle.certificates import mono_row as f
+    return f(r, M, seg, t, d)
 
 
 def kkt_certificate_rows(oracle, r, M, T, coef, pos, bcs, bce, lo, hi, rows):
-    """rows: list of (segment, tau, d, lo, hi).  Returns (primal violation, stationarity residual, complementarity violation)."""
-    P, A = oracle.assemble(r, T)
-    l, u = oracle.bounds(r, pos, bcs, bce)
-    l, u = l.copy(), u.copy()
-    wrows = [r + (r + 1) * i for i in range(M - 1)]
-    if lo is not None:
-        l[wrows] = lo
-        u[wrows] = hi
-    extra = [mono_row(r, M, s, tau * T[s], d) for (s, tau, d, _, _) in rows]
-    if extra:
-        A = np.vstack([A, np.array(extra)])
-        l = np.r_[l, [x[3] for x in rows]]
-        u = np.r_[u, [x[4] for x in rows]]
-    x = coef
-    Ax = A @ x
-    scale = max(1.0, np.max(np.abs(Ax)))
-    prim = max(np.max(l - Ax), np.max(Ax - u), 0.0) / scale
-    at_lo = np.abs(Ax - l) < 1e-8 * scale
-    at_hi = np.abs(Ax - u) < 1e-8 * scale
-    act = at_lo | at_hi
-    nu, *_ = np.linalg.lstsq(A[act].T, -(P @ x), rcond=None)     # multipliers live on the active rows only
-    stat = np.max(np.abs(P @ x + A[act].T @ nu)) / max(1.0, np.max(np.abs(P @ x)))
-    comp, nscale = 0.0, max(1e-300, np.max(np.abs(nu)))
-    for v, lo_, hi_ in zip(nu, at_lo[act] & ~at_hi[act], at_hi[act] & ~at_lo[act]):
-        if lo_:
-            comp = max(comp, v / nscale)         # P x + A' nu = 0: nu <= 0 at a lower bound
-        elif hi_:
-            comp = max(comp, -v / nscale)
-    return prim, stat, comp
+    """rows: list of (segment, tau, d, lo, hi).  Returns (primal violation, stationarity residual, complementarity violation):
+    oracle/certificates.py (shared with bench.py's `parity` record)."""
+    from oracle.certificates import kkt_certificate_rows as cert
+    return cert(r, M, T, coef, pos, bcs, bce, lo, hi, rows)
 
 
 def run_rows(ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, uniform):

@@ -186,6 +186,12 @@ def lib():
     return L
 
 
+def has_experiments():
+    """True when libuavqp.so was built with -DUAVQP_EXPERIMENTS (`make -C csrc experiments`): the measured-slower cross-check kernels of
+    cloud_grid2d.h (cloud_window = 2 / 3) and qp_corridor_lane.h (corridor_prelude_lanes = 1) exist; the default build refuses those settings."""
+    return b"experiments" in lib().uavqp_version()
+
+
 def check(rc, what):
     if rc != UAVQP_OK:
         msg = lib().uavqp_last_error().decode() if rc in (UAVQP_ERR_HIP, UAVQP_ERR_NO_DEVICE, UAVQP_ERR_RCCL, UAVQP_ERR_INVALID_ARG) else ""

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __re
     if (none_if_zero && *none_if_zero == 0u) {
         if (threadIdx.x == 0) {
             *n_out = 0;
-            if (host_slot) { *host_slot = (unsigned long long)host_seq << 32; __threadfence_system(); }
+            if (host_slot) { __threadfence_system(); *host_slot = (unsigned long long)host_seq << 32; __threadfence_system(); }
         }
         return;
     }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __re
         }
         if (threadIdx.x == 0) {
             *n_out = all;
-            if (host_slot) { *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
+            if (host_slot) { __threadfence_system(); *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
         }
         return;
     }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __re
         int all = 0;
         for (int k = 0; k < 16; ++k) all += s_tot[k];
         *n_out = all;
-        if (host_slot) { *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
+        if (host_slot) { __threadfence_system(); *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
     }
 }
 // The same compaction for lists beyond one workgroup's reach (16 384 entries): block b takes entries [16384 b, 16384 (b + 1)) -- phase 0
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(1024) void compact_order_blocks_kernel(const int32_
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *n_out = all;
-        if (host_slot) { *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
+        if (host_slot) { __threadfence_system(); *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
     }
 }
 __global__ void corridor_reset_kernel(int32_t* status, int32_t* iters, int n, const int32_t* only_i32, const unsigned char* only_u8) {

@@ -739,7 +739,7 @@ __global__ __launch_bounds__(64, 1) void rows_solve_kernel(RowsArgs a) {
 #pragma unroll
                 for (int c = 0; c < R; ++c) o[c] = Wf(k, F_Y + c);
             }
-            if (capped) atomicMin(&a.status[b], (int32_t)fail);      // (UAVQP_PRIMAL_INFEASIBLE < UAVQP_MAX_ITER_REACHED: an infeasible axis decides the trajectory)
+            if (capped) atomicMin(&a.status[b], (int32_t)(fail != 0 ? fail : (int)UAVQP_MAX_ITER_REACHED));      // (UAVQP_PRIMAL_INFEASIBLE < UAVQP_MAX_ITER_REACHED: an infeasible axis decides the trajectory; 0 is no status)
 #ifdef UAVQP_ROWS_REASON
             if (capped) it += 1000 * reason;
 #endif

@@ -969,7 +969,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 }
             }
             if (!isR) {
-                if (capped) atomicMin(&a.status[b], (int32_t)fail);     // (UAVQP_PRIMAL_INFEASIBLE < UAVQP_MAX_ITER_REACHED: an infeasible axis decides)
+                if (capped) atomicMin(&a.status[b], (int32_t)(fail != 0 ? fail : (int)UAVQP_MAX_ITER_REACHED));     // (UAVQP_PRIMAL_INFEASIBLE < UAVQP_MAX_ITER_REACHED: an infeasible axis decides; 0 is no status: a capped path that set no verdict reads "undecided")
                 if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
                 if (a.active) {
                     unsigned long long* o = a.active + (size_t)g * (2 + 2 * K);

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -700,8 +701,11 @@ __global__ __launch_bounds__(64) void realloc_kernel(ReallocArgs a) {
 #include "qp_rows2.h"
 #include "qp_rows_dual.h"
 #include "obstacle_grid.h"
+// Measured-slower alternatives kept as bit-identical cross-checks: `make experiments` (-DUAVQP_EXPERIMENTS) only
+#ifdef UAVQP_EXPERIMENTS
 #include "cloud_grid2d.h"
 #include "qp_corridor_lane.h"
+#endif
 
 namespace uavqp {
 // Specialised (R, M) instantiations of the register-resident kernel; everything else takes the generic one.
@@ -725,8 +729,12 @@ static twisted_fn find_twisted(int r, int M, int tile) {
 
 namespace uavqp {
 // "everything before me on this stream is done": (seq << 32 | *value) into a word of host-coherent pinned memory (value may be null)
+// Release side of the hand-over: the system-scope fence BEFORE the store orders everything this stream wrote before the kernel boundary
+// (coefficients, statuses: visible to this kernel) ahead of the word; the one behind it pushes the word itself out.
 __global__ void host_word_kernel(const int32_t* __restrict__ value, volatile unsigned long long* slot, unsigned int seq) {
-    *slot = ((unsigned long long)seq << 32) | (value ? (unsigned int)*value : 0u);
+    const unsigned int v = value ? (unsigned int)*value : 0u;
+    __threadfence_system();
+    *slot = ((unsigned long long)seq << 32) | v;
     __threadfence_system();
 }
 }  // namespace uavqp
@@ -742,6 +750,13 @@ static thread_local std::string g_last_error;
 // upper half is the sequence number awaited.  Bounded: every 65 536 polls the stream is asked -- a failed stream, an idle stream without
 // the word, or 60 s without either end the wait.  (Against hipStreamSynchronize / an event: no packet in the stream, and the host
 // reacts within the PCIe latency of the store instead of the runtime's wake-up: 17.8 -> 14.6 us for a one-trajectory call.)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
 static int await_host_word(hipStream_t s, volatile unsigned long long* w, unsigned int want, unsigned int* value, const char* who) {
     unsigned long long word = *w;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -751,12 +766,24 @@ static int await_host_word(hipStream_t s, volatile unsigned long long* w, unsign
             const char* what = nullptr;
             if (q != hipSuccess && q != hipErrorNotReady) what = ": the stream failed while a word from the device was awaited";
             else if (q == hipSuccess && (unsigned int)(*w >> 32) != want) what = ": a word from the device never arrived";
-            else if (std::chrono::steady_clock::now() - t_begin > std::chrono::seconds(60)) what = ": no word from the device within 60 s";
-            if (what) { g_last_error = std::string(who) + what; return UAVQP_ERR_HIP; }
+            else if (std::chrono::steady_clock::now() - t_begin > std::chrono::seconds(60)) {
+                // a long queue in front of the call (a user stream, a very large batch) is not an error: stop polling, wait for the stream the
+                // ordinary way -- nothing of this call may still be running against the caller's buffers when the call returns
+                const hipError_t e = hipStreamSynchronize(s);
+                word = *w;
+                if (e == hipSuccess && (unsigned int)(word >> 32) == want) break;
+                what = e == hipSuccess ? ": a word from the device never arrived" : ": the stream failed while a word from the device was awaited";
+            }
+            if (what) {
+                (void)hipStreamSynchronize(s);   // (error path: no kernel of this call may outlive it)
+                g_last_error = std::string(who) + what;
+                return UAVQP_ERR_HIP;
+            }
         }
-        __builtin_ia32_pause();
+        cpu_relax();
         word = *w;
     }
+    std::atomic_thread_fence(std::memory_order_acquire);   // acquire side: the page's payload is read only after the word
     if (value) *value = (unsigned int)(word & 0xFFFFFFFFull);
     return UAVQP_OK;
 }
@@ -812,7 +839,12 @@ struct uavqp_ctx {
 #ifndef UAVQP_SRC_HASH
 #define UAVQP_SRC_HASH "unknown"
 #endif
-extern "C" const char* uavqp_version(void) { return "uavqp 0.5.0 (gfx950, float64, src " UAVQP_SRC_HASH ")"; }
+#ifdef UAVQP_EXPERIMENTS
+#define UAVQP_BUILD_TAG ", experiments"
+#else
+#define UAVQP_BUILD_TAG ""
+#endif
+extern "C" const char* uavqp_version(void) { return "uavqp 0.6.0 (gfx950, float64, src " UAVQP_SRC_HASH UAVQP_BUILD_TAG ")"; }
 
 extern "C" void uavqp_default_settings(uavqp_settings* out) {
     if (!out) return;
@@ -843,15 +875,25 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
         !(st->realloc_overshoot < INFINITY) || st->corridor_pdas_rounds < 0 || st->corridor_pdas_rounds > 64 || st->corridor_pdas_rounds_warm < 0 || st->corridor_pdas_rounds_warm > 64 ||
         (st->generic_lanes_per_traj != 0 && st->generic_lanes_per_traj != 1 && st->generic_lanes_per_traj != 2 && st->generic_lanes_per_traj != 3) || st->generic_waves_per_cu < 0 ||
         st->generic_waves_per_cu > 32 || st->rows_lanes_per_problem < 0 || st->rows_lanes_per_problem > 2 ||
-        (st->corridor_prelude_lanes != 0 && st->corridor_prelude_lanes != 1 && st->corridor_prelude_lanes != 8))
+        false)
         return UAVQP_ERR_INVALID_ARG;
+#ifndef UAVQP_EXPERIMENTS
+    // the experimental paths (cloud_window 2 / 3: cloud_grid2d.h; corridor_prelude_lanes 1: qp_corridor_lane.h) exist in `make experiments` builds only
+    if (st->cloud_window == 2 || st->cloud_window == 3 || st->corridor_prelude_lanes == 1) {
+        g_last_error = "uavqp_set_settings: cloud_window 2 / 3 and corridor_prelude_lanes 1 select experimental kernels; this library was built without -DUAVQP_EXPERIMENTS";
+        return UAVQP_ERR_INVALID_ARG;
+    }
+#endif
     const int rc = apply_variant(ctx, st->kernel_variant);
     if (rc != UAVQP_OK) return rc;
     ctx->settings = *st;
     ctx->settings.warm_start = st->warm_start ? 1 : 0;
     ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
     ctx->settings.corridor_initial_guess = st->corridor_initial_guess < 0 ? 0 : (st->corridor_initial_guess > 2 ? 2 : st->corridor_initial_guess);
-    ctx->settings.cloud_window = st->cloud_window < 0 ? 0 : (st->cloud_window > 3 ? 3 : st->cloud_window);
+    // (cloud_window: any value outside 0..3 means "on" = 1, as before round 5; corridor_prelude_lanes sits in what used to be padding: a value
+    //  that is none of 0 / 1 / 8 -- a struct filled field by field without uavqp_default_settings -- is taken as the default, not refused)
+    ctx->settings.cloud_window = (st->cloud_window >= 0 && st->cloud_window <= 3) ? st->cloud_window : 1;
+    ctx->settings.corridor_prelude_lanes = (st->corridor_prelude_lanes == 1 || st->corridor_prelude_lanes == 8) ? st->corridor_prelude_lanes : 0;
     ctx->settings.corridor_tail_shape = st->corridor_tail_shape ? 1 : 0;
     return UAVQP_OK;
 }
@@ -1131,6 +1173,7 @@ static int ensure_stage(uavqp_ctx* ctx, size_t bytes) {
 
 
 // the pinned, device-mapped staging page of the latency paths (single-axis entry point, small host batches)
+static constexpr size_t MAPPED_HEAD = 256;   // head of the mapped page: the completion word of the polled host entries
 static int ensure_mapped(uavqp_ctx* ctx, size_t need) {
     if (need <= ctx->axis_bytes) return UAVQP_OK;
     UAVQP_HIP(hipStreamSynchronize(ctx->stream));
@@ -1179,10 +1222,10 @@ extern "C" int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uni
     // trajectory: 72 -> 3x us per call).
     const size_t b_all = b_off + b_wp + b_t + b_bc + b_out + b_st;
     if (b_all <= 256 * 1024) {
-        int rcm = ensure_mapped(ctx, b_all + 256);
+        int rcm = ensure_mapped(ctx, b_all + MAPPED_HEAD);
         if (rcm != UAVQP_OK) return rcm;
-        char* hb = (char*)ctx->h_axis;
-        char* db = (char*)ctx->d_axis;
+        char* hb = (char*)ctx->h_axis + MAPPED_HEAD;   // (the page's first 256 bytes hold the completion word: a FIXED slot no payload ever aliases)
+        char* db = (char*)ctx->d_axis + MAPPED_HEAD;
         if (uniform_segments == 0) std::memcpy(hb, seg_offsets, sizeof(int32_t) * (size_t)(n_traj + 1));
         std::memcpy(hb + b_off, waypoints, sizeof(double) * 3 * (size_t)(total_seg + n_traj));
         std::memcpy(hb + b_off + b_wp, times, sizeof(double) * (size_t)total_seg);
@@ -1195,8 +1238,11 @@ extern "C" int uavqp_solve_batch_host(uavqp_ctx* ctx, int r, int n_traj, int uni
         if (rcm != UAVQP_OK) return rcm;
         {   // (no stream synchronisation: see uavqp_solve_axis_host)
             const unsigned int seq = ++ctx->pipe_seq;
-            hipLaunchKernelGGL(uavqp::host_word_kernel, dim3(1), dim3(1), 0, ctx->stream, (const int32_t*)nullptr, (volatile unsigned long long*)(db + b_all), seq);
-            rcm = await_host_word(ctx->stream, (volatile unsigned long long*)(hb + b_all), seq, nullptr, "uavqp_solve_batch_host");
+            volatile unsigned long long* h_word = (volatile unsigned long long*)ctx->h_axis;
+            *h_word = 0ull;
+            std::atomic_thread_fence(std::memory_order_release);
+            hipLaunchKernelGGL(uavqp::host_word_kernel, dim3(1), dim3(1), 0, ctx->stream, (const int32_t*)nullptr, (volatile unsigned long long*)ctx->d_axis, seq);
+            rcm = await_host_word(ctx->stream, h_word, seq, nullptr, "uavqp_solve_batch_host");
             if (rcm != UAVQP_OK) return rcm;
         }
         std::memcpy(coeff_out, hb + b_off + b_wp + b_t + b_bc, sizeof(double) * 3 * 2 * r * (size_t)total_seg);
@@ -1244,14 +1290,14 @@ extern "C" int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const dou
     const size_t o_bc = o_t + align256(sizeof(double) * (size_t)n_seg);
     const size_t o_out = o_bc + align256(sizeof(double) * 2 * 3 * 3);
     const size_t o_st = o_out + align256(sizeof(double) * 3 * (size_t)nc * n_seg);
-    const size_t need = o_st + 256;
+    const size_t need = o_st + 256 + MAPPED_HEAD;
     UAVQP_HIP(hipSetDevice(ctx->device));
     {
         const int rcm = ensure_mapped(ctx, need);
         if (rcm != UAVQP_OK) return rcm;
     }
-    char* hb = (char*)ctx->h_axis;
-    char* db = (char*)ctx->d_axis;
+    char* hb = (char*)ctx->h_axis + MAPPED_HEAD;   // (completion word: the fixed slot at the head of the page)
+    char* db = (char*)ctx->d_axis + MAPPED_HEAD;
     double* wp = (double*)(hb + o_wp);
     for (int i = 0; i <= n_seg; ++i) {
         wp[3 * i] = pos_1d[i];
@@ -1274,8 +1320,11 @@ extern "C" int uavqp_solve_axis_host(uavqp_ctx* ctx, int r, int n_seg, const dou
     // (no stream synchronisation: a one-thread kernel behind the solve stamps a word of the page, the host polls it)
     {
         const unsigned int seq = ++ctx->pipe_seq;
-        hipLaunchKernelGGL(uavqp::host_word_kernel, dim3(1), dim3(1), 0, ctx->stream, (const int32_t*)nullptr, (volatile unsigned long long*)(db + o_st + 64), seq);
-        rc = await_host_word(ctx->stream, (volatile unsigned long long*)(hb + o_st + 64), seq, nullptr, "uavqp_solve_axis_host");
+        volatile unsigned long long* h_word = (volatile unsigned long long*)ctx->h_axis;
+        *h_word = 0ull;
+        std::atomic_thread_fence(std::memory_order_release);
+        hipLaunchKernelGGL(uavqp::host_word_kernel, dim3(1), dim3(1), 0, ctx->stream, (const int32_t*)nullptr, (volatile unsigned long long*)ctx->d_axis, seq);
+        rc = await_host_word(ctx->stream, h_word, seq, nullptr, "uavqp_solve_axis_host");
         if (rc != UAVQP_OK) return rc;
     }
     const int32_t status = *st;
@@ -1454,10 +1503,15 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
     // pipeline call must not grow the workspace, i.e. stop the stream and re-allocate, in the middle of the loop
     const size_t b_compact = align256(sizeof(int32_t) * (size_t)n_traj) + 256;
     // one lane per trajectory (qp_corridor_lane.h): batches of at most 16 segments per trajectory, G not cached across solves
+#ifdef UAVQP_EXPERIMENTS
     const bool lane_prelude = dual && !(d_gcache && gcache_mode != 0) && Mmax - 1 <= uavqp::LANE_NV && ctx->settings.corridor_prelude_lanes == 1;
     long long lgrid = ((long long)n_traj + 63) / 64;
     if (lgrid > (long long)ctx->num_cus * 4) lgrid = (long long)ctx->num_cus * 4;     // (one wave per SIMD: the register file, not the 27 KB of LDS per wave, sets it)
     const size_t b_lane = lane_prelude ? align256(sizeof(double) * (size_t)uavqp::lane_scratch_doubles(r) * (size_t)lgrid) : 0;
+#else
+    const bool lane_prelude = false;
+    const size_t b_lane = 0;
+#endif
     int rc = ensure_ws(ctx, b_xsol + b_queue + b_desc + b_order + b_state + b_guess + b_compact + b_lane);
     if (rc != UAVQP_OK) return rc;
     a.guess = guess ? (unsigned long long*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order + b_state) : nullptr;
@@ -1523,10 +1577,12 @@ static int corridor_warm_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_seg
             if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<3>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
             else hipLaunchKernelGGL((uavqp::corridor_dual_wave_kernel<4>), dim3((unsigned)wgrid), dim3(64), 0, ctx->stream, a, ctx->dual_trips_extra);
         }
+#ifdef UAVQP_EXPERIMENTS
     } else if (lane_prelude) {
         double* const d_lane = (double*)((char*)ctx->ws + b_xsol + b_queue + b_desc + b_order + b_state + b_guess + b_compact);
         if (r == 3) hipLaunchKernelGGL((uavqp::corridor_dual_lane_kernel<3>), dim3((unsigned)lgrid), dim3(64), 0, ctx->stream, a, d_lane, ctx->dual_trips_extra);
         else hipLaunchKernelGGL((uavqp::corridor_dual_lane_kernel<4>), dim3((unsigned)lgrid), dim3(64), 0, ctx->stream, a, d_lane, ctx->dual_trips_extra);
+#endif
     } else if (dual) {
         // groups of 8 lanes (two tableau columns each) for the trajectories of up to 17 segments, whole DPP rows for the longer ones: a batch
         // of mixed lengths gets both launches, each skipping (per wave: the dealing order is by length) what the other one takes
@@ -2311,6 +2367,7 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
     // Large clouds, boxes only: rows and points sorted along the cloud's longest axis, every block scans the points within `reach`
     // of its rows (obstacle_grid.h, cloud_window_kernel) -- identical boxes, fewer pairs.  The clearance output needs the exhaustive min.
     const bool windowed = !d_clearance && n_obs >= 4096 && n_rows >= 4096 && ctx->settings.cloud_window != 0;
+#ifdef UAVQP_EXPERIMENTS
     if (windowed && ctx->settings.cloud_window >= 3) {
         // Round 5, two passes on the 2-D cell grid (cloud_grid2d.h): the rows the bounding box does not cull scan the ring next to them; the ones whose
         // clearance so far does not bound what farther points could change are re-sorted by the radius it implies and scan exactly that -- identical boxes.
@@ -2398,7 +2455,9 @@ extern "C" int uavqp_corridor_from_cloud_device(uavqp_ctx* ctx, int r, int n_tra
             hipLaunchKernelGGL(uavqp::cloud_grid2d_kernel<3>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ga);
         else
             hipLaunchKernelGGL(uavqp::cloud_grid2d_kernel<4>, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ga);
-    } else if (windowed) {
+    } else
+#endif
+    if (windowed) {
         const double rmax = robot_r > robot_h ? robot_r : robot_h, rmin = robot_r > robot_h ? robot_h : robot_r;
         a.reach = rmax * (1.0 + 3.0 * h_max / rmin) * (1.0 + 1e-9) + 1e-9;
         const size_t b_cs = 256, b_ph = align256(sizeof(int32_t) * (uavqp::CLOUD_PT_BINS + 1)), b_rh = align256(sizeof(int32_t) * (uavqp::CLOUD_ROW_BINS + 2));

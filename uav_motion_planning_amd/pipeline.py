@@ -20,7 +20,7 @@ def corridor_pipeline_device(ctx, r, seg_offsets, waypoints, times, bc, obstacle
     Returns dict(coeff, status, corr_lo, corr_hi (the boxes of the final solve), first_hit (of the final check, check_samples = none),
     collision_free (bool per trajectory), colliding_before_repair, colliding_with_blocked_waypoints (of those: trajectories with a
     waypoint the cloud leaves no room around -- not repairable by narrower boxes), repairs, rounds, still_stretching, check_dt,
-    all_solved)."""
+    check_samples, all_solved); `collision_free` is formed on first access (see _PipelineResult)."""
     import torch
     n = seg_offsets.numel() - 1
     rows = waypoints.reshape(-1, 3).shape[0]
@@ -46,10 +46,48 @@ def corridor_pipeline_device(ctx, r, seg_offsets, waypoints, times, bc, obstacle
 
 
 class _PipelineResult(dict):
-    """The result dict; `collision_free` (first_hit >= check_samples, a torch comparison = one more launch) is formed when it is asked for."""
+    """The result dict.  `collision_free` (first_hit >= check_samples: a torch comparison = one more launch) is a LAZY key: it is a member of
+    the dict for every access path (`in`, get, keys / items / values, iteration, dict(res), **res) and is formed the first time any of them
+    touches it.  `check_samples` (the sample count of the final check; = "no hit" in first_hit) is a documented entry of the result."""
+    _LAZY = "collision_free"
+
+    def _materialise(self):
+        if not dict.__contains__(self, self._LAZY):
+            dict.__setitem__(self, self._LAZY, dict.__getitem__(self, "first_hit") >= dict.__getitem__(self, "check_samples"))
 
     def __missing__(self, key):
-        if key == "collision_free":
-            self[key] = self["first_hit"] >= self["check_samples"]
-            return self[key]
+        if key == self._LAZY:
+            self._materialise()
+            return dict.__getitem__(self, key)
         raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == self._LAZY or dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        if key == self._LAZY:
+            return self[key]
+        return dict.get(self, key, default)
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + (0 if dict.__contains__(self, self._LAZY) else 1)
+
+    def copy(self):
+        self._materialise()
+        return dict(self)
