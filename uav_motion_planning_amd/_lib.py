@@ -106,7 +106,7 @@ def build(force=False):
     csrc = os.path.join(_PKG, "csrc")
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
-    subprocess.check_call(["make", "-s", "-C", csrc])
+    subprocess.check_call(["make", "-s", "-j", str(min(8, os.cpu_count() or 1)), "-C", csrc])
     return LIB_PATH
 
 

@@ -34,6 +34,7 @@ __device__ __forceinline__ int cloud2d_cell(const Cloud2D& g, double a, double b
 }
 
 // one block: bounding box -> axes, cell size (at least min_cell, at most CLOUD2D_MAX_CELLS cells); zeroes both histograms
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(1024) void cloud2d_setup_kernel(const double* __restrict__ obs, int n_obs, double min_cell, Cloud2D* __restrict__ cg,
                                                              int32_t* __restrict__ pt_hist, int32_t* __restrict__ row_hist) {
     __shared__ double s[1024][6];
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(1024) void cloud2d_setup_kernel(const double* __res
         for (int ax = 0; ax < 3; ++ax) { cg->bb_lo[ax] = s[0][ax]; cg->bb_hi[ax] = s[0][3 + ax]; }
     }
 }
+#endif
 
 __device__ __forceinline__ void cloud2d_slice(long long total, long long& i0, long long& i1) {
     const long long per = (total + gridDim.x - 1) / gridDim.x;
@@ -88,6 +90,7 @@ __device__ __forceinline__ void cloud2d_slice(long long total, long long& i0, lo
     i1 = i0 + per < total ? i0 + per : total;
 }
 // histograms of the points and of the rows over the cells, hist[c + 1] counts cell c (LDS counts first, one global add per block and cell)
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(256) void cloud2d_hist_kernel(const double* __restrict__ obs, int n_obs, const double* __restrict__ wp, int n_rows,
                                                            const Cloud2D* __restrict__ cgp, int32_t* __restrict__ pt_hist, int32_t* __restrict__ row_hist) {
     __shared__ int s_h[2 * CLOUD2D_MAX_CELLS];
@@ -107,7 +110,9 @@ __global__ __launch_bounds__(256) void cloud2d_hist_kernel(const double* __restr
         if (c) atomicAdd(i < nc ? &pt_hist[1 + i] : &row_hist[1 + i - nc], c);
     }
 }
+#endif
 // inclusive scans in place (start[c] = first element of cell c, start[n cells] = total) and cursor copies; one block
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(1024) void cloud2d_scan_kernel(const Cloud2D* __restrict__ cgp, int32_t* __restrict__ pt_start, int32_t* __restrict__ pt_cursor,
                                                             int32_t* __restrict__ row_start, int32_t* __restrict__ row_cursor) {
     __shared__ int s_tot[1024];
@@ -132,6 +137,8 @@ __global__ __launch_bounds__(1024) void cloud2d_scan_kernel(const Cloud2D* __res
     scan(pt_start, pt_cursor);
     scan(row_start, row_cursor);
 }
+#endif
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(256) void cloud2d_scatter_kernel(const double* __restrict__ obs, int n_obs, const double* __restrict__ wp, int n_rows,
                                                               const Cloud2D* __restrict__ cgp, int32_t* __restrict__ pt_cursor, int32_t* __restrict__ row_cursor,
                                                               double* __restrict__ pts_sorted, int32_t* __restrict__ row_perm) {
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(256) void cloud2d_scatter_kernel(const double* __re
         }
     }
 }
+#endif
 
 struct Cloud2DArgs {
     CloudCorridorArgs c;          // row_perm, pt_start, pts_sorted, reach as in the window variant (pt_start per CELL here)
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(256) void cloud2d_hist_cull_kernel(CloudCorridorArg
     }
 }
 // scans over nb_pt + 1 / nb_row + 1 entries (bin counts at [1..]); one block
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(1024) void cloud2d_scan_n_kernel(const Cloud2D* __restrict__ cgp, int extra_row_bins, int row_mult, int32_t* __restrict__ pt_start,
                                                               int32_t* __restrict__ pt_cursor, int32_t* __restrict__ row_start, int32_t* __restrict__ row_cursor) {
     __shared__ int s_tot[1024];
@@ -365,6 +374,8 @@ __global__ __launch_bounds__(1024) void cloud2d_scan_n_kernel(const Cloud2D* __r
     if (pt_start) scan(pt_start, pt_cursor, nc);
     scan(row_start, row_cursor, nc * row_mult + extra_row_bins);
 }
+#endif
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(256) void cloud2d_scatter_bin_kernel(const double* __restrict__ obs, int n_obs, const int32_t* __restrict__ row_bin, int n_rows,
                                                                   const Cloud2D* __restrict__ cgp, int32_t* __restrict__ pt_cursor, int32_t* __restrict__ row_cursor,
                                                                   double* __restrict__ pts_sorted, int32_t* __restrict__ row_perm) {
@@ -395,13 +406,16 @@ __global__ __launch_bounds__(256) void cloud2d_scatter_bin_kernel(const double* 
         }
     }
 }
+#endif
 // rows of pass 2 by their key (-1: not in pass 2): one global cursor add per row (about a third of the rows, a few thousand bins)
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(256) void cloud2d_scatter2_kernel(const int32_t* __restrict__ row_key, int n_rows, int32_t* __restrict__ cursor2, int32_t* __restrict__ perm2) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (long long)gridDim.x * 256) {
         const int k = row_key[i];
         if (k >= 0) perm2[atomicAdd(&cursor2[k], 1)] = (int)i;
     }
 }
+#endif
 
 struct Cloud2PArgs {
     CloudCorridorArgs c;          // row_perm (pass 1: by cell, culled rows last), pt_start (per cell), pts_sorted, reach

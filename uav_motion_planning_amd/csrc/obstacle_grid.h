@@ -6,7 +6,8 @@
 // applies exactly the tests of ellipsoid_kernel (uavqp.hip) -- same candidate set, same arithmetic per pair, so the
 // flags are identical to the exhaustive scan.
 #pragma once
-#include "qp_device.h"
+#include "qp_core_kernels.h"
+#include "qp_wave_utils.h"
 
 namespace uavqp {
 
@@ -24,6 +25,7 @@ __device__ __forceinline__ int grid_coord(const GridView& g, double x, int ax) {
 }
 
 // per-block partial bounds: out[block][6] = min xyz, max xyz
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ void grid_bounds_kernel(const double* __restrict__ obs, int n_obs, double* __restrict__ out) {
     __shared__ double s[256][6];
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -53,7 +55,9 @@ __global__ void grid_bounds_kernel(const double* __restrict__ obs, int n_obs, do
     }
     if (threadIdx.x < 6) out[blockIdx.x * 6 + threadIdx.x] = s[0][threadIdx.x];
 }
+#endif
 
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ void grid_count_kernel(GridView g, const double* __restrict__ obs, int n_obs, int32_t* __restrict__ cell_of,
                                   int32_t* __restrict__ counts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +68,9 @@ __global__ void grid_count_kernel(GridView g, const double* __restrict__ obs, in
     cell_of[i] = c;
     atomicAdd(&counts[c], 1);
 }
+#endif
 
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ void grid_scatter_kernel(const double* __restrict__ obs, int n_obs, const int32_t* __restrict__ cell_of,
                                     int32_t* __restrict__ cursor, double* __restrict__ sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,6 +79,7 @@ __global__ void grid_scatter_kernel(const double* __restrict__ obs, int n_obs, c
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) sorted[(size_t)pos * 3 + ax] = obs[(size_t)i * 3 + ax];
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Corridor boxes from an obstacle cloud (include/uavqp.h: uavqp_corridor_from_cloud_device).
@@ -289,6 +296,7 @@ __device__ __forceinline__ int cloud_bin(double v, double lo, double inv, int nb
     return b;
 }
 // one block: bounding box of the cloud -> sort axis and bin geometry; zeroes the histograms
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(1024) void cloud_sort_setup_kernel(const double* __restrict__ obs, int n_obs, double reach, CloudSort* __restrict__ cs,
                                                                 int32_t* __restrict__ pt_hist, int32_t* __restrict__ row_hist) {
     __shared__ double s[1024][6];
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(1024) void cloud_sort_setup_kernel(const double* __
         for (int ax = 0; ax < 3; ++ax) { cs->bb_lo[ax] = s[0][ax]; cs->bb_hi[ax] = s[0][3 + ax]; }     // (+inf / -inf without a finite point: every row is culled -- no point, every box h_max)
     }
 }
+#endif
 // histograms of the points and of the rows (one launch), bins at [1..]: hist[b + 1] counts bin b, so that the scan leaves starts.
 // Counted in LDS first (neighbouring rows share bins: global atomics on the same address serialise -- 77 us for 266 k keys), one
 // global add per block and non-empty bin.  Every block works on ONE contiguous slice of the keys, the same slice in the scatter.
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(256) void cloud_sort_hist_kernel(CloudCorridorArgs 
     }
 }
 // inclusive scans in place (start[b] = first element of bin b, start[NB] = total) and cursor copies; one block
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(1024) void cloud_sort_scan_kernel(int32_t* __restrict__ pt_start, int32_t* __restrict__ pt_cursor, int32_t* __restrict__ row_start,
                                                                int32_t* __restrict__ row_cursor) {
     __shared__ int s_tot[1024];
@@ -390,9 +400,11 @@ __global__ __launch_bounds__(1024) void cloud_sort_scan_kernel(int32_t* __restri
     scan(pt_start, pt_cursor, CLOUD_PT_BINS);
     scan(row_start, row_cursor, CLOUD_ROW_BINS + 1);
 }
+#endif
 // scatter: the block counts its slice per bin in LDS again, reserves a range per non-empty bin with ONE global add, and hands out the
 // positions inside the ranges with LDS atomics (the order inside a bin is arbitrary: it decides which lane scans a row / where in a
 // tile a point sits, never a result -- the minimum over a set does not depend on the order)
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(256) void cloud_sort_scatter_kernel(const double* __restrict__ obs, int n_obs, const int32_t* __restrict__ row_bin, int n_rows,
                                                                  const CloudSort* __restrict__ cs, int32_t* __restrict__ pt_cursor,
                                                                  int32_t* __restrict__ row_cursor, double* __restrict__ pts_sorted,
@@ -423,6 +435,7 @@ __global__ __launch_bounds__(256) void cloud_sort_scatter_kernel(const double* _
         }
     }
 }
+#endif
 
 // PS waves share the rows of a block and split the points of every tile between them (PS = 2: 128 rows per 256-thread block): the number of
 // waves of the launch is rows / 64 x PS -- config 5 has only ~2200 row-waves for 1024 SIMDs, two per SIMD, too few to hide the LDS round trip

@@ -29,7 +29,8 @@
 // Checked against exact-rational fixtures including the active sets (tests/test_corridor_golden.py), the OSQP-faithful port and
 // a KKT certificate (tests/test_gpu_corridor.py), at BASELINE sizes in tests/test_gpu_baseline_sizes.py.
 #pragma once
-#include "qp_device.h"
+#include "qp_core_kernels.h"
+#include "qp_wave_utils.h"
 
 namespace uavqp {
 
@@ -111,10 +112,12 @@ struct FullBlocks {
     __device__ __forceinline__ double B00(int i, int c) const { return ((i + c) & 1) ? -B11[i][c] : B11[i][c]; }
 };
 
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+#endif
 // does trajectory b take part in this solve?  (no mask: all do)
 __device__ __forceinline__ bool corridor_takes_part(const int32_t* only_i32, const unsigned char* only_u8, int b) {
     if (!only_i32 && !only_u8) return true;
@@ -122,6 +125,7 @@ __device__ __forceinline__ bool corridor_takes_part(const int32_t* only_i32, con
 }
 // Dealing order of a masked re-solve: the entries of `order` (null: 0, 1, 2, ...) whose trajectory takes part, in the same sequence (the
 // order is by segment count: waves keep trajectories of similar length), and their number.  One workgroup: a block scan over n_traj flags.
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __restrict__ order, int n_traj, const int32_t* __restrict__ only_i32,
                                                              const unsigned char* __restrict__ only_u8, int32_t* __restrict__ out, int* __restrict__ n_out,
                                                              const unsigned int* __restrict__ none_if_zero = nullptr,
@@ -221,10 +225,12 @@ __global__ __launch_bounds__(1024) void compact_order_kernel(const int32_t* __re
         if (host_slot) { __threadfence_system(); *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
     }
 }
+#endif
 // The same compaction for lists beyond one workgroup's reach (16 384 entries): block b takes entries [16384 b, 16384 (b + 1)) -- phase 0
 // leaves the number it keeps in block_counts[b], phase 1 (a second launch of the same grid) writes them behind those of the blocks before it.
 // Order preserved; block 0 of phase 1 reports the total.  (one workgroup walked a million flags per pipeline round.)
 constexpr int COMPACT_BLOCK = 16384;
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(1024) void compact_order_blocks_kernel(const int32_t* __restrict__ order, int n_traj, const int32_t* __restrict__ only_i32,
                                                                     const unsigned char* __restrict__ only_u8, int32_t* __restrict__ out, int* __restrict__ n_out,
                                                                     const int* __restrict__ n_dev, int* __restrict__ block_counts, int phase,
@@ -291,6 +297,8 @@ __global__ __launch_bounds__(1024) void compact_order_blocks_kernel(const int32_
         if (host_slot) { __threadfence_system(); *host_slot = ((unsigned long long)host_seq << 32) | (unsigned)all; __threadfence_system(); }
     }
 }
+#endif
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ void corridor_reset_kernel(int32_t* status, int32_t* iters, int n, const int32_t* only_i32, const unsigned char* only_u8) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && corridor_takes_part(only_i32, only_u8, i)) {
@@ -298,6 +306,7 @@ __global__ void corridor_reset_kernel(int32_t* status, int32_t* iters, int n, co
         if (iters) iters[i] = 0;
     }
 }
+#endif
 
 __device__ __forceinline__ int swap_pair_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ unsigned long long swap_pair_u64(unsigned long long v) {
@@ -309,6 +318,7 @@ __device__ __forceinline__ unsigned long long swap_pair_u64(unsigned long long v
 // A wave sweeps as long as its longest half, so problems of similar length should share a wave; and the longest problems --
 // which also need the most iterations -- start first instead of stretching the tail of the launch.  The order inside a bin is
 // whatever the atomics give: it decides which lane pair solves a problem, never its result.
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(256) void seg_hist_kernel(const int32_t* __restrict__ seg_offsets, int n_traj, int* __restrict__ hist) {
     __shared__ int s_h[256];
     s_h[threadIdx.x] = 0;
@@ -321,6 +331,8 @@ __global__ __launch_bounds__(256) void seg_hist_kernel(const int32_t* __restrict
     __syncthreads();
     if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
+#endif
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(256) void seg_scan_kernel(const int* __restrict__ hist, int* __restrict__ cursor) {
     __shared__ int s_c[256];
     s_c[threadIdx.x] = hist[255 - threadIdx.x];   // position t <-> segment count 255 - t: longest first
@@ -332,6 +344,8 @@ __global__ __launch_bounds__(256) void seg_scan_kernel(const int* __restrict__ h
     __syncthreads();
     cursor[255 - threadIdx.x] = s_c[threadIdx.x];
 }
+#endif
+#ifndef UAVQP_KERNEL_TU   // a plain (non-template) kernel: emitted once, by the host translation unit (uavqp.hip)
 __global__ __launch_bounds__(256) void seg_scatter_kernel(const int32_t* __restrict__ seg_offsets, int n_traj, int* __restrict__ cursor,
                                                           int32_t* __restrict__ order) {
     // a batch has few distinct segment counts: one global add per trajectory on ~20 addresses serialises (38 us for 16 384
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const int32_t* __restr
     __syncthreads();
     for (int b = b0 + threadIdx.x; b < b1; b += 256) order[atomicAdd(&s_h[key(b)], 1)] = b;
 }
+#endif
 
 // One lane per (trajectory, axis): validation of the inputs and the permanent pins (lo == hi: a true equality row, as in the
 // reference), once per solve and off the solver's critical path -- a persistent wave that takes a new problem must not stall

@@ -21,7 +21,8 @@
 // Ragged batches are dealt to the lane PAIRS by segment count inside windows (window_sort_kernel, 32 trajectories per wave);
 // the rank ranges are rotated by the window index so that the long waves spread over the XCDs.  DESIGN.md section 5.2.
 #pragma once
-#include "qp_device.h"
+#include "qp_core_kernels.h"
+#include "qp_wave_utils.h"
 
 // (probe builds, tools/generic2_probe.py: -DG2_NO_WS / -DG2_NO_OUT take the workspace round trip / the coefficient stores out)
 #ifdef G2_NO_WS
