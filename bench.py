@@ -794,9 +794,57 @@ def run(args):
         gather = {"ms": g_s * 1e3, "bytes_per_rank_out": c_counts[rank] * 8, "bytes_total": tot * 8, "own_shard_intact": ok,
                   "through": ("uavqp_allgather_coeffs (RCCL, ctx communicator)" if gctx is not None else
                               (f"torch.distributed all-gather (uavqp_comm_create failed: {comm_err})" if rccl_ok else f"torch.distributed/{backend} stand-in")),
-                  "value_with_gather": n_step / (dt / K + g_s)}
+                  "value_with_gather": n_step / (dt / K + g_s),
+                  "value_with_gather_is": "serial: one step = solve, then the exchange behind it on the same stream (solve time per step + median gather time)"}
         if gctx is not None:
+            # what RCCL itself says the communicator is (ncclCommUserRank / ncclCommCount through uavqp_comm_info): the exchange ran on N ranks
+            rk_, wd_ = gctx.comm_info()
+            gather["rccl_rank"], gather["rccl_world"] = rk_, wd_
+            gather["rccl_world_matches_n_gpus"] = bool(wd_ == world)
+            # ---- overlapped: the gather of step i on the communicator's stream while step i + 1 solves on a second stream.  At 5 us per
+            # solve the exchange (every rank receives the whole batch) is the step: serial, the N-rank value is the gather's; overlapped it
+            # is max(solve, gather) per step -- the only way "near-linear scaling" can survive the exchange
+            try:
+                s2, c2 = make_slot()                      # the solves of this leg: their own ctx and stream; the gathers stay on gctx's stream
+                launch(c2, 0)
+                torch.cuda.synchronize()
+                KO = max(K, 20)
+                fulls = [torch.zeros(tot, dtype=torch.float64, device=dev) for _ in range(2)]
+                ow = []
+                for _ in range(5):
+                    fence()
+                    o0 = time.perf_counter()
+                    done_g = {}
+                    for i in range(KO):
+                        if i - S in done_g:
+                            s2.wait_event(done_g.pop(i - S))      # the gather that still reads this step's output buffer has finished
+                        launch(c2, i)
+                        ev = torch.cuda.Event()
+                        ev.record(s2)
+                        stream.wait_event(ev)
+                        D.allgather_shards(sets[i % S]["out"], c_counts, fulls[i & 1], gctx)
+                        eg = torch.cuda.Event()
+                        eg.record(stream)
+                        done_g[i] = eg
+                    gctx.synchronize()
+                    torch.cuda.synchronize()
+                    ow.append(time.perf_counter() - o0)
+                    fence()
+                o_s = float(np.median(ow))
+                t = torch.tensor([o_s], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                o_s = float(t.item())
+                gather["value_with_gather_overlapped"] = n_step * KO / o_s
+                gather["overlapped"] = {"steps": KO, "ms_per_step": o_s / KO * 1e3, "own_shard_intact": bool(torch.equal(fulls[(KO - 1) & 1][off:off + c_counts[rank]], sets[(KO - 1) % S]["out"])),
+                                        "note": "eager launches: step i + 1 solves on a second ctx / stream while uavqp_allgather_coeffs of step i runs on the communicator's stream "
+                                                "(an event per step orders gather i behind solve i; a solve waits for the gather that still reads its output buffer); median of 5"}
+            except Exception as e:  # noqa: BLE001 (the extra leg must not take the line down)
+                gather["value_with_gather_overlapped"] = None
+                gather["overlapped"] = {"error": repr(e)}
             gctx.comm_destroy()
+        else:
+            gather["rccl_world"] = None
+            gather["value_with_gather_overlapped"] = None
 
     out = None
     if rank == 0:

@@ -476,6 +476,8 @@ int uavqp_pack_polynomial_trajectory(int r, int n_seg, const double* coeff_traj,
  *                               the other ranks by whatever it has (MPI, a file, a socket, torch.distributed's store).
  *   uavqp_comm_create           collective over all ranks: the ctx creates and owns the RCCL communicator (one per ctx; released
  *                               by uavqp_comm_destroy / uavqp_destroy).  world = 1 is valid (single-GPU self test).
+ *   uavqp_comm_info             rank and world size of the ctx's communicator as RCCL reports them (ncclCommUserRank, ncclCommCount):
+ *                               what bench.py records as allgather.rccl_world -- evidence that the exchange ran on a communicator of N ranks.
  *   uavqp_allgather_coeffs      device buffers, asynchronous on the ctx stream (ordered behind the solve): rank g contributes
  *                               counts[g] doubles from d_local; d_full receives the shards back to back in rank order
  *                               (sum_g counts[g] doubles).  Equal counts: one ncclAllGather; otherwise every rank sends its shard
@@ -488,6 +490,7 @@ int uavqp_shard_bounds(int n_traj, int world, int32_t* bounds);
 int uavqp_shard_bounds_ragged(const int32_t* seg_offsets, int n_traj, int world, int32_t* bounds);
 int uavqp_comm_unique_id(void* id_out);
 int uavqp_comm_create(uavqp_ctx* ctx, int rank, int world, const void* unique_id);
+int uavqp_comm_info(const uavqp_ctx* ctx, int32_t* rank_out, int32_t* world_out);
 int uavqp_comm_destroy(uavqp_ctx* ctx);
 int uavqp_allgather_coeffs(uavqp_ctx* ctx, const double* d_local, const int64_t* counts, double* d_full);
 int uavqp_allgather_status(uavqp_ctx* ctx, const int32_t* d_local, const int64_t* counts, int32_t* d_full);

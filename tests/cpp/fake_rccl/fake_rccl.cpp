@@ -1,4 +1,4 @@
-// TEST-ONLY stand-in for librccl.so.1 (tests/test_gpu_multirank_fake_rccl.py): the nine symbols libuavqp.so binds at run time
+// TEST-ONLY stand-in for librccl.so.1 (tests/test_gpu_multirank_fake_rccl.py): the eleven symbols libuavqp.so binds at run time
 // (csrc/uavqp_comm.h), implemented for ranks that are THREADS OF ONE PROCESS sharing one GPU -- the one configuration a single-GPU box
 // offers (real RCCL refuses two ranks on one device).  Purpose: execute the world > 1 branches of the C ABI (the grouped
 // ncclSend / ncclRecv all-gather-v of allgather_shards, in-place aliasing, zero-sized shards) before the driver's 8-GPU run does.
@@ -105,6 +105,18 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     c->rank = rank;
     *comm = c;
     w->barrier();   // like the real thing: returns once every rank has joined
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = comm->w->world;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
+    if (!comm || !rank) return ncclInvalidArgument;
+    *rank = comm->rank;
     return ncclSuccess;
 }
 

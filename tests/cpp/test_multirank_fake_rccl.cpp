@@ -32,6 +32,10 @@ static void gather_case(int world, const std::vector<int64_t>& counts, bool in_p
             uavqp_ctx* ctx = nullptr;
             if (uavqp_create(&ctx, 0) != UAVQP_OK) { CHECK(false, "create"); return; }
             CHECK(uavqp_comm_create(ctx, rank, world, id) == UAVQP_OK, "comm_create rank %d: %s", rank, uavqp_last_error());
+            {   // what the communicator library itself says (ncclCommUserRank / ncclCommCount): bench.py's allgather.rccl_world
+                int32_t rk = -1, wd = -1;
+                CHECK(uavqp_comm_info(ctx, &rk, &wd) == UAVQP_OK && rk == rank && wd == world, "comm_info rank %d: got (%d, %d): %s", rank, rk, wd, uavqp_last_error());
+            }
             double *d_full = nullptr, *d_loc = nullptr;
             int32_t *s_full = nullptr, *s_loc = nullptr;
             hipMalloc((void**)&d_full, sizeof(double) * (total + 1));
@@ -72,6 +76,11 @@ int main() {
     gather_case(3, {5, 0, 9}, false);       // a zero-sized shard in the middle
     gather_case(3, {5, 0, 9}, true);
     gather_case(3, {0, 0, 4}, true);
+    // the driver's node: eight ranks -- equal shards (configs 2 / 3: ncclAllGather) and the ragged shards of configs 4 / 5 (grouped send / recv)
+    gather_case(8, {6, 6, 6, 6, 6, 6, 6, 6}, true);
+    gather_case(8, {6, 6, 6, 6, 6, 6, 6, 6}, false);
+    gather_case(8, {9, 4, 7, 0, 11, 5, 8, 3}, true);
+    gather_case(8, {9, 4, 7, 0, 11, 5, 8, 3}, false);
     std::printf("raw gathers done, failures so far %d\n", g_bad);
 
     // ---- 2. TrajOptimizer::solveSharded on two ranks vs the single-process host solve
@@ -107,12 +116,13 @@ int main() {
         CHECK(traj_optimization::TrajOptimizer::uniqueId(id), "unique id");
         const size_t nc = static_cast<size_t>(3) * 2 * r * segs;
         std::vector<std::thread> th;
-        for (int rank = 0; rank < 2; ++rank)
+        const int world_sh = mode == 0 ? 8 : 2;      // (the equality solve also on the driver's eight ranks)
+        for (int rank = 0; rank < world_sh; ++rank)
             th.emplace_back([&, rank] {
                 hipSetDevice(0);
                 traj_optimization::TrajOptimizer sh(r);
                 setup(sh);
-                CHECK(sh.initDistributed(rank, 2, id), "initDistributed rank %d", rank);
+                CHECK(sh.initDistributed(rank, world_sh, id), "initDistributed rank %d", rank);
                 const bool ok = sh.solveSharded();
                 double worst = 0.0, scale = 0.0;
                 int st_diff = 0;

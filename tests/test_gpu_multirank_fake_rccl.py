@@ -2,7 +2,7 @@
 time, so the rank > 1 branches of the multi-GPU entry points (the grouped ncclSend / ncclRecv all-gather-v of allgather_shards in
 csrc/uavqp.hip, zero-sized shards, in-place aliasing, TrajOptimizer::solveSharded with real shard bounds) had never executed
 anywhere.  Here they do: tests/cpp/test_multirank_fake_rccl.cpp runs the ranks as THREADS of one process (one uavqp_ctx each on
-device 0) against a TEST-ONLY librccl.so.1 (tests/cpp/fake_rccl/fake_rccl.cpp: the nine symbols libuavqp.so binds with dlopen,
+device 0) against a TEST-ONLY librccl.so.1 (tests/cpp/fake_rccl/fake_rccl.cpp: the eleven symbols libuavqp.so binds with dlopen,
 rendezvous through process memory, device-to-device copies) put in front of the real one with LD_LIBRARY_PATH.  The 8-GPU run over
 real RCCL / xGMI is the driver's; this test is about rank bookkeeping, not about bandwidth."""
 import os
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_and_three_ranks_through_the_c_abi_with_a_fake_rccl():
+def test_two_three_and_eight_ranks_through_the_c_abi_with_a_fake_rccl():
     rocm = "/opt/rocm"
     if shutil.which("g++") is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
         pytest.skip("no g++ / HIP headers on this box")
@@ -34,4 +34,4 @@ def test_two_and_three_ranks_through_the_c_abi_with_a_fake_rccl():
     env = dict(os.environ, LD_LIBRARY_PATH=fake_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout[-3000:] + run.stderr[-2000:]
-    assert "mode 2 rank 1" in run.stdout
+    assert "mode 2 rank 1" in run.stdout and "mode 0 rank 7" in run.stdout       # eight ranks = the driver's node

@@ -61,6 +61,7 @@ SYMBOLS = (
     "uavqp_shard_bounds_ragged",
     "uavqp_comm_unique_id",
     "uavqp_comm_create",
+    "uavqp_comm_info",
     "uavqp_comm_destroy",
     "uavqp_allgather_coeffs",
     "uavqp_allgather_status",
@@ -174,6 +175,7 @@ def lib():
     L.uavqp_comm_unique_id.argtypes = [vp]
     L.uavqp_comm_create.argtypes = [vp, i32, i32, vp]
     L.uavqp_comm_destroy.argtypes = [vp]
+    L.uavqp_comm_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.uavqp_allgather_coeffs.argtypes = [vp, dp, vp, dp]
     L.uavqp_allgather_status.argtypes = [vp, ip, vp, ip]
     L.uavqp_capture_begin.argtypes = [vp]

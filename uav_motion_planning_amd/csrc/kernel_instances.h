@@ -59,10 +59,12 @@
 // ---- qp_rows.h / qp_rows2.h: the general-rows solvers
 #define UAVQP_ROWS_RK(R_, K_)                                                                  \
     UAVQP_INST __global__ void uavqp::rows_solve_kernel<R_, K_>(uavqp::RowsArgs);                 \
-    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, true, false>(uavqp::Rows2Args);    \
-    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, true, true>(uavqp::Rows2Args);     \
-    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, false, false>(uavqp::Rows2Args);   \
-    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, false, true>(uavqp::Rows2Args);
+    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, true, false, false>(uavqp::Rows2Args);    \
+    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, true, false, true>(uavqp::Rows2Args);     \
+    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, true, true, false>(uavqp::Rows2Args);     \
+    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, false, false, false>(uavqp::Rows2Args);   \
+    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, false, false, true>(uavqp::Rows2Args);    \
+    UAVQP_INST __global__ void uavqp::rows_pair_kernel<R_, K_, false, true, false>(uavqp::Rows2Args);
 // (one translation unit per (R, K): k_rows31.hip ... k_rows42.hip -- five register-heavy kernels each)
 #define UAVQP_INSTANCES_ROWS31 UAVQP_ROWS_RK(3, 1)
 #define UAVQP_INSTANCES_ROWS32 UAVQP_ROWS_RK(3, 2)

@@ -46,9 +46,18 @@ struct Rows2Args {
     const int32_t* order;       // dealing order of the trajectories (longest first), may be null
     double* lam;                // dual state [wave][own knot 0..kown][2 (1 + K)][lane]: current / new multiplier of the knot box and the rows
     double* gfun;               // row functionals [segment][K][2 R] (g_l, g_r of p^(d)(tau T) = g_l' x_k + g_r' x_{k+1}, ORIGINAL frame), made once per
-                                // solve by rows_gfun_kernel: they depend on the time allocation only (not on the axis, not on the working set)
+                                // solve by rows_prep_kernel: they depend on the time allocation only (not on the axis, not on the working set)
     int ws_knots;               // own knots per lane kept in the HBM workspace (beyond the LDS slots)
     int lam_knots;              // own knots per lane in `lam` (= own segments per lane in `gfun`)
+    double* coeff;              // round 6: the pair kernel writes the polynomials of a finished problem itself (segment_coeffs_det on its sweep state, as
+                                // corridor_solve_kernel does since round 4); null: the Hermite solution goes to RowsArgs::xsol for corridor_emit_kernel
+    // round 6: rows_prep_kernel is the FIRST kernel of the step and also (i) makes the row functionals (was: rows_gfun_kernel, a second pass over
+    // the same rows), (ii) initialises status / iteration counts (was: fill_i32_kernel + a memset) and (iii) clears what the dual prelude only
+    // writes for the trajectories it takes (was: two memsets) -- any of these may be null
+    int prep_gfun;              // 1: write `gfun`
+    unsigned long long* init_warm_box;    // [n_traj][3][2]  -> 0
+    unsigned long long* init_warm_rows;   // [n_traj][3][2 K] -> 0
+    unsigned int* init_counters;          // 128 words -> 0 (block 0): the prelude's counter block and the pair kernel's queue behind it
 };
 
 // validation + permanent masks.  desc[0]: bit 0 = valid, bit 1 = has a free knot (M >= 2), bits 8.. = M; desc[1] = knot boxes with
@@ -61,6 +70,7 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
     const RowsArgs& a = aa.r;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    if (aa.init_counters && blockIdx.x == 0 && threadIdx.x < 128) aa.init_counters[threadIdx.x] = 0u;
     for (long long bq = (long long)blockIdx.x * (blockDim.x >> 6) + wib; bq < a.n_traj; bq += n_waves) {
         const int b = (int)bq;
         int s0, M;
@@ -68,8 +78,13 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
         const bool shape_ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;
         const bool seg = shape_ok && lane < M;                  // this lane has a segment
         bool t_bad = false;
-        if (seg) { const double t = a.times[s0 + lane]; t_bad = !((t > 0.0) && (t < INFINITY)); }
+        double t_seg = 1.0;
+        if (seg) { t_seg = a.times[s0 + lane]; t_bad = !((t_seg > 0.0) && (t_seg < INFINITY)); }
         const bool t_ok = shape_ok && __ballot(t_bad) == 0ull;
+        // first kernel of the step: the outputs every later kernel only lowers / raises / ORs into start here
+        if (lane == 0 && a.iters) a.iters[b] = 0;
+        if (aa.init_warm_box && lane < 6) aa.init_warm_box[(size_t)b * 6 + lane] = 0ull;
+        if (aa.init_warm_rows && lane < 6 * K) aa.init_warm_rows[(size_t)b * 6 * K + lane] = 0ull;
         // knot boxes: lane k = interior knot k = 1..M-1, the three axes are 24 contiguous bytes per array
         const bool knot = t_ok && lane >= 1 && lane < M;
         bool kbad[3] = {false, false, false}, keq[3] = {false, false, false};
@@ -91,6 +106,27 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) { rbad[j][ax] = false; req[j][ax] = false; }
         }
+        if (aa.prep_gfun && shape_ok) {
+            // the row functionals of this trajectory (they depend on the time allocation only: the same for the three axes, for the dual
+            // prelude and for every solve of the rows kernel): one (segment, row slot) per lane and trip -- contiguous loads and stores, every
+            // lane busy (lane = segment would leave three quarters of the wave idle in the longest part of this kernel); zeros for an unused or
+            // invalid row
+            for (int e0 = 0; e0 < M * K; e0 += 64) {
+                const int el = e0 + lane;
+                if (el < M * K) {
+                    const size_t e = (size_t)s0 * K + el;
+                    const int d = a.row_deriv[e];
+                    const double tau = a.row_tau[e], tq = a.times[s0 + el / K];
+                    double gl[R], gr[R];
+#pragma unroll
+                    for (int c = 0; c < R; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
+                    if (d >= 0 && d < R && tq > 0.0 && tq < INFINITY && tau >= 0.0 && tau < 1.0) row_functional<R>(tq, tau, d, gl, gr);
+                    double* o = aa.gfun + e * 2 * R;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) { o[c] = gl[c]; o[R + c] = gr[c]; }
+                }
+            }
+        }
         if (t_ok && lane < M) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -111,6 +147,7 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
         unsigned long long used[K], anybad = 0ull;
 #pragma unroll
         for (int j = 0; j < K; ++j) { used[j] = __ballot(rused[j]); anybad |= __ballot(rbad_any[j]); }
+        bool all_ok = true;      // (wave-uniform: ballots)
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             unsigned long long bad = anybad | __ballot(kbad[ax]);
@@ -119,8 +156,8 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
 #pragma unroll
             for (int j = 0; j < K; ++j) { bad |= __ballot(rbad[j][ax]); rq[j] = __ballot(req[j][ax]); }
             const bool ok = t_ok && bad == 0ull;
+            all_ok = all_ok && ok;
             if (lane == ax) {
-                if (!ok) atomicMin(&a.status[b], (int32_t)UAVQP_INVALID_INPUT);
                 unsigned long long* o = aa.desc + ((size_t)3 * b + ax) * (2 + 2 * K);
                 o[0] = ok ? (1ull | (M >= 2 ? 2ull : 0ull) | ((unsigned long long)M << 8)) : 0ull;
                 o[1] = eq;
@@ -128,23 +165,8 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
                 for (int j = 0; j < K; ++j) { o[2 + 2 * j] = used[j]; o[3 + 2 * j] = rq[j]; }
             }
         }
-    }
-}
-
-// row functionals of every (segment, row slot): one lane each
-template <int R, int K>
-__global__ __launch_bounds__(256) void rows_gfun_kernel(Rows2Args aa, long long total_segments) {
-    const RowsArgs& a = aa.r;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total_segments * K; e += (long long)gridDim.x * blockDim.x) {
-        const int d = a.row_deriv[e];
-        double gl[R], gr[R];
-#pragma unroll
-        for (int c = 0; c < R; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
-        const double T = a.times[e / K], tau = a.row_tau[e];
-        if (d >= 0 && d < R && T > 0.0 && T < INFINITY && tau >= 0.0 && tau < 1.0) row_functional<R>(T, tau, d, gl, gr);
-        double* o = aa.gfun + (size_t)e * 2 * R;
-#pragma unroll
-        for (int c = 0; c < R; ++c) { o[c] = gl[c]; o[R + c] = gr[c]; }
+        // the trajectory's status starts here (the first kernel of the step: ONE store, nothing to lower yet)
+        if (lane == 0) a.status[b] = all_ok ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
     }
 }
 
@@ -154,13 +176,24 @@ __global__ __launch_bounds__(256) void rows_gfun_kernel(Rows2Args aa, long long 
 // and the infeasibility certificate (qp_rows.h's header).  So the pass that sees every problem carries none of that machinery --
 // selects on a mode flag in the sweeps, the entering functional, the certificate's bookkeeping: measured +10 % on config 3 + K = 2,
 // where not one of 196 608 problems needs it -- and the second launch finds an empty list (a few microseconds).
-template <int R, int K, bool WS, bool GI>
+//
+// VER = true (round 6): the VERIFYING pass of a step whose starting sets come from the dual prelude (qp_rows_dual.h) -- on BASELINE config 3 +
+// K = 2 every one of the 196 608 problems is confirmed by its first block solve.  That solve needs no dual state: nothing was in the set
+// before (every multiplier starts at 0), so the pass neither reads nor writes `lam` (the HBM round trip of 2 (1 + K) doubles per own knot and
+// lane was 0.3 GB of the kernel's 0.7 GB); a problem the first solve does not confirm -- a wrong-signed multiplier, a violated constraint, a
+// singular set -- goes to the redo list and is solved from its start by the GI = true launch, which keeps the general machinery and takes
+// exactly the path the general first pass would have taken.
+// aa.coeff != null (round 6): a finished problem turns the Hermite states of its sweep slots into the polynomials of its own segments
+// (segment_coeffs_det, as corridor_solve_kernel does since round 4: bit-identical to corridor_emit_kernel on the same numbers) -- through LDS
+// and out as whole lines when the wave finishes together (always, in the verifying pass), straight from the lanes otherwise.
+template <int R, int K, bool WS, bool GI, bool VER = false>
 __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
+    static_assert(!(VER && GI), "the verifying pass leaves everything beyond one solve to the GI = true launch");
     const RowsArgs& a = aa.r;
     constexpr int ND = R - 1, B = R + K, NL = B * (B + 1) / 2, NCN = 1 + K, F = NL + B, BM = R + 2 * K;
     constexpr int NT = rows2_lds_knots(R, K);
     constexpr int NONE = 1 << 30;
-    __shared__ double s_rec[NT * F * 64];
+    __shared__ __attribute__((aligned(16))) double s_rec[NT * F * 64];
     const int lane = threadIdx.x;
     const int isR = lane & 1;
     // state slot s = own knot m - s (slot 0: the meeting knot).  LDS for s < NT, else the HBM workspace (per-lane branch: the lanes
@@ -250,7 +283,9 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                         const long long gn = 3LL * bn + axn;
                         const unsigned long long* dsc = aa.desc + (size_t)gn * (2 + 2 * K);
                         const unsigned long long d0 = dsc[0];
-                        if (d0 & 1ull) {
+                        // (with the fused emission a trajectory that rows_prep_kernel flagged on ANY axis is left untouched on all three, as
+                        // corridor_emit_kernel left it)
+                        if ((d0 & 1ull) && !(aa.coeff && a.status[bn] == (int32_t)UAVQP_INVALID_INPUT)) {
                             int sn, Mn;
                             if (a.uniform > 0) { Mn = a.uniform; sn = bn * Mn; } else { sn = a.seg_offsets[bn]; Mn = a.seg_offsets[bn + 1] - sn; }
                             g = gn; b = bn; ax = axn; M = Mn; s0 = sn;
@@ -587,6 +622,10 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         // (direction mode: lam_new is the RATE of the multiplier per unit step of q's; its "new" value is lc + rate, the ratio test is unbounded,
         // the entering constraint itself stores the unit rate: + for a box multiplier towards the violated side, - for a row's (row convention))
         auto dual = [&](double& lc, double& ln, bool active, bool equality, bool was, double lam_new, double bad, double mag, bool add_lc, int kind, int idx) {
+            if (VER) {            // first solve from the starting set: every current multiplier is 0; a wrong-signed new one sends the problem to the second pass
+                if (active && !equality && bad > 1e-13 * mag && bad > 0.0) step_cand(0.0, kind, idx);
+                return;
+            }
             if (!any_dirm) {      // the common path: a wave without a lane pair in direction mode
                 lc = was ? lc + tpend * (ln - lc) : 0.0;
                 const bool wrong = bad > 1e-13 * (mag + (add_lc ? fabs(lc) : 0.0)) && bad > 0.0;
@@ -651,7 +690,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 }
                 const int sl = mm - j - 1;
 #pragma unroll
-                for (int c = 0; c < NCN; ++c) { f.lc[c] = LC(sl, c); f.ln[c] = LN(sl, c); }
+                for (int c = 0; c < NCN; ++c) { f.lc[c] = VER ? 0.0 : LC(sl, c); f.ln[c] = VER ? 0.0 : LN(sl, c); }
             };
             BInA anx;
             load_bina(mm - 1, anx);
@@ -791,9 +830,11 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     }
                 }
                 // the block's multipliers back (the meeting knot's box -- slot 0, constraint 0 -- belongs to the pair step below)
+                if (!VER) {
 #pragma unroll
-                for (int c = 0; c < NCN; ++c)
-                    if (c > 0 || j + 1 < mm) { LC(sl1, c) = lcv[c]; LN(sl1, c) = lnv[c]; }
+                    for (int c = 0; c < NCN; ++c)
+                        if (c > 0 || j + 1 < mm) { LC(sl1, c) = lcv[c]; LN(sl1, c) = lnv[c]; }
+                }
                 // ---- rotate
 #pragma unroll
                 for (int i = 0; i < B; ++i) { ynn[i] = yn[i]; yn[i] = y[i]; }
@@ -812,10 +853,12 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 const double lam = (isR ? ol + lam_meet : lam_meet + ol), mag = (isR ? om + mag_meet : mag_meet + om);
                 const bool pj = kbit(pin, mm), ej = kbit(eqmask, mm), uj = kbit(upper, mm);
                 const bool was = (ppin >> (kk & 63)) & 1ull;
-                double lc0 = LC(0, 0), ln0 = LN(0, 0);
+                double lc0 = VER ? 0.0 : LC(0, 0), ln0 = VER ? 0.0 : LN(0, 0);
                 dual(lc0, ln0, pj, ej, was, lam, uj ? lam : -lam, mag, false, 0, kk);
-                LC(0, 0) = lc0;
-                LN(0, 0) = ln0;
+                if (!VER) {
+                    LC(0, 0) = lc0;
+                    LN(0, 0) = ln0;
+                }
                 if (!pj) {
                     const double l = klo(mm), h = khi(mm), v = ym[0];
                     const double below = l - v, above = v - h;
@@ -894,6 +937,9 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 } else if (inconsistent && !GI) {
                     redo = true;         // decided by the second pass
                     finish = true;
+                } else if (VER && (tkind >= 0 || vkind >= 0)) {
+                    redo = true;         // the starting set is not the final one: the second pass solves the problem from its start
+                    finish = true;
                 } else if (inconsistent) {
                     if (new_kind >= 0) {
                         // the constraint that has just entered depends on the working set: out again, one solve for the direction
@@ -951,24 +997,137 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
 #ifdef UAVQP_ROWS2_TIMING
         r2_acc[7] += 1;
 #endif
-        // ================= hand-over: Hermite solution of the interior knots (original frame) =================
-        if (finish && redo) {
-            if (!isR) aa.redo[atomicAdd(a.queue + 1, 1u)] = (unsigned int)g;
-            g = -1;
-            m = 0;
-        } else if (finish) {
-            for (int j = 1; j <= mm; ++j) {
-                if (j == mm && isR) continue;      // the meeting knot is written by the L lane
-                const int kk = korig(j);
-                if (kk < 1 || kk > M - 1) continue;
-                double* o = a.xsol + (base3 + 3LL * kk) * R;
+        // ================= hand-over: a finished problem leaves its polynomials (or its Hermite solution) and frees the pair =================
+        if (finish && redo && !isR) aa.redo[atomicAdd(a.queue + 1, 1u)] = (unsigned int)g;
+        const bool emitp = finish && !redo;
+        if (__ballot(emitp) != 0ull) {
+            if (!aa.coeff) {
+                if (emitp) {
+                    for (int j = 1; j <= mm; ++j) {
+                        if (j == mm && isR) continue;      // the meeting knot is written by the L lane
+                        const int kk = korig(j);
+                        if (kk < 1 || kk > M - 1) continue;
+                        double* o = a.xsol + (base3 + 3LL * kk) * R;
 #pragma unroll
-                for (int c = 0; c < R; ++c) {
-                    const double v = rec_ld(mm - j, NL + c);
-                    o[c] = (isR && (c & 1)) ? -v : v;
+                        for (int c = 0; c < R; ++c) {
+                            const double v = rec_ld(mm - j, NL + c);
+                            o[c] = (isR && (c & 1)) ? -v : v;
+                        }
+                    }
+                }
+            } else {
+                // own segment j joins own knots j (slot m - j) and j + 1 (slot m - j - 1; own knot 0 is the boundary knot x0): Hermite data back in
+                // the ORIGINAL frame (the reversed lane flips the odd derivatives and swaps the ends), then the same segment_coeffs_det on the
+                // same numbers corridor_emit_kernel would read back from xsol
+                constexpr int NC = 2 * R;
+                const bool al16 = (reinterpret_cast<uintptr_t>(aa.coeff) & 15u) == 0;
+                const bool whole = !WS && a.uniform >= 2 && al16 && __ballot(act && !finish) == 0ull;
+                if (whole) {
+                    // the whole wave hands over in this trip (the rule: one verifying solve), every slot on chip: the coefficients go through LDS --
+                    // over the sweep records nobody needs any more, [pair][segment][2 R] -- and leave as linear 16-byte-per-lane stores, whole lines
+                    const int Mu = a.uniform;
+                    double X[NT + 1][R];
+#pragma unroll
+                    for (int s = 0; s <= NT; ++s) {
+#pragma unroll
+                        for (int q = 0; q < R; ++q) X[s][q] = x0[q];
+                        if (s < NT && s < mm) {
+#pragma unroll
+                            for (int q = 0; q < R; ++q) X[s][q] = RL(s, NL + q);
+                        }
+#pragma unroll
+                        for (int q = 1; q < R; q += 2) X[s][q] = isR ? -X[s][q] : X[s][q];
+                    }
+                    wave_lds_sync();
+                    bool finite = true;
+                    double* const stage = s_rec + (size_t)(lane >> 1) * Mu * NC;
+#pragma unroll
+                    for (int s = 1; s <= NT; ++s) {
+                        const int j = mm - s;
+                        if (s <= mm && emitp) {
+                            const int sg = isR ? M - 1 - j : j;
+                            double ys[ND], ye[ND], c[NC];
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) { ys[d] = isR ? X[s - 1][d + 1] : X[s][d + 1]; ye[d] = isR ? X[s][d + 1] : X[s - 1][d + 1]; }
+                            const double Tk = a.times[s0 + sg];
+                            segment_coeffs_det<R>(isR ? X[s - 1][0] : X[s][0], ys, isR ? X[s][0] : X[s - 1][0], ye, Tk, fast_rcp(Tk), c);
+                            finite = finite && (fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY);
+#pragma unroll
+                            for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(stage + sg * NC + q) = make_double2(c[q], c[q + 1]);
+                        }
+                    }
+                    if (emitp && !finite) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
+                    wave_lds_sync();
+                    const int PP = Mu * R;                                   // 16-byte pieces per problem
+                    const unsigned inv = 0xFFFFFFFFu / (unsigned)PP + 1u;    // t / PP = (t * inv) >> 32 for t < 2^16
+                    const int gi = emitp ? (int)g : -1;
+                    for (int t0 = 0; t0 < 32 * PP; t0 += 64) {
+                        const int t = t0 + lane;
+                        const int pr = (int)(((unsigned long long)(unsigned)t * inv) >> 32);
+                        const int gp = __shfl(gi, 2 * (pr < 32 ? pr : 31), 64);
+                        if (pr < 32 && gp >= 0) {
+                            const int off = t - pr * PP;
+                            const double2 v = *reinterpret_cast<const double2*>(s_rec + 2 * (size_t)t);
+                            *reinterpret_cast<double2*>(aa.coeff + (size_t)gp * Mu * NC + 2 * off) = v;
+                        }
+                    }
+                    wave_lds_sync();
+                } else {
+                    bool finite = true;
+                    if (emitp && single) {
+                        if (!isR) {      // no free knot: the polynomial of the boundary data
+                            double ys[ND], ye[ND], c[NC];
+                            const double* bc = a.bc + (size_t)b * 2 * ND * 3 + ax;
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) { ys[d] = x0[d + 1]; ye[d] = bc[(ND + d) * 3]; }
+                            const double Tk = a.times[s0];
+                            segment_coeffs_det<R>(x0[0], ys, a.waypoints[base3 + 3 * M], ye, Tk, fast_rcp(Tk), c);
+                            finite = (fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY);
+                            double* o = aa.coeff + ((size_t)3 * s0 + (size_t)ax * M) * NC;
+#pragma unroll
+                            for (int q = 0; q < NC; ++q) o[q] = c[q];
+                        }
+                    } else {
+                        const int me = emitp ? mm : -1;
+                        double xn[R];
+#pragma unroll
+                        for (int q = 0; q < R; ++q) xn[q] = 0.0;
+                        for (int s = 0; s <= me; ++s) {
+                            const int j = mm - s;
+                            double xo[R];
+#pragma unroll
+                            for (int q = 0; q < R; ++q) xo[q] = x0[q];
+                            if (s < mm) {
+#pragma unroll
+                                for (int q = 0; q < R; ++q) xo[q] = rec_ld(s, NL + q);
+                            }
+#pragma unroll
+                            for (int q = 1; q < R; q += 2) xo[q] = isR ? -xo[q] : xo[q];     // back to the original frame
+                            if (s >= 1) {
+                                const int sg = isR ? M - 1 - j : j;                           // original segment of own segment j
+                                double ys[ND], ye[ND], c[NC];
+#pragma unroll
+                                for (int d = 0; d < ND; ++d) { ys[d] = isR ? xn[d + 1] : xo[d + 1]; ye[d] = isR ? xo[d + 1] : xn[d + 1]; }
+                                const double Tk = a.times[s0 + sg];
+                                segment_coeffs_det<R>(isR ? xn[0] : xo[0], ys, isR ? xo[0] : xn[0], ye, Tk, fast_rcp(Tk), c);
+                                finite = finite && (fabs(c[NC - 1]) < INFINITY) && (fabs(c[R]) < INFINITY);
+                                double* o = aa.coeff + ((size_t)3 * s0 + (size_t)ax * M + sg) * NC;
+                                if (al16) {
+#pragma unroll
+                                    for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(o + q) = make_double2(c[q], c[q + 1]);
+                                } else {
+#pragma unroll
+                                    for (int q = 0; q < NC; ++q) o[q] = c[q];
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < R; ++q) xn[q] = xo[q];
+                        }
+                    }
+                    if (emitp && !finite) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);
                 }
             }
-            if (!isR) {
+            if (emitp && !isR) {
                 if (capped) atomicMin(&a.status[b], (int32_t)(fail != 0 ? fail : (int)UAVQP_MAX_ITER_REACHED));     // (UAVQP_PRIMAL_INFEASIBLE < UAVQP_MAX_ITER_REACHED: an infeasible axis decides; 0 is no status: a capped path that set no verdict reads "undecided")
                 if (a.iters) atomicMax(&a.iters[b], (int32_t)it);
                 if (a.active) {
@@ -983,6 +1142,8 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     }
                 }
             }
+        }
+        if (finish) {
             g = -1;
             m = 0;
         }

@@ -31,7 +31,7 @@ struct RowsDualArgs {
     unsigned long long* warm_rows;   // [problem][2 K]: (active, upper) per row slot, bit s = segment s -- zeroed by the host, written for handled ones
     unsigned char* need_phase1;      // [n_traj]: 1 = not handled here
     unsigned int* n_phase1;          // their number (zeroed by the host)
-    const double* gfun;              // [segment][K][2 R]: g_l, g_r of every row (rows_gfun_kernel, launched before this kernel)
+    const double* gfun;              // [segment][K][2 R]: g_l, g_r of every row (rows_prep_kernel, launched before this kernel)
     const double* kdF;               // the chain records of rows_chain_kernel (launched before this kernel), one array per half, knot-major:
     const double* kdB;               // half h of knot k of trajectory b at kd_h + (k - 1) * kd_plane + b * rows_chain_half_mem(R)
     long long kd_plane;

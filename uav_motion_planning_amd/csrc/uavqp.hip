@@ -1079,10 +1079,12 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     // starts from the empty set).
     const bool warm = d_corr_lo != nullptr && ctx->settings.warm_start != 0;
     const int K_ = rows_per_segment;
+    const int K = rows_per_segment, Bk = r + K;
+    const bool pair_kernel = ctx->settings.rows_lanes_per_problem != 1;
     // Round 4: the starting set of boxes AND rows from the position-space dual method on the refined time grid (qp_rows_dual.h: a row is a
     // bound on a component of a knot inserted at its time); trajectories it does not take (rows at tau = 0, too many constraints) go
     // through the box phase as before.  uavqp_settings.corridor_initial_guess != 2 or warm_start = 0 switch it off.
-    const bool prelude = ctx->settings.corridor_initial_guess == 2 && ctx->settings.warm_start != 0 && ctx->settings.rows_lanes_per_problem != 1 &&
+    const bool prelude = ctx->settings.corridor_initial_guess == 2 && ctx->settings.warm_start != 0 && pair_kernel &&
                          Mmax >= 2 && (Mmax - 1) + K_ * Mmax <= 48;
     if (warm || prelude) {
         if ((size_t)n_traj * 6 > ctx->rows_warm_count) {
@@ -1094,21 +1096,45 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
             ctx->rows_warm_count = (size_t)n_traj * 6;
         }
     }
+    const long long total_seg = rows - n_traj;
+    const long long pairs = 3LL * n_traj;
     unsigned long long* d_warm_rows = nullptr;
     unsigned char* d_need_phase1 = nullptr;
     double* d_gfun_pre = nullptr;
     unsigned int* d_n_phase1 = nullptr;
+    unsigned int* d_queue = nullptr;
+    unsigned long long* d_desc = nullptr;
+    int32_t* d_status_box = nullptr;
     int32_t* d_cp1 = nullptr;
     int* d_na1 = nullptr;
-    if (prelude) {
-        const size_t b_wr = align256(sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_), b_np = align256((size_t)n_traj);
-        const size_t b_gf = align256(sizeof(double) * (size_t)(rows - n_traj) * K_ * 2 * r);     // row functionals: made here, used by the prelude AND the rows kernel
+    double* d_kd = nullptr;
+    size_t b_kd = 0;
+    long long kd_plane = 0;
+    uavqp::RowsArgs a;
+    a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax;
+    a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 12 * Mmax * (1 + K) + 30;
+    a.eps_prim_inf = ctx->settings.eps_prim_inf;
+    a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
+    a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.row_tau = d_row_tau; a.row_deriv = d_row_deriv; a.row_lo = d_row_lo; a.row_hi = d_row_hi;
+    a.status = d_status_out; a.iters = d_iters_out; a.active = (unsigned long long*)d_active_out;
+    a.xsol = nullptr; a.ws = nullptr; a.queue = nullptr; a.warm = nullptr; a.warm_rows = nullptr;
+    uavqp::Rows2Args aa{};
+    if (pair_kernel) {
+        // Round 6: everything the step keeps across its launches lives in ONE persistent allocation (rows_warm2: the box phase in the middle
+        // re-uses ctx->ws), and rows_prep_kernel is the step's FIRST kernel: validation + permanent masks as before, and with them the row
+        // functionals (was rows_gfun_kernel: a second pass over the same rows), the initial status / iteration counts (was fill_i32_kernel + a
+        // memset) and the clearing of what the prelude only writes for the trajectories it takes (was two memsets).
+        const size_t b_wr = prelude ? align256(sizeof(uint64_t) * (size_t)n_traj * 3 * 2 * K_) : 0, b_np = prelude ? align256((size_t)n_traj) : 0;
+        const size_t b_ctr = 512;                                                                  // [0, 256): the prelude's counters; [256, 512): the pair kernel's queue
+        const size_t b_gf = align256(sizeof(double) * (size_t)total_seg * K_ * 2 * r);             // row functionals: made once, used by the prelude AND the rows kernel
         // chain records (rows_chain_kernel): two halves, knot-major planes of n_traj (padded to whole waves) rows each, knots 1 .. Mmax - 1 <= 31
         const int kd_planes = Mmax - 1 < 1 ? 1 : (Mmax - 1 > 31 ? 31 : Mmax - 1);
-        const long long kd_plane = ((long long)n_traj + 63) / 64 * 64 * uavqp::rows_chain_half_mem(r);
-        const size_t b_kd = 2 * align256(sizeof(double) * (size_t)kd_planes * (size_t)kd_plane);
-        const size_t b_cp = align256(sizeof(int32_t) * (size_t)n_traj) + 256;     // compacted order of the box phase + its count
-        const size_t need = b_wr + b_np + 256 + b_gf + b_kd + b_cp;
+        kd_plane = ((long long)n_traj + 63) / 64 * 64 * uavqp::rows_chain_half_mem(r);
+        b_kd = prelude ? 2 * align256(sizeof(double) * (size_t)kd_planes * (size_t)kd_plane) : 0;
+        const size_t b_cp = prelude ? align256(sizeof(int32_t) * (size_t)n_traj) + 256 : 0;       // compacted order of the box phase + its count
+        const size_t b_desc = align256(sizeof(unsigned long long) * (size_t)pairs * (2 + 2 * K));
+        const size_t b_sb = warm ? align256(sizeof(int32_t) * (size_t)n_traj) : 0;                 // the box phase's statuses (not the step's)
+        const size_t need = b_wr + b_np + b_ctr + b_gf + b_kd + b_cp + b_desc + b_sb;
         if (need > ctx->rows_warm2_bytes) {
             UAVQP_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->rows_warm2) UAVQP_HIP(hipFree(ctx->rows_warm2));
@@ -1117,28 +1143,31 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
             UAVQP_HIP(hipMalloc((void**)&ctx->rows_warm2, need));
             ctx->rows_warm2_bytes = need;
         }
-        d_warm_rows = (unsigned long long*)ctx->rows_warm2;
-        d_need_phase1 = (unsigned char*)ctx->rows_warm2 + b_wr;
-        d_n_phase1 = (unsigned int*)((char*)ctx->rows_warm2 + b_wr + b_np);
-        d_gfun_pre = (double*)((char*)ctx->rows_warm2 + b_wr + b_np + 256);
-        double* const d_kd = (double*)((char*)ctx->rows_warm2 + b_wr + b_np + 256 + b_gf);
-        d_cp1 = (int32_t*)((char*)ctx->rows_warm2 + b_wr + b_np + 256 + b_gf + b_kd);
-        d_na1 = (int*)((char*)d_cp1 + align256(sizeof(int32_t) * (size_t)n_traj));
-        UAVQP_HIP(hipMemsetAsync(ctx->rows_warm2, 0, b_wr + b_np + 256, ctx->stream));
-        {
-            uavqp::Rows2Args ga{};
-            ga.r.row_tau = d_row_tau; ga.r.row_deriv = d_row_deriv; ga.r.times = d_times;
-            ga.gfun = d_gfun_pre;
-            const long long total_seg_ = rows - n_traj;
-            long long gg = (total_seg_ * K_ + 255) / 256;
-            if (gg > (long long)ctx->num_cus * 16) gg = (long long)ctx->num_cus * 16;
-            if (gg < 1) gg = 1;
-            if (r == 3 && K_ == 1) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<3, 1>), dim3((unsigned)gg), dim3(256), 0, ctx->stream, ga, total_seg_);
-            else if (r == 3) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<3, 2>), dim3((unsigned)gg), dim3(256), 0, ctx->stream, ga, total_seg_);
-            else if (K_ == 1) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<4, 1>), dim3((unsigned)gg), dim3(256), 0, ctx->stream, ga, total_seg_);
-            else hipLaunchKernelGGL((uavqp::rows_gfun_kernel<4, 2>), dim3((unsigned)gg), dim3(256), 0, ctx->stream, ga, total_seg_);
-        }
-        UAVQP_HIP(hipMemsetAsync(ctx->rows_warm, 0, sizeof(uint64_t) * (size_t)n_traj * 6, ctx->stream));
+        char* p = (char*)ctx->rows_warm2;
+        d_warm_rows = prelude ? (unsigned long long*)p : nullptr; p += b_wr;
+        d_need_phase1 = prelude ? (unsigned char*)p : nullptr; p += b_np;
+        d_n_phase1 = (unsigned int*)p; d_queue = (unsigned int*)(p + 256); p += b_ctr;
+        d_gfun_pre = (double*)p; p += b_gf;
+        d_kd = (double*)p; p += b_kd;
+        d_cp1 = prelude ? (int32_t*)p : nullptr;
+        d_na1 = prelude ? (int*)(p + align256(sizeof(int32_t) * (size_t)n_traj)) : nullptr; p += b_cp;
+        d_desc = (unsigned long long*)p; p += b_desc;
+        d_status_box = warm ? (int32_t*)p : nullptr;
+        a.queue = d_queue;
+        ctx->dbg_queue = a.queue;
+        aa.r = a;
+        aa.desc = d_desc; aa.gfun = d_gfun_pre; aa.prep_gfun = 1;
+        aa.init_warm_box = (warm || prelude) ? (unsigned long long*)ctx->rows_warm : nullptr;
+        aa.init_warm_rows = d_warm_rows;
+        aa.init_counters = d_n_phase1;                      // 128 words: the prelude's counters and the queue behind them
+        long long pgrid = ((long long)n_traj + 3) / 4;      // rows_prep_kernel: one trajectory per wave, four waves per block
+        if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
+        if (r == 3 && K == 1) hipLaunchKernelGGL((uavqp::rows_prep_kernel<3, 1>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);
+        else if (r == 3) hipLaunchKernelGGL((uavqp::rows_prep_kernel<3, 2>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);
+        else if (K == 1) hipLaunchKernelGGL((uavqp::rows_prep_kernel<4, 1>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);
+        else hipLaunchKernelGGL((uavqp::rows_prep_kernel<4, 2>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);
+    }
+    if (prelude) {
         uavqp::RowsDualArgs da{};
         da.r.n_traj = n_traj; da.r.uniform = uniform_segments; da.r.max_segments = Mmax;
         da.r.seg_offsets = d_seg_offsets; da.r.waypoints = d_waypoints; da.r.times = d_times; da.r.bc = d_bc;
@@ -1170,11 +1199,11 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     }
     if (warm) {
         // (with the prelude: only for the trajectories it did not take -- their dealing order is compacted here, where their count is known:
-        // usually zero, and then nothing is scanned)
+        // usually zero, and then nothing is scanned.  The box phase's statuses are its own: the step's statuses started in rows_prep_kernel)
         if (prelude) hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)nullptr, n_traj, (const int32_t*)nullptr,
                                         (const unsigned char*)d_need_phase1, d_cp1, d_na1, (const unsigned int*)d_n_phase1);
         const int rc1 = corridor_warm_impl(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times,
-                                           d_bc, d_corr_lo, d_corr_hi, d_coeff_out, d_status_out, nullptr, ctx->rows_warm, 0, rows - n_traj, nullptr,
+                                           d_bc, d_corr_lo, d_corr_hi, d_coeff_out, pair_kernel ? d_status_box : d_status_out, nullptr, ctx->rows_warm, 0, rows - n_traj, nullptr,
                                            nullptr, d_need_phase1, nullptr, nullptr, 0, prelude ? d_cp1 : nullptr, prelude ? d_na1 : nullptr);
         if (rc1 != UAVQP_OK) return rc1;
     }
@@ -1188,18 +1217,8 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         ctx->dbg_dual = g_rows_dbg;
     }
 #endif
-    const int K = rows_per_segment, Bk = r + K;
-    uavqp::RowsArgs a;
-    a.n_traj = n_traj; a.uniform = uniform_segments; a.max_segments = Mmax;
-    a.max_iter = ctx->settings.max_iter > 0 ? ctx->settings.max_iter : 12 * Mmax * (1 + K) + 30;
-    a.eps_prim_inf = ctx->settings.eps_prim_inf;
-    a.seg_offsets = d_seg_offsets; a.waypoints = d_waypoints; a.times = d_times; a.bc = d_bc;
-    a.corr_lo = d_corr_lo; a.corr_hi = d_corr_hi; a.row_tau = d_row_tau; a.row_deriv = d_row_deriv; a.row_lo = d_row_lo; a.row_hi = d_row_hi;
-    a.status = d_status_out; a.iters = d_iters_out; a.active = (unsigned long long*)d_active_out;
     a.warm = (warm || prelude) ? (const unsigned long long*)ctx->rows_warm : nullptr;
     a.warm_rows = prelude ? (const unsigned long long*)d_warm_rows : nullptr;
-    const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
-    const bool pair_kernel = ctx->settings.rows_lanes_per_problem != 1;
     int rc;
     if (pair_kernel) {
         // two lanes per problem, sweep state in LDS (qp_rows2.h): 80 KiB per single-wave workgroup = two waves per CU
@@ -1207,26 +1226,17 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         const int NT = uavqp::rows2_lds_knots(r, K);
         const int kown = (Mmax + 1) / 2;                       // own knots of the longer half, meeting knot included = state slots 0..kown-1
         const int ws_knots = kown > NT ? kown - NT : 0;
-        const long long pairs = 3LL * n_traj;
         long long grid = (pairs + 31) / 32;
         const long long max_grid = (long long)ctx->num_cus * uavqp::rows2_waves_per_cu();
         if (grid > max_grid) grid = max_grid;
         const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort;
-        const size_t b_desc = align256(sizeof(unsigned long long) * (size_t)pairs * (2 + 2 * K));
         const size_t b_order = deal_by_length ? align256(sizeof(int32_t) * (size_t)n_traj) + 2048 : 0;
         const size_t b_state = align256(sizeof(double) * (size_t)ws_knots * Fp * (size_t)grid * 64);
         const size_t b_lam = align256(sizeof(double) * (size_t)kown * 2 * NCN * (size_t)grid * 64);
-        const long long total_seg = rows - n_traj;
-        const size_t b_gfun = d_gfun_pre ? 0 : align256(sizeof(double) * (size_t)total_seg * K * 2 * r);
         const size_t b_redo = align256(sizeof(unsigned int) * (size_t)pairs);
-        rc = ensure_ws(ctx, b_xsol + 256 + b_desc + b_order + b_state + b_lam + b_gfun + b_redo);
+        rc = ensure_ws(ctx, 256 + b_order + b_state + b_lam + b_redo);
         if (rc != UAVQP_OK) return rc;
-        char* p = (char*)ctx->ws;
-        a.xsol = (double*)p; p += b_xsol;
-        a.queue = (unsigned int*)p; p += 256;
-        ctx->dbg_queue = a.queue;
-        uavqp::Rows2Args aa;
-        aa.desc = (unsigned long long*)p; p += b_desc;
+        char* p = (char*)ctx->ws + 256;
         aa.order = nullptr;
         if (deal_by_length) {
             int32_t* d_order = (int32_t*)p;
@@ -1243,32 +1253,27 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         p += b_order;
         a.ws = (double*)p; p += b_state;
         aa.lam = (double*)p; p += b_lam;
-        aa.gfun = d_gfun_pre ? d_gfun_pre : (double*)p;
-        p += b_gfun;
         aa.redo = (unsigned int*)p;
         aa.ws_knots = ws_knots;
         aa.lam_knots = kown;
-        UAVQP_HIP(hipMemsetAsync(a.queue, 0, 256, ctx->stream));
-        hipLaunchKernelGGL(uavqp::fill_i32_kernel, dim3((n_traj + 255) / 256), dim3(256), 0, ctx->stream, d_status_out, n_traj, (int32_t)UAVQP_SOLVED);
-        if (d_iters_out) UAVQP_HIP(hipMemsetAsync(d_iters_out, 0, sizeof(int32_t) * (size_t)n_traj, ctx->stream));
+        aa.coeff = d_coeff_out;                                 // the pair kernels write the polynomials themselves: no xsol, no emission launch
+        aa.prep_gfun = 0; aa.init_warm_box = nullptr; aa.init_warm_rows = nullptr; aa.init_counters = nullptr;
         aa.r = a;
-        long long pgrid = ((long long)n_traj + 3) / 4;          // rows_prep_kernel: one trajectory per wave, four waves per block
-        if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
-        long long ggrid = (total_seg * K + 255) / 256;
-        if (ggrid > (long long)ctx->num_cus * 16) ggrid = (long long)ctx->num_cus * 16;
-        if (ggrid < 1) ggrid = 1;
-        const long long grid2 = grid < (long long)ctx->num_cus ? grid : (long long)ctx->num_cus;     // (the redo list is short: one wave per CU at most)
+        // first pass: every problem.  With the prelude's starting sets it is the VERIFYING pass (one block solve, no dual state in HBM; what it
+        // does not confirm goes to the redo list); without them the general first pass.  Second pass (Goldfarb-Idnani's dependent-constraint
+        // route, and every problem the verifying pass handed on): the redo list -- empty as a rule (one wave per CU then; behind the
+        // verifying pass the full grid: its list may be long when the prelude did not take the batch)
+        const long long grid2 = prelude ? grid : (grid < (long long)ctx->num_cus ? grid : (long long)ctx->num_cus);
 #define UAVQP_ROWS2(RR, KK)                                                                                                                  \
     do {                                                                                                                                     \
-        hipLaunchKernelGGL((uavqp::rows_prep_kernel<RR, KK>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);                       \
-        if (!d_gfun_pre) hipLaunchKernelGGL((uavqp::rows_gfun_kernel<RR, KK>), dim3((unsigned)ggrid), dim3(256), 0, ctx->stream, aa, total_seg); \
-        /* first pass: every problem; second pass (Goldfarb-Idnani's dependent-constraint route): the few the first leaves on its redo list */ \
         if (ws_knots > 0) {                                                                                                                 \
-            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);         \
-            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, true>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa);         \
+            if (prelude) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, false, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa); \
+            else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);        \
+            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, true, false>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa);  \
         } else {                                                                                                                            \
-            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);        \
-            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, true>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa);        \
+            if (prelude) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, false, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa); \
+            else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);        \
+            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, true, false>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa); \
         }                                                                                                                                   \
     } while (0)
         if (r == 3 && K == 1) UAVQP_ROWS2(3, 1);
@@ -1277,6 +1282,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         else UAVQP_ROWS2(4, 2);
 #undef UAVQP_ROWS2
     } else {
+        const size_t b_xsol = align256(sizeof(double) * 3 * (size_t)r * (size_t)rows);
         const int F = Bk * (Bk + 1) / 2 + Bk + 2 * (1 + K);   // must match rows_solve_kernel's state layout
         long long grid = (3LL * n_traj + 63) / 64;
         const long long max_grid = (long long)ctx->num_cus * 4;
@@ -1295,17 +1301,17 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
             if (K == 1) hipLaunchKernelGGL((uavqp::rows_solve_kernel<4, 1>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL((uavqp::rows_solve_kernel<4, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
         }
-    }
-    // Hermite solution -> coefficients (the corridor solver's emission kernel; it reads the same fields)
-    uavqp::CorridorArgs e{};
-    e.n_traj = n_traj; e.uniform = uniform_segments; e.max_segments = Mmax; e.seg_offsets = d_seg_offsets; e.waypoints = d_waypoints;
-    e.times = d_times; e.bc = d_bc; e.coeff = d_coeff_out; e.status = d_status_out; e.xsol = ctx->ws;
-    const long long chunks = 3LL * (rows - n_traj);
-    long long egrid = (chunks + 255) / 256;
-    if (egrid > (long long)ctx->num_cus * 16) egrid = (long long)ctx->num_cus * 16;
-    if (chunks > 0) {
-        if (r == 3) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<3>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, e, chunks);
-        else hipLaunchKernelGGL((uavqp::corridor_emit_kernel<4>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, e, chunks);
+        // Hermite solution -> coefficients (the corridor solver's emission kernel; it reads the same fields) -- the one-lane cross-check kernel only
+        uavqp::CorridorArgs e{};
+        e.n_traj = n_traj; e.uniform = uniform_segments; e.max_segments = Mmax; e.seg_offsets = d_seg_offsets; e.waypoints = d_waypoints;
+        e.times = d_times; e.bc = d_bc; e.coeff = d_coeff_out; e.status = d_status_out; e.xsol = ctx->ws;
+        const long long chunks = 3LL * (rows - n_traj);
+        long long egrid = (chunks + 255) / 256;
+        if (egrid > (long long)ctx->num_cus * 16) egrid = (long long)ctx->num_cus * 16;
+        if (chunks > 0) {
+            if (r == 3) hipLaunchKernelGGL((uavqp::corridor_emit_kernel<3>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, e, chunks);
+            else hipLaunchKernelGGL((uavqp::corridor_emit_kernel<4>), dim3((unsigned)egrid), dim3(256), 0, ctx->stream, e, chunks);
+        }
     }
     UAVQP_HIP(hipGetLastError());
     return UAVQP_OK;
@@ -1935,6 +1941,18 @@ extern "C" int uavqp_comm_create(uavqp_ctx* ctx, int rank, int world, const void
     ctx->comm.comm = comm;
     ctx->comm.rank = rank;
     ctx->comm.world = world;
+    return UAVQP_OK;
+}
+
+extern "C" int uavqp_comm_info(const uavqp_ctx* ctx, int32_t* rank_out, int32_t* world_out) {
+    if (!ctx || (!rank_out && !world_out)) return UAVQP_ERR_INVALID_ARG;
+    if (!ctx->comm.comm) { g_last_error = "no communicator: call uavqp_comm_create first"; return UAVQP_ERR_INVALID_ARG; }
+    // asked of RCCL, not remembered: ncclCommUserRank / ncclCommCount of the communicator the ctx owns
+    int rk = -1, wd = -1;
+    UAVQP_RCCL(uavqp::rccl().CommUserRank(ctx->comm.comm, &rk));
+    UAVQP_RCCL(uavqp::rccl().CommCount(ctx->comm.comm, &wd));
+    if (rank_out) *rank_out = rk;
+    if (world_out) *world_out = wd;
     return UAVQP_OK;
 }
 

@@ -19,6 +19,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // what RCCL itself says the communicator is (uavqp_comm_info)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -53,6 +55,8 @@ struct RcclApi {
         GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
         CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommCount = (decltype(CommCount))sym("ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))sym("ncclCommUserRank");
         AllGather = (decltype(AllGather))sym("ncclAllGather");
         Send = (decltype(Send))sym("ncclSend");
         Recv = (decltype(Recv))sym("ncclRecv");

@@ -204,6 +204,12 @@ class Context:
         _lib.check(_lib.lib().uavqp_comm_create(self._h, int(rank), int(world), buf), "uavqp_comm_create")
         self.rank, self.world = int(rank), int(world)
 
+    def comm_info(self):
+        """(rank, world) of this ctx's communicator as RCCL itself reports them (ncclCommUserRank / ncclCommCount)."""
+        rk, wd = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        _lib.check(_lib.lib().uavqp_comm_info(self._h, ctypes.byref(rk), ctypes.byref(wd)), "uavqp_comm_info")
+        return int(rk.value), int(wd.value)
+
     def comm_destroy(self):
         _lib.check(_lib.lib().uavqp_comm_destroy(self._h), "uavqp_comm_destroy")
 
