@@ -36,8 +36,16 @@ namespace uavqp {
 #ifndef UAVQP_ROWS2_LDS_KB
 #define UAVQP_ROWS2_LDS_KB 80   // LDS per single-wave workgroup: 80 KiB = two waves per CU with the whole state of a 16-segment problem on chip
 #endif
-constexpr int rows2_waves_per_cu() { return 160 / UAVQP_ROWS2_LDS_KB; }
-constexpr int rows2_lds_knots(int R, int K) { return (UAVQP_ROWS2_LDS_KB * 1024) / (64 * 8 * ((R + K) * (R + K + 1) / 2 + (R + K))); }
+// Round 6: the LDS of the VERIFYING pass is its own knob.  Measured on config 3 + K = 2 (docs/measurement_log.md R6.1): 80 / 53 / 40 / 32 / 26 KiB per wave
+// = 2 / 3 / 4 / 5 / 6 waves per CU: 426 / 405 / 364 / 373 / 397 us -- the kernel is bound by the dependent issue of a single wave per SIMD, and at 40 KiB
+// every SIMD has one; but the sweep records that no longer fit go through the HBM workspace: + 0.9 GB of counter traffic (2.05 -> 2.98 GB per step) for
+// - 0.08 ms (2.17 -> 2.09 ms).  Default: everything on chip (80); -DUAVQP_ROWS2_VER_LDS_KB=40 buys the time with the bytes.
+#ifndef UAVQP_ROWS2_VER_LDS_KB
+#define UAVQP_ROWS2_VER_LDS_KB 80
+#endif
+constexpr int rows2_lds_kb(bool ver) { return ver ? UAVQP_ROWS2_VER_LDS_KB : UAVQP_ROWS2_LDS_KB; }
+constexpr int rows2_waves_per_cu(bool ver = false) { return 160 / rows2_lds_kb(ver); }
+constexpr int rows2_lds_knots(int R, int K, bool ver = false) { return (rows2_lds_kb(ver) * 1024) / (64 * 8 * ((R + K) * (R + K + 1) / 2 + (R + K))); }
 
 struct Rows2Args {
     RowsArgs r;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
     static_assert(!(VER && GI), "the verifying pass leaves everything beyond one solve to the GI = true launch");
     const RowsArgs& a = aa.r;
     constexpr int ND = R - 1, B = R + K, NL = B * (B + 1) / 2, NCN = 1 + K, F = NL + B, BM = R + 2 * K;
-    constexpr int NT = rows2_lds_knots(R, K);
+    constexpr int NT = rows2_lds_knots(R, K, VER);
     constexpr int NONE = 1 << 30;
     __shared__ __attribute__((aligned(16))) double s_rec[NT * F * 64];
     const int lane = threadIdx.x;
@@ -1021,19 +1029,22 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 // same numbers corridor_emit_kernel would read back from xsol
                 constexpr int NC = 2 * R;
                 const bool al16 = (reinterpret_cast<uintptr_t>(aa.coeff) & 15u) == 0;
-                const bool whole = !WS && a.uniform >= 2 && al16 && __ballot(act && !finish) == 0ull;
+                // (NX: own knots per lane the staged path handles -- all of the LDS slots, plus, in a kernel with workspace slots, those up to 8;
+                //  the staging area [32 pairs][segments][2 R] must fit the LDS of the records)
+                constexpr int NX = WS ? (NT > 8 ? NT : 8) : NT;
+                const bool whole = a.uniform >= 2 && (a.uniform + 1) / 2 <= NX && 32 * a.uniform * NC <= NT * F * 64 && al16 && __ballot(act && !finish) == 0ull;
                 if (whole) {
-                    // the whole wave hands over in this trip (the rule: one verifying solve), every slot on chip: the coefficients go through LDS --
-                    // over the sweep records nobody needs any more, [pair][segment][2 R] -- and leave as linear 16-byte-per-lane stores, whole lines
+                    // the whole wave hands over in this trip (the rule: one verifying solve): the coefficients go through LDS -- over the sweep records
+                    // nobody needs any more, [pair][segment][2 R] -- and leave as linear 16-byte-per-lane stores, whole lines
                     const int Mu = a.uniform;
-                    double X[NT + 1][R];
+                    double X[NX + 1][R];
 #pragma unroll
-                    for (int s = 0; s <= NT; ++s) {
+                    for (int s = 0; s <= NX; ++s) {
 #pragma unroll
                         for (int q = 0; q < R; ++q) X[s][q] = x0[q];
-                        if (s < NT && s < mm) {
+                        if (s < NX && s < mm) {
 #pragma unroll
-                            for (int q = 0; q < R; ++q) X[s][q] = RL(s, NL + q);
+                            for (int q = 0; q < R; ++q) X[s][q] = (s < NT) ? RL(s < NT ? s : 0, NL + q) : RG(s < NT ? NT : s, NL + q);
                         }
 #pragma unroll
                         for (int q = 1; q < R; q += 2) X[s][q] = isR ? -X[s][q] : X[s][q];
@@ -1042,7 +1053,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     bool finite = true;
                     double* const stage = s_rec + (size_t)(lane >> 1) * Mu * NC;
 #pragma unroll
-                    for (int s = 1; s <= NT; ++s) {
+                    for (int s = 1; s <= NX; ++s) {
                         const int j = mm - s;
                         if (s <= mm && emitp) {
                             const int sg = isR ? M - 1 - j : j;

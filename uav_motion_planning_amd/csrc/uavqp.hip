@@ -1223,15 +1223,19 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     if (pair_kernel) {
         // two lanes per problem, sweep state in LDS (qp_rows2.h): 80 KiB per single-wave workgroup = two waves per CU
         const int Fp = Bk * (Bk + 1) / 2 + Bk, NCN = 1 + K;
-        const int NT = uavqp::rows2_lds_knots(r, K);
         const int kown = (Mmax + 1) / 2;                       // own knots of the longer half, meeting knot included = state slots 0..kown-1
-        const int ws_knots = kown > NT ? kown - NT : 0;
-        long long grid = (pairs + 31) / 32;
-        const long long max_grid = (long long)ctx->num_cus * uavqp::rows2_waves_per_cu();
+        // the general passes keep 80 KiB of sweep records per wave (two waves per CU); the verifying pass 40 KiB (four: one per SIMD) and the rest in
+        // the HBM workspace -- each pass has its own count of workspace knots and its own grid
+        const int NT = uavqp::rows2_lds_knots(r, K, false), NTv = uavqp::rows2_lds_knots(r, K, true);
+        const int ws_knots = kown > NT ? kown - NT : 0, ws_knots_v = kown > NTv ? kown - NTv : 0;
+        long long grid = (pairs + 31) / 32, grid_v = grid;
+        const long long max_grid = (long long)ctx->num_cus * uavqp::rows2_waves_per_cu(false), max_grid_v = (long long)ctx->num_cus * uavqp::rows2_waves_per_cu(true);
         if (grid > max_grid) grid = max_grid;
+        if (grid_v > max_grid_v) grid_v = max_grid_v;
         const bool deal_by_length = uniform_segments == 0 && n_traj >= 64 && ctx->settings.ragged_window_sort;
         const size_t b_order = deal_by_length ? align256(sizeof(int32_t) * (size_t)n_traj) + 2048 : 0;
-        const size_t b_state = align256(sizeof(double) * (size_t)ws_knots * Fp * (size_t)grid * 64);
+        const size_t b_state_g = sizeof(double) * (size_t)ws_knots * Fp * (size_t)grid * 64, b_state_v = prelude ? sizeof(double) * (size_t)ws_knots_v * Fp * (size_t)grid_v * 64 : 0;
+        const size_t b_state = align256(b_state_g > b_state_v ? b_state_g : b_state_v);
         const size_t b_lam = align256(sizeof(double) * (size_t)kown * 2 * NCN * (size_t)grid * 64);
         const size_t b_redo = align256(sizeof(unsigned int) * (size_t)pairs);
         rc = ensure_ws(ctx, 256 + b_order + b_state + b_lam + b_redo);
@@ -1264,17 +1268,20 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         // route, and every problem the verifying pass handed on): the redo list -- empty as a rule (one wave per CU then; behind the
         // verifying pass the full grid: its list may be long when the prelude did not take the batch)
         const long long grid2 = prelude ? grid : (grid < (long long)ctx->num_cus ? grid : (long long)ctx->num_cus);
+        uavqp::Rows2Args av = aa;                               // the verifying pass: its own workspace split
+        av.ws_knots = ws_knots_v;
 #define UAVQP_ROWS2(RR, KK)                                                                                                                  \
     do {                                                                                                                                     \
-        if (ws_knots > 0) {                                                                                                                 \
-            if (prelude) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, false, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa); \
-            else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);        \
-            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, true, false>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa);  \
+        if (prelude) {                                                                                                                      \
+            if (ws_knots_v > 0) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, false, true>), dim3((unsigned)grid_v), dim3(64), 0, ctx->stream, av); \
+            else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, false, true>), dim3((unsigned)grid_v), dim3(64), 0, ctx->stream, av);               \
+        } else if (ws_knots > 0) {                                                                                                          \
+            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);  \
         } else {                                                                                                                            \
-            if (prelude) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, false, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa); \
-            else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa);        \
-            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, true, false>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa); \
+            hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, false, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, aa); \
         }                                                                                                                                   \
+        if (ws_knots > 0) hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, true, true, false>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa); \
+        else hipLaunchKernelGGL((uavqp::rows_pair_kernel<RR, KK, false, true, false>), dim3((unsigned)grid2), dim3(64), 0, ctx->stream, aa);           \
     } while (0)
         if (r == 3 && K == 1) UAVQP_ROWS2(3, 1);
         else if (r == 3) UAVQP_ROWS2(3, 2);
