@@ -37,6 +37,8 @@
 #endif
 
 // the solver families are compiled as their own translation units (k_*.hip): here their instantiations are only DECLARED
+// (-DUAVQP_SINGLE_TU: a build that includes this file whole -- tools/ubench/twisted_phases.hip -- instantiates everything itself)
+#ifndef UAVQP_SINGLE_TU
 #include "kernel_instances.h"
 UAVQP_INSTANCES_TWISTED3
 UAVQP_INSTANCES_TWISTED4
@@ -49,6 +51,7 @@ UAVQP_INSTANCES_ROWS41
 UAVQP_INSTANCES_ROWS42
 UAVQP_INSTANCES_ROWS_DUAL
 UAVQP_INSTANCES_CLOUD
+#endif
 
 namespace uavqp {
 // Specialised (R, M) instantiations of the register-resident kernel; everything else takes the generic one.
