@@ -7,7 +7,7 @@
 # REFUSES to run when libuavqp.so was not built from the sources next to it (summaries that predate the last kernel commits):
 # the library reports the hash of its sources (uavqp_version()), `make src-hash` recomputes it from the files on this box.  The hash goes
 # into <out>/MANIFEST.txt; `git log -1 --format=%h` of the commit whose tree has that hash is what the summaries belong to.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 LIB_HASH=$(python - <<PY
@@ -64,6 +64,8 @@ python tools/config1_latency.py > $O/config1_latency.txt 2>> $O/other_configs.er
 [ -x tools/ubench/axis_latency ] && ( echo "C ABI, no Python (tools/ubench/axis_latency.cpp):"; tools/ubench/axis_latency 3000 ) >> $O/config1_latency.txt 2>&1
 # soaks: equality / corridor, general rows (every unsolved draw cross-checked against the OSQP port: exit code 1 on a feasible one), pipeline
 ( python tools/soak.py 300 95; python tools/soak_rows.py 150 95; python tools/soak_rows.py 150 96; python tools/soak_aux.py 100 95 ) > $O/soak.txt 2>&1
+# round 6: the rows soak also at the facade's eps_prim_inf = 1e-3 and with the reason codes of a -DUAVQP_ROWS_REASON build (tools/soak_rows_r6.sh; fresh seeds)
+tools/soak_rows_r6.sh $O/soak_rows 150 97 98 > $O/soak_rows_r6.txt 2>&1
 ( python tools/soak_pipeline.py 80 15 ) > $O/soak_pipeline.txt 2>&1
 if [ -x tools/ubench/tw/h_16 ]; then
   ( cd tools/ubench/tw; for v in h_16 h_base h_t32; do echo "== $v 4096"; ./$v 4096; done; echo "== h_base 8192"; ./h_base 8192; echo "== h_t32 65536"; ./h_t32 65536 12 ) > $O/headline_timeline.txt 2>&1
