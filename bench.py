@@ -805,11 +805,20 @@ def run(args):
             # solve the exchange (every rank receives the whole batch) is the step: serial, the N-rank value is the gather's; overlapped it
             # is max(solve, gather) per step -- the only way "near-linear scaling" can survive the exchange
             try:
-                s2, c2 = make_slot()                      # the solves of this leg: their own ctx and stream; the gathers stay on gctx's stream
-                launch(c2, 0)
-                torch.cuda.synchronize()
-                KO = max(K, 20)
-                fulls = [torch.zeros(tot, dtype=torch.float64, device=dev) for _ in range(2)]
+                setup_err = None
+                try:
+                    s2, c2 = make_slot()                  # the solves of this leg: their own ctx and stream; the gathers stay on gctx's stream
+                    launch(c2, 0)
+                    torch.cuda.synchronize()
+                    KO = max(K, 20)
+                    fulls = [torch.zeros(tot, dtype=torch.float64, device=dev) for _ in range(2)]
+                except Exception as e:  # noqa: BLE001
+                    setup_err = repr(e)
+                # every rank runs the leg or none does: a rank that dropped out alone would leave the others waiting in a collective
+                tf = torch.tensor([0 if setup_err else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(tf, op=dist.ReduceOp.MIN)
+                if int(tf.item()) == 0:
+                    raise RuntimeError(setup_err or "another rank could not set the overlapped leg up")
                 ow = []
                 for _ in range(5):
                     fence()
@@ -883,6 +892,8 @@ def run(args):
             parity["checked"] = (f"output of the LAST timed step (buffer set {cap['set']} of {S}), copied back after the timed region; "
                                  + ("every trajectory" if n_par >= n_local else f"{sample.size} drawn trajectories (both ends of the batch included)"))
             parity["buffer_sets_bitwise_equal"] = cap["sets_equal"]
+            if world > 1:
+                parity["checked"] += f"; rank 0's shard of {world}"
         traffic = measure_traffic(args) if (world == 1 and not args.no_traffic) else None
         # FP64 roof ("report FP64 FLOP/s next to GB/s") and per-kernel view, from counters / traces of child runs
         fp64 = kernels = None

@@ -96,3 +96,6 @@ def test_bench_exchange_leg_goes_through_the_ctx_communicator(config):
     g = d["allgather"]
     assert g["through"].startswith("uavqp_allgather_coeffs (RCCL, ctx communicator)"), g["through"]
     assert g["own_shard_intact"] is True and g["ms"] > 0 and d["n_gpus"] == 1 and d["value"] > 0
+    # round 6: RCCL's own view of the communicator, and the overlapped leg (gather of step i beside the solve of step i + 1) on every config
+    assert g["rccl_world"] == 1 and g["rccl_rank"] == 0
+    assert g["value_with_gather_overlapped"] and g["overlapped"]["own_shard_intact"], g.get("overlapped")

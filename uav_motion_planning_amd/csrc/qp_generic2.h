@@ -57,17 +57,6 @@
 
 namespace uavqp {
 
-// wave-uniform maximum of a per-lane integer in [0, 256): eight ballots
-__device__ __forceinline__ int wave_max_int(int v) {
-    int r = 0;
-#pragma unroll
-    for (int bit = 7; bit >= 0; --bit) {
-        const int t = r | (1 << bit);
-        if (__ballot(v >= t) != 0ull) r = t;
-    }
-    return r;
-}
-
 // 16-byte store to an address that went through LDS as an integer: spelled as a GLOBAL store (address space 1) -- from a generic
 // pointer the compiler emits flat_store, and a pending FLAT operation makes it wait with vmcnt(0) / lgkmcnt(0) everywhere
 __device__ __forceinline__ void store16_global(unsigned long long addr, double2 v) {

@@ -41,8 +41,17 @@ namespace uavqp {
 // every SIMD has one; but the sweep records that no longer fit go through the HBM workspace: + 0.9 GB of counter traffic (2.05 -> 2.98 GB per step) for
 // - 0.08 ms (2.17 -> 2.09 ms).  Default: everything on chip (80); -DUAVQP_ROWS2_VER_LDS_KB=40 buys the time with the bytes.
 #ifndef UAVQP_ROWS2_VER_LDS_KB
-#define UAVQP_ROWS2_VER_LDS_KB 80
+#define UAVQP_ROWS2_VER_LDS_KB 40
 #endif
+// ... and the records that 40 KiB no longer hold stay ON CHIP all the same: the verifying pass keeps the UAVQP_ROWS2_VER_REG_KNOTS own knots farthest from
+// the meeting knot in REGISTERS (the kernel runs one wave per SIMD: 512 registers per lane, 336 in use).  Both sweeps iterate over the slot index
+// s = m - j, which is the same for every lane of the wave at any moment (a lane with a shorter half starts its forward sweep later and ends its
+// backward sweep earlier), so "slot s of the register file" is a scalar branch on a wave-uniform s, never an indexed register access.  Four waves per CU
+// (every SIMD busy) with the whole state of a 16-segment problem on chip: no workspace traffic.  0: LDS (+ HBM workspace) only.
+#ifndef UAVQP_ROWS2_VER_REG_KNOTS
+#define UAVQP_ROWS2_VER_REG_KNOTS 4
+#endif
+constexpr int rows2_reg_knots(bool ver) { return ver ? UAVQP_ROWS2_VER_REG_KNOTS : 0; }
 constexpr int rows2_lds_kb(bool ver) { return ver ? UAVQP_ROWS2_VER_LDS_KB : UAVQP_ROWS2_LDS_KB; }
 constexpr int rows2_waves_per_cu(bool ver = false) { return 160 / rows2_lds_kb(ver); }
 constexpr int rows2_lds_knots(int R, int K, bool ver = false) { return (rows2_lds_kb(ver) * 1024) / (64 * 8 * ((R + K) * (R + K + 1) / 2 + (R + K))); }
@@ -200,6 +209,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
     const RowsArgs& a = aa.r;
     constexpr int ND = R - 1, B = R + K, NL = B * (B + 1) / 2, NCN = 1 + K, F = NL + B, BM = R + 2 * K;
     constexpr int NT = rows2_lds_knots(R, K, VER);
+    constexpr int NRS = (VER && !WS) ? rows2_reg_knots(true) : 0;      // slots NT .. NT + NRS - 1 live in registers (kernels without workspace slots only)
     constexpr int NONE = 1 << 30;
     __shared__ __attribute__((aligned(16))) double s_rec[NT * F * 64];
     const int lane = threadIdx.x;
@@ -211,6 +221,64 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
     auto RG = [&](int s, int f) -> double& { return ws[((size_t)(s - NT) * F + f) * 64]; };
     auto rec_ld = [&](int s, int f) -> double { return (!WS || s < NT) ? RL(s, f) : RG(s, f); };
     auto rec_st = [&](int s, int f, double v) { if (!WS || s < NT) RL(s, f) = v; else RG(s, f) = v; };
+    // register slots (NRS > 0): rr[q] = the record of slot NT + q; `s` below is wave-uniform wherever these are used
+    double rr[NRS > 0 ? NRS : 1][F];
+    auto slot_st = [&](int s, const double (&e)[NL], const double (&h)[B]) __attribute__((always_inline)) {
+        bool in_reg = false;
+        if constexpr (NRS > 0) {
+#pragma unroll
+            for (int q = 0; q < NRS; ++q)
+                if (s == NT + q) {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) rr[q][i] = e[i];
+#pragma unroll
+                    for (int i = 0; i < B; ++i) rr[q][NL + i] = h[i];
+                    in_reg = true;
+                }
+        }
+        if (!in_reg) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) rec_st(s, i, e[i]);
+#pragma unroll
+            for (int i = 0; i < B; ++i) rec_st(s, NL + i, h[i]);
+        }
+    };
+    auto slot_ld = [&](int s, double (&e)[NL], double (&h)[B]) __attribute__((always_inline)) {
+        bool in_reg = false;
+        if constexpr (NRS > 0) {
+#pragma unroll
+            for (int q = 0; q < NRS; ++q)
+                if (s == NT + q) {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) e[i] = rr[q][i];
+#pragma unroll
+                    for (int i = 0; i < B; ++i) h[i] = rr[q][NL + i];
+                    in_reg = true;
+                }
+        }
+        if (!in_reg) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) e[i] = rec_ld(s, i);
+#pragma unroll
+            for (int i = 0; i < B; ++i) h[i] = rec_ld(s, NL + i);
+        }
+    };
+    auto slot_st_y = [&](int s, const double (&y)[B]) __attribute__((always_inline)) {
+        bool in_reg = false;
+        if constexpr (NRS > 0) {
+#pragma unroll
+            for (int q = 0; q < NRS; ++q)
+                if (s == NT + q) {
+#pragma unroll
+                    for (int i = 0; i < B; ++i) rr[q][NL + i] = y[i];
+                    in_reg = true;
+                }
+        }
+        if (!in_reg) {
+#pragma unroll
+            for (int i = 0; i < B; ++i) rec_st(s, NL + i, y[i]);
+        }
+    };
     // dual state: slot s, constraint c (0: the knot box, 1 + j: row slot j of the segment the block closes), cur / new
     double* const lamb = aa.lam + (size_t)blockIdx.x * (size_t)aa.lam_knots * 2 * NCN * 64 + lane;
     auto LC = [&](int s, int c) -> double& { return lamb[((size_t)s * 2 * NCN + c) * 64]; };
@@ -513,7 +581,11 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         if (mm >= 1 && !single) sa.build(Tseg(0));
         FIn fnx;
         if (mm >= 1 && !single) load_fin(1, fnx);
-        for (int j = 1; j < mm; ++j) {
+        // (NRS > 0: the sweeps run over the slot index s = m - j, wave-uniform: a lane whose half is shorter than the wave's longest joins late)
+        const int mtop = NRS > 0 ? __builtin_amdgcn_readfirstlane(wave_max_int(mm)) : 0;
+        for (int sq = NRS > 0 ? mtop - 1 : mm - 1; sq >= 1; --sq) {
+            const int j = mm - sq;         // NRS == 0: j = 1 .. m - 1 as before; NRS > 0: j < 1 = not started yet
+            if (NRS > 0 && j < 1) continue;
             double D[B][B], rhs[B];
             bool racv[K];
             const FIn fcur = fnx;
@@ -525,11 +597,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             {
                 double e[NL];
                 LDLPack<B>::get(ldl, e);
-                const int s = mm - j;
-#pragma unroll
-                for (int q = 0; q < NL; ++q) rec_st(s, q, e[q]);
-#pragma unroll
-                for (int q = 0; q < B; ++q) rec_st(s, NL + q, rhs[q]);
+                slot_st(sq, e, rhs);
             }
 #pragma unroll
             for (int i = 0; i < B; ++i) hprev[i] = rhs[i];
@@ -702,7 +770,9 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
             };
             BInA anx;
             load_bina(mm - 1, anx);
-            for (int j = mm - 1; j >= 0; --j) {
+            for (int sq = 1; sq <= (NRS > 0 ? mtop : mm); ++sq) {
+                const int j = mm - sq;          // (NRS > 0: the slot index is the wave-uniform loop variable; a shorter half is done early)
+                if (NRS > 0 && j < 0) continue;
                 // own segment j joins own knots j and j + 1; block j + 1 (= yn) carries its rows' multipliers
                 const int sl1 = mm - j - 1;                 // slot of own knot j + 1
                 const BInA ba_ = anx;
@@ -731,11 +801,12 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                     for (int c = 0; c < R; ++c) { gl[jj][c] = usedj[jj] ? gl[jj][c] : 0.0; gr[jj][c] = usedj[jj] ? gr[jj][c] : 0.0; }
                 }
                 double y[B];
-                const int s = mm - j;
+                const int s = sq;
                 if (j >= 1) {
-                    double h[B], t[B];
+                    double h[B], t[B], e[NL];
+                    slot_ld(s, e, h);
 #pragma unroll
-                    for (int i = 0; i < B; ++i) { h[i] = rec_ld(s, NL + i); t[i] = 0.0; }
+                    for (int i = 0; i < B; ++i) t[i] = 0.0;
                     const bool pk = kbit(pin, j), pn = kbit(pin, j + 1);
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
@@ -750,15 +821,11 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                         t[i] = acc;
                     }
                     SmallLDL<B> ldl;
-                    double e[NL];
-#pragma unroll
-                    for (int q = 0; q < NL; ++q) e[q] = rec_ld(s, q);
                     LDLPack<B>::set(ldl, e);
                     ldl.solve(t);
 #pragma unroll
                     for (int i = 0; i < B; ++i) y[i] = h[i] - t[i];
-#pragma unroll
-                    for (int i = 0; i < B; ++i) rec_st(s, NL + i, y[i]);
+                    slot_st_y(s, y);
                 } else {
 #pragma unroll
                     for (int i = 0; i < B; ++i) y[i] = i < R ? x0[i] : 0.0;
@@ -1010,7 +1077,23 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
         const bool emitp = finish && !redo;
         if (__ballot(emitp) != 0ull) {
             if (!aa.coeff) {
+                static_assert(NRS == 0 || true, "");
                 if (emitp) {
+                    if constexpr (NRS > 0) {      // (register slots: compile-time slot indices)
+#pragma unroll
+                        for (int sx = 0; sx < NT + NRS; ++sx) {
+                            const int j = mm - sx;
+                            const int kk = korig(j);
+                            if (j >= 1 && !(sx == 0 && isR) && kk >= 1 && kk <= M - 1) {
+                                double* o = a.xsol + (base3 + 3LL * kk) * R;
+#pragma unroll
+                                for (int c = 0; c < R; ++c) {
+                                    const double v = sx < NT ? RL(sx < NT ? sx : 0, NL + c) : rr[sx < NT ? 0 : sx - NT][NL + c];
+                                    o[c] = (isR && (c & 1)) ? -v : v;
+                                }
+                            }
+                        }
+                    } else {
                     for (int j = 1; j <= mm; ++j) {
                         if (j == mm && isR) continue;      // the meeting knot is written by the L lane
                         const int kk = korig(j);
@@ -1022,6 +1105,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                             o[c] = (isR && (c & 1)) ? -v : v;
                         }
                     }
+                    }
                 }
             } else {
                 // own segment j joins own knots j (slot m - j) and j + 1 (slot m - j - 1; own knot 0 is the boundary knot x0): Hermite data back in
@@ -1031,7 +1115,7 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                 const bool al16 = (reinterpret_cast<uintptr_t>(aa.coeff) & 15u) == 0;
                 // (NX: own knots per lane the staged path handles -- all of the LDS slots, plus, in a kernel with workspace slots, those up to 8;
                 //  the staging area [32 pairs][segments][2 R] must fit the LDS of the records)
-                constexpr int NX = WS ? (NT > 8 ? NT : 8) : NT;
+                constexpr int NX = WS ? (NT > 8 ? NT : 8) : NT + NRS;
                 const bool whole = a.uniform >= 2 && (a.uniform + 1) / 2 <= NX && 32 * a.uniform * NC <= NT * F * 64 && al16 && __ballot(act && !finish) == 0ull;
                 if (whole) {
                     // the whole wave hands over in this trip (the rule: one verifying solve): the coefficients go through LDS -- over the sweep records
@@ -1044,7 +1128,8 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                         for (int q = 0; q < R; ++q) X[s][q] = x0[q];
                         if (s < NX && s < mm) {
 #pragma unroll
-                            for (int q = 0; q < R; ++q) X[s][q] = (s < NT) ? RL(s < NT ? s : 0, NL + q) : RG(s < NT ? NT : s, NL + q);
+                            for (int q = 0; q < R; ++q)
+                                X[s][q] = (s < NT) ? RL(s < NT ? s : 0, NL + q) : (NRS > 0 ? rr[(NRS > 0 && s >= NT && s < NT + NRS) ? s - NT : 0][NL + q] : RG(s < NT ? NT : s, NL + q));
                         }
 #pragma unroll
                         for (int q = 1; q < R; q += 2) X[s][q] = isR ? -X[s][q] : X[s][q];
@@ -1103,15 +1188,13 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                         double xn[R];
 #pragma unroll
                         for (int q = 0; q < R; ++q) xn[q] = 0.0;
-                        for (int s = 0; s <= me; ++s) {
+                        // one slot of the walk from the meeting knot outwards: xo = the Hermite data of own knot m - s (original frame), xn = the previous
+                        // slot's; own segment j = m - s joins the two
+                        auto seg_step = [&](int s, const double (&xrec)[R]) __attribute__((always_inline)) {
                             const int j = mm - s;
                             double xo[R];
 #pragma unroll
-                            for (int q = 0; q < R; ++q) xo[q] = x0[q];
-                            if (s < mm) {
-#pragma unroll
-                                for (int q = 0; q < R; ++q) xo[q] = rec_ld(s, NL + q);
-                            }
+                            for (int q = 0; q < R; ++q) xo[q] = (s < mm) ? xrec[q] : x0[q];
 #pragma unroll
                             for (int q = 1; q < R; q += 2) xo[q] = isR ? -xo[q] : xo[q];     // back to the original frame
                             if (s >= 1) {
@@ -1133,6 +1216,25 @@ __global__ __launch_bounds__(64, 1) void rows_pair_kernel(Rows2Args aa) {
                             }
 #pragma unroll
                             for (int q = 0; q < R; ++q) xn[q] = xo[q];
+                        };
+                        if constexpr (NRS > 0) {
+                            // (register slots: compile-time slot indices, static trip count; the lanes' own bounds are predicates)
+#pragma unroll
+                            for (int s = 0; s <= NT + NRS; ++s) {
+                                if (s <= me) {
+                                    double xr[R];
+#pragma unroll
+                                    for (int q = 0; q < R; ++q) xr[q] = s < NT ? RL(s < NT ? s : 0, NL + q) : rr[(s >= NT && s < NT + NRS) ? s - NT : 0][NL + q];
+                                    seg_step(s, xr);
+                                }
+                            }
+                        } else {
+                            for (int s = 0; s <= me; ++s) {
+                                double xr[R];
+#pragma unroll
+                                for (int q = 0; q < R; ++q) xr[q] = s < mm ? rec_ld(s, NL + q) : 0.0;
+                                seg_step(s, xr);
+                            }
                         }
                     }
                     if (emitp && !finite) atomicMin(&a.status[b], (int32_t)UAVQP_NON_FINITE);

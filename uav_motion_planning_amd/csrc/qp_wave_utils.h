@@ -58,4 +58,15 @@ __device__ __forceinline__ void load_tile_guarded(const double* __restrict__ g, 
     for (int i = lane; i < ND_; i += 64) s[i] = (i < n_valid) ? g[i] : fill;
 }
 
+// wave-uniform maximum of a per-lane integer in [0, 256): eight ballots
+__device__ __forceinline__ int wave_max_int(int v) {
+    int r = 0;
+#pragma unroll
+    for (int bit = 7; bit >= 0; --bit) {
+        const int t = r | (1 << bit);
+        if (__ballot(v >= t) != 0ull) r = t;
+    }
+    return r;
+}
+
 }  // namespace uavqp

@@ -1229,8 +1229,9 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         const int kown = (Mmax + 1) / 2;                       // own knots of the longer half, meeting knot included = state slots 0..kown-1
         // the general passes keep 80 KiB of sweep records per wave (two waves per CU); the verifying pass 40 KiB (four: one per SIMD) and the rest in
         // the HBM workspace -- each pass has its own count of workspace knots and its own grid
+        // (the verifying pass also keeps rows2_reg_knots() slots in registers -- unless the batch needs workspace slots anyway: that instantiation has none)
         const int NT = uavqp::rows2_lds_knots(r, K, false), NTv = uavqp::rows2_lds_knots(r, K, true);
-        const int ws_knots = kown > NT ? kown - NT : 0, ws_knots_v = kown > NTv ? kown - NTv : 0;
+        const int ws_knots = kown > NT ? kown - NT : 0, ws_knots_v = kown > NTv + uavqp::rows2_reg_knots(true) ? kown - NTv : 0;
         long long grid = (pairs + 31) / 32, grid_v = grid;
         const long long max_grid = (long long)ctx->num_cus * uavqp::rows2_waves_per_cu(false), max_grid_v = (long long)ctx->num_cus * uavqp::rows2_waves_per_cu(true);
         if (grid > max_grid) grid = max_grid;
