@@ -500,7 +500,7 @@ __device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a
 // WS: some halves are longer than NT knots, their far slots live in the HBM workspace (one uniform branch per record access);
 // WS = false compiles every such test away (config 3: the whole state is in LDS).
 template <int R, bool WS, int WPC = UAVQP_CORRIDOR_WAVES_PER_CU>
-__global__ __launch_bounds__(64, 1) void corridor_solve_kernel(CorridorArgs a) {
+__global__ __launch_bounds__(64, (WPC > 4 ? 2 : 1)) void corridor_solve_kernel(CorridorArgs a) {
     constexpr int ND = R - 1;
     constexpr int NT = corridor_lds_knots(R, WPC);
     // sweep state per own knot: LDL' factors of S_j (strict lower triangle + inverse pivots: R (R + 1) / 2 numbers), x_j (first
