@@ -61,6 +61,7 @@ cd $R
 python tools/rows_ab.py 65536 > $O/rows_ab.jsonl 2>> $O/other_configs.err
 python tools/rows_ab.py 64 small >> $O/rows_ab.jsonl 2>> $O/other_configs.err
 python tools/config1_latency.py > $O/config1_latency.txt 2>> $O/other_configs.err
+make -s -C tools/ubench axis_latency -B > /dev/null 2>&1   # (always against the library of this tree)
 [ -x tools/ubench/axis_latency ] && ( echo "C ABI, no Python (tools/ubench/axis_latency.cpp):"; tools/ubench/axis_latency 3000 ) >> $O/config1_latency.txt 2>&1
 # soaks: equality / corridor, general rows (every unsolved draw cross-checked against the OSQP port: exit code 1 on a feasible one), pipeline
 ( python tools/soak.py 300 95; python tools/soak_rows.py 150 95; python tools/soak_rows.py 150 96; python tools/soak_aux.py 100 95 ) > $O/soak.txt 2>&1
