@@ -262,7 +262,10 @@ int uavqp_solve_corridor_warm_device(uavqp_ctx* ctx, int r, int n_traj, int unif
  * working set reaches zero -- that constraint leaves, the solve goes on (degenerate but feasible problems are SOLVED) -- or none does:
  * a Farkas certificate, status UAVQP_PRIMAL_INFEASIBLE if it passes OSQP's test at uavqp_settings.eps_prim_inf (the reference's 1e-3,
  * minimum_control.cpp:161), else UAVQP_MAX_ITER_REACHED.  UAVQP_MAX_ITER_REACHED also ends a problem at uavqp_settings.max_iter (default
- * 12 M (1 + rows_per_segment) + 30) and one whose working set is regular but too ill-conditioned for the block solve (undecided).  Both
+ * 12 M (1 + rows_per_segment) + 30) and one whose working set is regular but too ill-conditioned for the block solve (undecided: the direction
+ * solve that would yield the certificate does not vanish, |diag(H) z| > max(eps_prim_inf, 1e-6) |dy| -- the one class of problems the OSQP port proves
+ * infeasible and this back-end leaves undecided: 2 of 1246 infeasible soak draws at the reference's eps_prim_inf = 1e-3, 14 at 1e-9, profiles/r06_soak.txt;
+ * a feasible problem is never called infeasible).  Both
  * statuses hand back the minimiser of the last regular working set, which need NOT satisfy the remaining rows.  A single-segment
  * trajectory has no free unknown at all: its rows are only checked (violated -> UAVQP_PRIMAL_INFEASIBLE).  M <= 63.
  * Asynchronous for uniform batches; a ragged batch costs one 4-byte read-back + stream synchronisation (see uavqp_solve_corridor_batch_device). */
