@@ -401,15 +401,47 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         // and the functionals of its first K + 1 constraints -- are loaded one knot ahead (two register sets, the loop below alternates
         // between them): the compiler cannot lift a load above the G entries written just before it, and every exposed LDS round trip was
         // ~10 % on top of an issue-bound phase.
+        // Round 6: what a column INJECTS into the recursion it injects at its own two knots only -- k_R = k_L + 1 (the functional's right knot) and k_L:
+        //     z^(k) = [k = k_R] Z_kk (g_r - E_{k-1}' g_l) + [k = k_L] S_k^-1 g_l - E_k z^(k+1),      e_0' Z_{.,n} part: Z_{k_R,n}' g_r + Z_{k_L,n}' g_l
+        // -- so both injections (u1, u2) and the whole last-block-column vector wv are made ONCE per lane from the records of ITS two knots (lane-private
+        // LDS reads), and a knot of the loop is the 9 FMAs of -E_k z plus two selects, not 45 FMAs of which 36 multiply the zeros of the other 13 knots
+        // (backward pass + G: 130 -> 90 instructions per knot; the loop needs E_{k-1} of its knot and nothing else of the record).
         constexpr bool PF = R == 3;     // (r = 4: the second register set does not fit)
+        double u1[R], u2[R];
+        {
+            const bool hasR = vc && kLc + 1 >= 1 && kLc + 1 <= n, hasL = vc && kLc >= 1 && kLc <= n;
+            const double* const recR = ES(hasR ? kLc + 1 : 1);
+            const double* const recL = ES(hasL ? kLc : 1);
+            double tR[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                double t = gRc[i];
+#pragma unroll
+                for (int p_ = 0; p_ < R; ++p_) t -= recR[NE + p_ * R + i] * gLc[p_];      // g_r - E_{k_R - 1}' g_l   (E_0 = 0)
+                tR[i] = t;
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                double a1 = 0.0, a2 = 0.0, w = 0.0;
+#pragma unroll
+                for (int p_ = 0; p_ < R; ++p_) {
+                    const int hi_ = i > p_ ? i : p_, lo_ = i > p_ ? p_ : i, f_ = hi_ * (hi_ + 1) / 2 + lo_;       // packed lower triangle of a symmetric block
+                    a1 += recR[HB + f_] * tR[p_];                     // Z_kk (k_R)
+                    a2 += recL[f_] * gLc[p_];                         // S_k^-1 (k_L)
+                    w = fma(recR[HB + NE + p_ * R + i], hasR ? gRc[p_] : 0.0, w);      // Z_kn (k_R)' g_r
+                    w = fma(recL[HB + NE + p_ * R + i], hasL ? gLc[p_] : 0.0, w);      // Z_kn (k_L)' g_l
+                }
+                u1[i] = hasR ? a1 : 0.0;
+                u2[i] = hasL ? a2 : 0.0;
+                wv[i] = w;
+            }
+        }
         struct KnotOps {
-            double Si[NE], Em[R][R];
+            double Em[R][R];
             int kt;
         };
         auto load_ops = [&](int k, KnotOps& o) __attribute__((always_inline)) {
             const double* const rec = ES(k);
-#pragma unroll
-            for (int f = 0; f < NE; ++f) o.Si[f] = rec[f];
 #pragma unroll
             for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -432,42 +464,15 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                     gfv[t][p] = g2.x; gfv[t][p + 1] = g2.y;
                 }
             }
-            double Si[R][R], Zkk[R][R], Zkn[R][R];
-            {
-                const double* const rec = ES(k);     // (Z_kk and Z_kn of this knot: needed a few dozen instructions further down)
-                int f = 0;
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int q = 0; q <= i; ++q) { Si[i][q] = o.Si[f]; Si[q][i] = o.Si[f]; Zkk[i][q] = rec[HB + f]; Zkk[q][i] = Zkk[i][q]; ++f; }
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int q = 0; q < R; ++q) Zkn[i][q] = rec[HB + NE + i * R + q];
-            }
             lds_publish();
             // this lane's column
-            const double dR = (k == kLc + 1) ? 1.0 : 0.0, dL = (k == kLc) ? 1.0 : 0.0;
-            double inj1[R], inj2[R], wg[R], vn[R];
+            double vn[R];
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                double t = gRc[i];
+                double t = (k == kLc + 1) ? u1[i] : ((k == kLc) ? u2[i] : 0.0);
 #pragma unroll
-                for (int p = 0; p < R; ++p) t -= o.Em[p][i] * gLc[p];      // g_r - E_{k-1}' g_l   (E_0 = 0: a row of segment 0 has no variable on its left)
-                inj1[i] = dR * t;
-                inj2[i] = dL * gLc[i];
-                wg[i] = dR * gRc[i] + dL * gLc[i];
-            }
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                double t = 0.0;
-#pragma unroll
-                for (int p = 0; p < R; ++p) t += Zkk[i][p] * inj1[p] + Si[i][p] * inj2[p] - Ek[i][p] * v[p];
+                for (int p = 0; p < R; ++p) t -= Ek[i][p] * v[p];
                 vn[i] = t;
-                double w = wv[i];
-#pragma unroll
-                for (int p = 0; p < R; ++p) w = fma(Zkn[p][i], wg[p], w);
-                wv[i] = w;
             }
             // entries of G: constraints that sit at knot k against every column that does not sit in front of them
 #pragma unroll
