@@ -1108,8 +1108,6 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
     unsigned int* d_queue = nullptr;
     unsigned long long* d_desc = nullptr;
     int32_t* d_status_box = nullptr;
-    int32_t* d_cp1 = nullptr;
-    int* d_na1 = nullptr;
     double* d_kd = nullptr;
     size_t b_kd = 0;
     long long kd_plane = 0;
@@ -1134,10 +1132,9 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         const int kd_planes = Mmax - 1 < 1 ? 1 : (Mmax - 1 > 31 ? 31 : Mmax - 1);
         kd_plane = ((long long)n_traj + 63) / 64 * 64 * uavqp::rows_chain_half_mem(r);
         b_kd = prelude ? 2 * align256(sizeof(double) * (size_t)kd_planes * (size_t)kd_plane) : 0;
-        const size_t b_cp = prelude ? align256(sizeof(int32_t) * (size_t)n_traj) + 256 : 0;       // compacted order of the box phase + its count
         const size_t b_desc = align256(sizeof(unsigned long long) * (size_t)pairs * (2 + 2 * K));
         const size_t b_sb = warm ? align256(sizeof(int32_t) * (size_t)n_traj) : 0;                 // the box phase's statuses (not the step's)
-        const size_t need = b_wr + b_np + b_ctr + b_gf + b_kd + b_cp + b_desc + b_sb;
+        const size_t need = b_wr + b_np + b_ctr + b_gf + b_kd + b_desc + b_sb;
         if (need > ctx->rows_warm2_bytes) {
             UAVQP_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->rows_warm2) UAVQP_HIP(hipFree(ctx->rows_warm2));
@@ -1152,8 +1149,6 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         d_n_phase1 = (unsigned int*)p; d_queue = (unsigned int*)(p + 256); p += b_ctr;
         d_gfun_pre = (double*)p; p += b_gf;
         d_kd = (double*)p; p += b_kd;
-        d_cp1 = prelude ? (int32_t*)p : nullptr;
-        d_na1 = prelude ? (int*)(p + align256(sizeof(int32_t) * (size_t)n_traj)) : nullptr; p += b_cp;
         d_desc = (unsigned long long*)p; p += b_desc;
         d_status_box = warm ? (int32_t*)p : nullptr;
         a.queue = d_queue;
@@ -1200,14 +1195,13 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         else if (K_ == 1) hipLaunchKernelGGL((uavqp::rows_dual_kernel<4, 1>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
         else hipLaunchKernelGGL((uavqp::rows_dual_kernel<4, 2>), dim3((unsigned)dgrid), dim3(64), 0, ctx->stream, da, 0);
     }
-    if (warm) {
-        // (with the prelude: only for the trajectories it did not take -- their dealing order is compacted here, where their count is known:
-        // usually zero, and then nothing is scanned.  The box phase's statuses are its own: the step's statuses started in rows_prep_kernel)
-        if (prelude) hipLaunchKernelGGL(uavqp::compact_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)nullptr, n_traj, (const int32_t*)nullptr,
-                                        (const unsigned char*)d_need_phase1, d_cp1, d_na1, (const unsigned int*)d_n_phase1);
+    if (warm && !prelude) {
+        // The box phase -- only WITHOUT the prelude.  (Round 6: with it, what the prelude does not take is, by the host's own admission test
+        // (Mmax - 1) + K Mmax <= 48, exactly what rows_prep_kernel flags as invalid input -- bad durations, bad rows -- or a single segment, which has no
+        // knot box to start from: the three launches that compacted and solved that list -- empty as a rule -- are gone; need_phase1 is still written,
+        // nobody reads it.)  The box phase's statuses are its own: the step's statuses started in rows_prep_kernel.
         const int rc1 = corridor_warm_impl(ctx, r, n_traj, uniform_segments, max_segments, d_seg_offsets, d_waypoints, d_times,
-                                           d_bc, d_corr_lo, d_corr_hi, d_coeff_out, pair_kernel ? d_status_box : d_status_out, nullptr, ctx->rows_warm, 0, rows - n_traj, nullptr,
-                                           nullptr, d_need_phase1, nullptr, nullptr, 0, prelude ? d_cp1 : nullptr, prelude ? d_na1 : nullptr);
+                                           d_bc, d_corr_lo, d_corr_hi, d_coeff_out, pair_kernel ? d_status_box : d_status_out, nullptr, ctx->rows_warm, 0, rows - n_traj);
         if (rc1 != UAVQP_OK) return rc1;
     }
 #ifdef UAVQP_DUAL_DEBUG
