@@ -137,7 +137,16 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
                     double gl[R], gr[R];
 #pragma unroll
                     for (int c = 0; c < R; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
-                    if (d >= 0 && d < R && tq > 0.0 && tq < INFINITY && tau >= 0.0 && tau < 1.0) row_functional<R>(tq, tau, d, gl, gr);
+                    if (d >= 0 && d < R && tq > 0.0 && tq < INFINITY && tau >= 0.0 && tau < 1.0) {
+                        // (one straight-line instance per derivative order: with d a run-time value the factorial and power loops of row_functional are
+                        //  some thirty divergent little loops per call)
+                        switch (d) {
+                            case 0: row_functional<R>(tq, tau, 0, gl, gr); break;
+                            case 1: row_functional<R>(tq, tau, 1, gl, gr); break;
+                            case 2: row_functional<R>(tq, tau, 2, gl, gr); break;
+                            default: row_functional<R>(tq, tau, R - 1, gl, gr); break;
+                        }
+                    }
                     double* o = aa.gfun + e * 2 * R;
 #pragma unroll
                     for (int c = 0; c < R; ++c) { o[c] = gl[c]; o[R + c] = gr[c]; }
