@@ -454,14 +454,22 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             const int cf = kt & 255, cnt = (kt >> 8) & 255;
             int cdv[K + 1];
             double gfv[K + 1][2 * R];
+            // (from knot 2 on the first constraint of a knot is its BOX -- functional e_0 on this knot: its entry of G is the position component of
+            //  z^(k) itself, no functional to load, no dot product; knot 1 may start with the rows of segment 0)
+            const bool box0 = k >= 2;
 #pragma unroll
             for (int t = 0; t <= K; ++t) {
                 const int i = min(cf + t, NRW - 1);
                 cdv[t] = CD[i];
+                if (t == 0 && box0) {
 #pragma unroll
-                for (int p = 0; p < 2 * R; p += 2) {
-                    const double2 g2 = *reinterpret_cast<const double2_a*>(GF + i * 2 * R + p);
-                    gfv[t][p] = g2.x; gfv[t][p + 1] = g2.y;
+                    for (int p = 0; p < 2 * R; ++p) gfv[t][p] = 0.0;
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 2 * R; p += 2) {
+                        const double2 g2 = *reinterpret_cast<const double2_a*>(GF + i * 2 * R + p);
+                        gfv[t][p] = g2.x; gfv[t][p + 1] = g2.y;
+                    }
                 }
             }
             lds_publish();
@@ -481,8 +489,11 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
                     const int i = cf + t;
                     const int kLi = cdv[t] & 255;
                     double val = 0.0;
+                    if (t == 0 && box0) val = vn[0];
+                    else {
 #pragma unroll
-                    for (int p = 0; p < R; ++p) val += kLi == k ? (gfv[t][p] * vn[p] + gfv[t][R + p] * v[p]) : gfv[t][R + p] * vn[p];   // (kLi = 0 at k = 1: only its right knot is a variable)
+                        for (int p = 0; p < R; ++p) val += kLi == k ? (gfv[t][p] * vn[p] + gfv[t][R + p] * v[p]) : gfv[t][R + p] * vn[p];   // (kLi = 0 at k = 1: only its right knot is a variable)
+                    }
                     if (vc && i <= c) sg[tri_c + i] = val;      // (constraints are numbered along the knots: i <= c never sits behind c)
                 }
             }
