@@ -35,6 +35,7 @@ struct RowsDualArgs {
     const double* kdF;               // the chain records of rows_chain_kernel (launched before this kernel), one array per half, knot-major:
     const double* kdB;               // half h of knot k of trajectory b at kd_h + (k - 1) * kd_plane + b * rows_chain_half_mem(R)
     long long kd_plane;
+    unsigned int* ticket;            // dealing counter (zeroed before the launch; null: wave w takes trajectories w, w + grid, ...)
 #ifdef UAVQP_DUAL_DEBUG
     double* dbg;
 #endif
@@ -285,7 +286,14 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
     auto GP = [&](int i, int j) -> double& { const int hi = max(i, j), lo = min(i, j); return sg[hi * (hi + 1) / 2 + lo]; };
     const int crow = min(c, NRW - 1);
 
-    for (long long bq = blockIdx.x; bq < a.n_traj; bq += gridDim.x) {
+    // Dealing (round 6): the first trajectory of a wave is its block index, every further one a TICKET drawn from a counter.  The exchanges a
+    // trajectory needs vary (config 3 + K = 2: 27 +- 8 over the three axes); with the round-robin of rounds 4-5 every wave summed 32 of them and the
+    // launch lasted as long as the unluckiest of 2048 sums -- PMC: the mean wave was resident 83 % of the kernel's cycles.  The ticket is asked for at the
+    // top of a trajectory and read at its end (the atomic's round trip sits under the whole solve).
+    unsigned int tk = 0;
+    for (long long bq = blockIdx.x; bq < a.n_traj;
+         bq = aa.ticket ? (long long)gridDim.x + (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk) : bq + (long long)gridDim.x) {
+        if (aa.ticket && lane == 0) tk = atomicAdd(aa.ticket, 1u);
         const int b = aa.order ? aa.order[bq] : (int)bq;
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }

@@ -1173,6 +1173,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         da.order = nullptr;
         da.warm_box = (unsigned long long*)ctx->rows_warm; da.warm_rows = d_warm_rows; da.need_phase1 = d_need_phase1; da.gfun = d_gfun_pre;
         da.kdF = d_kd; da.kdB = (const double*)((const char*)d_kd + b_kd / 2); da.kd_plane = kd_plane; da.n_phase1 = d_n_phase1;
+        da.ticket = d_n_phase1 ? d_n_phase1 + 16 : nullptr;      // (the prelude's counter block: zeroed by rows_prep_kernel, the step's first kernel)
         {   // the chain of every trajectory once, one lane each (the prelude's waves would each repeat it in 64 lanes)
             long long cg = ((long long)n_traj + 63) / 64;
             if (cg > (long long)ctx->num_cus * 16) cg = (long long)ctx->num_cus * 16;
