@@ -382,6 +382,35 @@ def test_rows_prelude_changes_iterations_not_results(gpu_ctx, r, M, K, ragged):
         assert np.array_equal(res[1][2], res[2][2])
 
 
+def test_rows_prelude_deals_by_ticket_or_round_robin_with_the_same_results():
+    """Round 6: rows_dual_kernel draws the trajectories of a wave from a ticket counter (the launch used to last as long as the unluckiest
+    round-robin sum of solves); UAVQP_DEAL_TICKETS=0, read when a context is created, deals round-robin as before.  Which wave solves a
+    trajectory decides nothing: everything identical bit for bit, on a batch of more trajectories than the launch has waves (so that
+    tickets ARE drawn) whose size is not a multiple of anything."""
+    import os
+    r, M, K, n = 3, 8, 2, 5003
+    b = W.uniform_batch(3, n, M, r, time_mode="distance")
+    tot = n * M
+    mid = 0.5 * (b["waypoints"][:, :-1] + b["waypoints"][:, 1:]).reshape(tot, 3)
+    lo, hi = W.corridor_boxes(b, config_index=3)
+    tau = np.tile(np.array([0.5, 0.5]), (tot, 1))
+    drv = np.tile(np.array([0, 1]), (tot, 1))
+    rlo, rhi = np.zeros((tot, K, 3)), np.zeros((tot, K, 3))
+    rlo[:, 0], rhi[:, 0] = mid - 0.25, mid + 0.25
+    rlo[:, 1], rhi[:, 1] = -3.5, 3.5
+    out = {}
+    for tag in ("1", "0"):
+        os.environ["UAVQP_DEAL_TICKETS"] = tag
+        try:
+            with U.Context(0) as ctx:
+                out[tag] = run_rows(ctx, r, b, lo, hi, K, tau, drv, rlo, rhi, M)
+        finally:
+            os.environ.pop("UAVQP_DEAL_TICKETS", None)
+    assert (out["1"][1] == U.UAVQP_SOLVED).mean() > 0.8 and out["1"][2].mean() < 1.5      # (the prelude's sets were the solution's)
+    for a, c in zip(out["1"], out["0"]):
+        assert np.array_equal(a, c, equal_nan=True)
+
+
 def _one_row_problem(n, gap, duplicate=False):
     """n copies of a 6-segment jerk problem whose segment 2 carries the SAME position sample twice: slot 0 bounds it from above at
     a, slot 1 from below at a + gap (gap > 0: no common point; gap = 0: one point, the two rows are the same equation)."""

@@ -52,8 +52,8 @@ struct RowsDualArgs {
 #endif
 
 // G (lower triangle), chain records of knots 1..31 (two halves of rows_chain_half_mem doubles: the DMA's 16-byte pieces), functionals, durations,
-// masks, int tables.  r = 3: 2560 doubles = 20 480 bytes, eight of them are exactly the 160 KB of a CU.
-constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 / 2 + 31 * 2 * ((R * (R + 1) / 2 + R * R + 1) & ~1) + 48 * 2 * R + 34 + 6 + 64; }
+// int tables (the masks handed over alias the functionals, which are dead by then).  r = 3: 2554 doubles = 20 432 bytes, eight of them fit the 160 KB of a CU.
+constexpr int rows_dual_lds_doubles(int R) { return 48 * 49 / 2 + 31 * 2 * ((R * (R + 1) / 2 + R * R + 1) & ~1) + 48 * 2 * R + 34 + 64; }
 
 // What the prelude needs of the block LDL' chain of a trajectory is the same in all 64 lanes of the wave that solves it (one trajectory
 // per wave: 48 columns): computing it THERE repeats every 3 x 3 recursion 64 times -- a third of the kernel's instructions.
@@ -272,13 +272,15 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
     // records -- 16.4 KB per wave in all, so that the register file (256 VGPRs: two waves per SIMD), not LDS, sets the 8 waves per CU.
     // (First version: full rows with the records aliased underneath, 22 KB: 7 waves per CU, one SIMD of four with a single wave.)
     constexpr int ND = R - 1, NRW = 48, NE = R * (R + 1) / 2, HB = rows_chain_half_mem(R), RS = 2 * HB;    // (record in LDS: the second half starts at HB)
-    constexpr int O_ER = NRW * (NRW + 1) / 2, O_GF = O_ER + 31 * RS, O_TB = O_GF + NRW * 2 * R, O_MK = O_TB + 34, O_IT = O_MK + 6;
+    constexpr int O_ER = NRW * (NRW + 1) / 2, O_GF = O_ER + 31 * RS, O_TB = O_GF + NRW * 2 * R, O_IT = O_TB + 34, NMK = 2 + 2 * K;
     static_assert(O_ER % 2 == 0 && O_GF % 2 == 0 && O_TB % 2 == 0 && O_IT % 2 == 0, "16-byte functionals, 8-byte tables on even offsets");
     __shared__ __attribute__((aligned(16))) double sg[rows_dual_lds_doubles(R)];
     const int lane = threadIdx.x, c = lane;
     double* const GF = sg + O_GF;      // [48][2 R]: g_l, g_r of every constraint (a box: e_0, 0)
     double* const TB = sg + O_TB;      // [33]: durations
-    unsigned long long* const MK = reinterpret_cast<unsigned long long*>(sg + O_MK);
+    // [3][2 + 2 K] masks handed over, per axis: on top of the functionals -- nothing reads those after the backward pass
+    unsigned long long* const MK = reinterpret_cast<unsigned long long*>(sg + O_GF);
+    static_assert(3 * NMK <= NRW * 2 * R, "the masks of the three axes fit the functionals' space");
     int* const KT = reinterpret_cast<int*>(sg + O_IT);       // [34] per knot: first constraint that sits there | count << 8
     int* const CD = KT + 34;                                   // [48] per constraint: left knot | kind << 8 (0 box, 1 + slot) | segment << 12
     int* const CNT = CD + 48;                                  // [33] rows per segment
@@ -288,19 +290,19 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
 
     // Dealing (round 6): the first trajectory of a wave is its block index, every further one a TICKET drawn from a counter.  The exchanges a
     // trajectory needs vary (config 3 + K = 2: 27 +- 8 over the three axes); with the round-robin of rounds 4-5 every wave summed 32 of them and the
-    // launch lasted as long as the unluckiest of 2048 sums -- PMC: the mean wave was resident 83 % of the kernel's cycles.  The ticket is asked for at the
-    // top of a trajectory and read at its end (the atomic's round trip sits under the whole solve).
+    // launch lasted as long as the unluckiest of 2048 sums -- PMC: the mean wave was resident 83 % of the kernel's cycles.  The ticket is asked for behind
+    // the last load of a trajectory (in front of the three axes' exchanges: no wait for a load also waits for the atomic) and read at its end.
     unsigned int tk = 0;
     for (long long bq = blockIdx.x; bq < a.n_traj;
          bq = aa.ticket ? (long long)gridDim.x + (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk) : bq + (long long)gridDim.x) {
-        if (aa.ticket && lane == 0) tk = atomicAdd(aa.ticket, 1u);
+        auto draw = [&]() __attribute__((always_inline)) { if (aa.ticket && lane == 0) tk = atomicAdd(aa.ticket, 1u); };
         const int b = aa.order ? aa.order[bq] : (int)bq;
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
         s0 = __builtin_amdgcn_readfirstlane(s0);
         M = __builtin_amdgcn_readfirstlane(M);
         const bool shape_ok = M >= 2 && M <= 32 && (a.uniform > 0 || M <= a.max_segments);
-        if (!shape_ok) { if (lane == 0) { aa.need_phase1[b] = 1; atomicAdd(aa.n_phase1, 1u); } continue; }
+        if (!shape_ok) { if (lane == 0) { aa.need_phase1[b] = 1; atomicAdd(aa.n_phase1, 1u); } draw(); continue; }
         const int n = M - 1;
         RD_T_DECL
         lds_publish();
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
             NC += ci;
         }
         const bool handled = (__ballot(segok) == ~0ull) && NC <= NRW;
-        if (!handled) { if (lane == 0) { aa.need_phase1[b] = 1; atomicAdd(aa.n_phase1, 1u); } wait_vmcnt0(); continue; }
+        if (!handled) { if (lane == 0) { aa.need_phase1[b] = 1; atomicAdd(aa.n_phase1, 1u); } wait_vmcnt0(); draw(); continue; }
         if (lane == 0) aa.need_phase1[b] = 0;
         if (myseg) {
 #pragma unroll
@@ -618,6 +620,8 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
         v16d A0, A1, A2;
 #define own_row(kq) pick_row(A0, A1, A2, (kq))
         const int max_trips = 4 * NC + 16 + max_trips_extra;
+        if (lane < 3 * NMK) MK[lane] = 0ull;      // (behind the lds_publish that ends the backward pass; the axis loop publishes before it ORs into them)
+        draw();
 #pragma unroll 1
         for (int axis = 0; axis < 3; ++axis) {
             const double lo = axis == 0 ? lo3[0] : (axis == 1 ? lo3[1] : lo3[2]);
@@ -703,31 +707,29 @@ __global__ __launch_bounds__(64, 2) void rows_dual_kernel(RowsDualArgs aa, int m
 #ifdef UAVQP_DUAL_DEBUG
             rd_acc[8] += trips;
 #endif
-            // ---- hand the working set of this axis over in the rows kernel's layout: boxes by interior knot, rows by slot and segment
-            lds_publish();
-            if (lane < 2 + 2 * K) MK[lane] = 0ull;
-            lds_publish();
+            // ---- the working set of this axis in the rows kernel's layout: boxes by interior knot, rows by slot and segment (LDS; stored for the three
+            // axes at once below)
             if (vc && inW && sw != 0.0) {
                 const int kind = (cdc >> 8) & 15, seg = (cdc >> 12) & 255;
-                const int word = kind == 0 ? 0 : 2 * kind;
+                const int word = axis * NMK + (kind == 0 ? 0 : 2 * kind);
                 const unsigned long long bit = 1ull << (kind == 0 ? kLc : seg);
                 atomicOr(&MK[word], bit);
                 if (sw < 0.0) atomicOr(&MK[word + 1], bit);
             }
-            lds_publish();
 #ifdef UAVQP_DUAL_DEBUG
             if (dbg && vc) { dbg[2304 + 192 * axis + 96 + c] = y; dbg[2304 + 192 * axis + 48 + c] = (double)trips; }
-            if (dbg && lane == 0) for (int j = 0; j < 2 + 2 * K; ++j) dbg[2304 + 700 + 8 * axis + j] = (double)MK[j];
 #endif
-            if (lane == 0) {
-                const size_t prob = 3 * (size_t)b + axis;
-                aa.warm_box[2 * prob] = MK[0];
-                aa.warm_box[2 * prob + 1] = MK[1];
-#pragma unroll
-                for (int j = 0; j < 2 * K; ++j) aa.warm_rows[2 * K * prob + j] = MK[2 + j];
-            }
             RD_T(7);
         }
+        // hand-over: the masks of the three axes are contiguous per trajectory in both arrays -- 48 bytes of boxes, 48 K bytes of rows: two store
+        // instructions per trajectory.  (Rounds 4-5: lane 0 stored 2 + 2 K words per axis, eighteen 8-byte stores each a write transaction of its own:
+        // 114 MB of counted write traffic for 9.4 MB of masks.)
+        lds_publish();
+#ifdef UAVQP_DUAL_DEBUG
+        if (dbg && lane == 0) for (int ax_ = 0; ax_ < 3; ++ax_) for (int j = 0; j < NMK; ++j) dbg[2304 + 700 + 8 * ax_ + j] = (double)MK[ax_ * NMK + j];
+#endif
+        if (lane < 6) aa.warm_box[6 * (size_t)b + lane] = MK[(lane >> 1) * NMK + (lane & 1)];
+        if (lane < 6 * K) aa.warm_rows[6 * K * (size_t)b + lane] = MK[(lane / (2 * K)) * NMK + 2 + lane % (2 * K)];
 #ifdef UAVQP_DUAL_DEBUG
         if (dbg && lane == 0) for (int k_ = 0; k_ < 9; ++k_) dbg[3100 + k_] = (double)rd_acc[k_];
 #endif

@@ -158,6 +158,7 @@ struct uavqp_ctx {
     uint64_t* rows_warm = nullptr;   // [n_traj][3][2] working set of the box-only phase of uavqp_solve_rows_batch_device
     size_t rows_warm_count = 0;
     double* dummy = nullptr;
+    int deal_tickets = 1;            // rows_dual_kernel deals its trajectories by ticket (UAVQP_DEAL_TICKETS=0: round-robin as in rounds 4-5, A/B runs)
     // staging buffers of the host-pointer entry points
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -299,6 +300,7 @@ extern "C" int uavqp_create(uavqp_ctx** out_ctx, int device) {
     }
     if (std::getenv("UAVQP_NO_LSORT")) ctx->settings.ragged_window_sort = 0;
     if (std::getenv("UAVQP_NO_WAVE_PRELUDE")) ctx->wave_prelude = 0;
+    if (const char* e = std::getenv("UAVQP_DEAL_TICKETS")) ctx->deal_tickets = std::atoi(e) != 0;
     if (const char* e = std::getenv("UAVQP_DUAL_TRIPS_EXTRA")) ctx->dual_trips_extra = std::atoi(e);
     if (const char* e = std::getenv("UAVQP_WAVE_PRELUDE")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) ctx->wave_prelude = v; }
     if (const char* e = std::getenv("UAVQP_GENERIC_NAX")) ctx->settings.generic_lanes_per_traj = std::atoi(e) == 3 ? 1 : 3;
@@ -1173,7 +1175,7 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         da.order = nullptr;
         da.warm_box = (unsigned long long*)ctx->rows_warm; da.warm_rows = d_warm_rows; da.need_phase1 = d_need_phase1; da.gfun = d_gfun_pre;
         da.kdF = d_kd; da.kdB = (const double*)((const char*)d_kd + b_kd / 2); da.kd_plane = kd_plane; da.n_phase1 = d_n_phase1;
-        da.ticket = d_n_phase1 ? d_n_phase1 + 16 : nullptr;      // (the prelude's counter block: zeroed by rows_prep_kernel, the step's first kernel)
+        da.ticket = (d_n_phase1 && ctx->deal_tickets) ? d_n_phase1 + 16 : nullptr;      // (the prelude's counter block: zeroed by rows_prep_kernel, the step's first kernel)
         {   // the chain of every trajectory once, one lane each (the prelude's waves would each repeat it in 64 lanes)
             long long cg = ((long long)n_traj + 63) / 64;
             if (cg > (long long)ctx->num_cus * 16) cg = (long long)ctx->num_cus * 16;
