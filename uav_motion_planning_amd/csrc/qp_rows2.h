@@ -82,31 +82,41 @@ struct Rows2Args {
 // One trajectory per wave, lane s = segment s (and interior knot s), all three axes: every array is read in contiguous runs and the
 // masks are ballots.  (Round 2-4: one lane per (trajectory, axis) walking its own 1.3 KB of strided inputs -- 0.77 GB of fetch for
 // 0.24 GB of inputs on config 3 + K = 2, 132 us.)
-template <int R, int K>
+template <int R, int K, int TW = 1>
 __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
+    // TW = 2 (round 6; the host picks it when no trajectory has more than 32 segments): TWO trajectories per wave, lanes 0-31 / 32-63 -- with one per
+    // wave a 16-segment trajectory keeps 16 lanes busy in the validation and 32 in the functionals, and the kernel is bound by the instructions it
+    // issues (config 3 + K = 2: 100 us for 0.31 GB); every ballot below is read through the half's 32-bit window.
+    static_assert(TW == 1 || TW == 2, "one or two trajectories per wave");
+    constexpr int HL = 64 / TW;                                     // lanes per trajectory
     const RowsArgs& a = aa.r;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int half = TW == 2 ? lane >> 5 : 0, hl = TW == 2 ? lane & 31 : lane;
+    const unsigned long long hmask = TW == 2 ? 0xFFFFFFFFull : ~0ull;
+    auto hballot = [&](bool x) -> unsigned long long { return (__ballot(x) >> (TW == 2 ? 32 * half : 0)) & hmask; };
     const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const long long n_units = ((long long)a.n_traj + TW - 1) / TW;
     if (aa.init_counters && blockIdx.x == 0 && threadIdx.x < 128) aa.init_counters[threadIdx.x] = 0u;
-    for (long long bq = (long long)blockIdx.x * (blockDim.x >> 6) + wib; bq < a.n_traj; bq += n_waves) {
-        const int b = (int)bq;
+    for (long long bq = (long long)blockIdx.x * (blockDim.x >> 6) + wib; bq < n_units; bq += n_waves) {
+        const bool present = TW * bq + half < a.n_traj;
+        const int b = present ? (int)(TW * bq + half) : 0;
         int s0, M;
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
-        const bool shape_ok = (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= 63;
-        const bool seg = shape_ok && lane < M;                  // this lane has a segment
+        const bool shape_ok = present && (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= HL - 1;
+        const bool seg = shape_ok && hl < M;                    // this lane has a segment
         bool t_bad = false;
         double t_seg = 1.0;
-        if (seg) { t_seg = a.times[s0 + lane]; t_bad = !((t_seg > 0.0) && (t_seg < INFINITY)); }
-        const bool t_ok = shape_ok && __ballot(t_bad) == 0ull;
+        if (seg) { t_seg = a.times[s0 + hl]; t_bad = !((t_seg > 0.0) && (t_seg < INFINITY)); }
+        const bool t_ok = shape_ok && hballot(t_bad) == 0ull;
         // first kernel of the step: the outputs every later kernel only lowers / raises / ORs into start here
-        if (lane == 0 && a.iters) a.iters[b] = 0;
-        if (aa.init_warm_box && lane < 6) aa.init_warm_box[(size_t)b * 6 + lane] = 0ull;
-        if (aa.init_warm_rows && lane < 6 * K) aa.init_warm_rows[(size_t)b * 6 * K + lane] = 0ull;
+        if (present && hl == 0 && a.iters) a.iters[b] = 0;
+        if (present && aa.init_warm_box && hl < 6) aa.init_warm_box[(size_t)b * 6 + hl] = 0ull;
+        if (present && aa.init_warm_rows && hl < 6 * K) aa.init_warm_rows[(size_t)b * 6 * K + hl] = 0ull;
         // knot boxes: lane k = interior knot k = 1..M-1, the three axes are 24 contiguous bytes per array
-        const bool knot = t_ok && lane >= 1 && lane < M;
+        const bool knot = t_ok && hl >= 1 && hl < M;
         bool kbad[3] = {false, false, false}, keq[3] = {false, false, false};
         if (knot) {
-            const long long at = 3LL * ((long long)s0 + b + lane);
+            const long long at = 3LL * ((long long)s0 + b + hl);
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 const double l = a.corr_lo ? a.corr_lo[at + ax] : a.waypoints[at + ax];
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
                 keq[ax] = l == h;
             }
         }
-        // rows of segment `lane`
+        // rows of segment `hl`
         bool rused[K], rbad_any[K], rbad[K][3], req[K][3];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -123,14 +133,17 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) { rbad[j][ax] = false; req[j][ax] = false; }
         }
-        if (aa.prep_gfun && shape_ok) {
+        if (aa.prep_gfun) {
             // the row functionals of this trajectory (they depend on the time allocation only: the same for the three axes, for the dual
             // prelude and for every solve of the rows kernel): one (segment, row slot) per lane and trip -- contiguous loads and stores, every
             // lane busy (lane = segment would leave three quarters of the wave idle in the longest part of this kernel); zeros for an unused or
             // invalid row
-            for (int e0 = 0; e0 < M * K; e0 += 64) {
-                const int el = e0 + lane;
-                if (el < M * K) {
+            const int mk = shape_ok ? M * K : 0;
+            int mk_max = mk;
+            if (TW == 2) mk_max = max(mk_max, __shfl_xor(mk_max, 32, 64));
+            for (int e0 = 0; e0 < mk_max; e0 += HL) {
+                const int el = e0 + hl;
+                if (el < mk) {
                     const size_t e = (size_t)s0 * K + el;
                     const int d = a.row_deriv[e];
                     const double tau = a.row_tau[e], tq = a.times[s0 + el / K];
@@ -153,10 +166,10 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
                 }
             }
         }
-        if (t_ok && lane < M) {
+        if (t_ok && hl < M) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const size_t e = (size_t)(s0 + lane) * K + j;
+                const size_t e = (size_t)(s0 + hl) * K + j;
                 const int d = a.row_deriv[e];
                 if (d < 0) continue;
                 const double tau = a.row_tau[e];
@@ -172,18 +185,18 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
         }
         unsigned long long used[K], anybad = 0ull;
 #pragma unroll
-        for (int j = 0; j < K; ++j) { used[j] = __ballot(rused[j]); anybad |= __ballot(rbad_any[j]); }
-        bool all_ok = true;      // (wave-uniform: ballots)
+        for (int j = 0; j < K; ++j) { used[j] = hballot(rused[j]); anybad |= hballot(rbad_any[j]); }
+        bool all_ok = true;      // (uniform per trajectory: ballots)
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            unsigned long long bad = anybad | __ballot(kbad[ax]);
-            const unsigned long long eq = __ballot(keq[ax]);
+            unsigned long long bad = anybad | hballot(kbad[ax]);
+            const unsigned long long eq = hballot(keq[ax]);
             unsigned long long rq[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) { bad |= __ballot(rbad[j][ax]); rq[j] = __ballot(req[j][ax]); }
+            for (int j = 0; j < K; ++j) { bad |= hballot(rbad[j][ax]); rq[j] = hballot(req[j][ax]); }
             const bool ok = t_ok && bad == 0ull;
             all_ok = all_ok && ok;
-            if (lane == ax) {
+            if (present && hl == ax) {
                 unsigned long long* o = aa.desc + ((size_t)3 * b + ax) * (2 + 2 * K);
                 o[0] = ok ? (1ull | (M >= 2 ? 2ull : 0ull) | ((unsigned long long)M << 8)) : 0ull;
                 o[1] = eq;
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
             }
         }
         // the trajectory's status starts here (the first kernel of the step: ONE store, nothing to lower yet)
-        if (lane == 0) a.status[b] = all_ok ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
+        if (present && hl == 0) a.status[b] = all_ok ? (int32_t)UAVQP_SOLVED : (int32_t)UAVQP_INVALID_INPUT;
     }
 }
 

@@ -1160,12 +1160,17 @@ static int rows_batch_impl(uavqp_ctx* ctx, int r, int n_traj, int uniform_segmen
         aa.init_warm_box = (warm || prelude) ? (unsigned long long*)ctx->rows_warm : nullptr;
         aa.init_warm_rows = d_warm_rows;
         aa.init_counters = d_n_phase1;                      // 128 words: the prelude's counters and the queue behind them
-        long long pgrid = ((long long)n_traj + 3) / 4;      // rows_prep_kernel: one trajectory per wave, four waves per block
+        // rows_prep_kernel: four waves per block; two trajectories per wave when none has more than 31 segments (a half-wave's lanes), else one
+        const int tw = Mmax <= 31 ? 2 : 1;
+        long long pgrid = ((long long)n_traj + 4 * tw - 1) / (4 * tw);
         if (pgrid > (long long)ctx->num_cus * 16) pgrid = (long long)ctx->num_cus * 16;
-        if (r == 3 && K == 1) hipLaunchKernelGGL((uavqp::rows_prep_kernel<3, 1>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);
-        else if (r == 3) hipLaunchKernelGGL((uavqp::rows_prep_kernel<3, 2>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);
-        else if (K == 1) hipLaunchKernelGGL((uavqp::rows_prep_kernel<4, 1>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);
-        else hipLaunchKernelGGL((uavqp::rows_prep_kernel<4, 2>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa);
+#define UAVQP_PREP_LAUNCH(R_, K_) do { if (tw == 2) hipLaunchKernelGGL((uavqp::rows_prep_kernel<R_, K_, 2>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa); \
+                                       else hipLaunchKernelGGL((uavqp::rows_prep_kernel<R_, K_, 1>), dim3((unsigned)pgrid), dim3(256), 0, ctx->stream, aa); } while (0)
+        if (r == 3 && K == 1) UAVQP_PREP_LAUNCH(3, 1);
+        else if (r == 3) UAVQP_PREP_LAUNCH(3, 2);
+        else if (K == 1) UAVQP_PREP_LAUNCH(4, 1);
+        else UAVQP_PREP_LAUNCH(4, 2);
+#undef UAVQP_PREP_LAUNCH
     }
     if (prelude) {
         uavqp::RowsDualArgs da{};
