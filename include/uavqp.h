@@ -115,7 +115,9 @@ int uavqp_set_variant(uavqp_ctx* ctx, int variant);
  *                          inequality-constrained solves; <= 0 = automatic (8 * max_segments + 20).  Hitting it yields
  *                          UAVQP_MAX_ITER_REACHED with a feasible, smooth trajectory (as OSQP's status of the same name).
  *   kernel_variant         as uavqp_set_variant (0 auto)
- *   ragged_window_sort     1: ragged batches >= 2048 are dealt to lanes by segment count inside windows (default), 0: lane order
+ *   ragged_window_sort     1: ragged batches >= 2048 are dealt to lanes by segment count inside windows (default; since round 6 the waves of the
+ *                          lane-pair kernel rank their window themselves, up to 63 segments), 2: the same dealing from its own launch in front of
+ *                          the solve (rounds 2-5; results identical), 0: lane order
  *   generic_lanes_per_traj 0 auto, 1 = one lane per trajectory, 2 = a lane pair per trajectory (two-sided elimination),
  *                          3 = one lane per (trajectory, axis)
  *   generic_waves_per_cu   0 auto, > 0: resident waves per CU of the generic kernel

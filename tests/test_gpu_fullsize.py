@@ -169,10 +169,47 @@ def test_long_trajectories_generic_path(gpu_ctx, oracle):
         assert np.max(np.abs(got - ref)) < 1e-8 * np.max(np.abs(ref))
 
 
+@pytest.mark.parametrize("r,mx,n", [(4, 48, 5003), (3, 48, 2048), (4, 7, 40000)])
+def test_waves_that_rank_their_own_window_deal_like_the_sort_kernel(gpu_ctx, r, mx, n):
+    """Round 6: no window_sort_kernel launch in front of the pair kernel -- each of the 16 waves of a window ranks the window's 512 segment
+    counts itself (descending count, ascending index: the same order in every wave, no atomics) and takes its 32 ranks.  A rank computed
+    differently by two waves would solve a trajectory twice or never: statuses pre-filled with 0, outputs with NaN, everything compared bit for
+    bit with the separate sort launch (setting 2) and the plain lane order (0).  Up to the longest trajectories the pair kernel takes (48
+    segments), with zero-segment and over-long (invalid) trajectories, a last window of 395 / exactly 4 windows / many equal counts."""
+    import torch
+    rng = np.random.default_rng(7 * mx + r)
+    Ms = rng.integers(0, mx + 6, size=n)                    # 0 and mx + 1 .. mx + 5: invalid input
+    so = np.zeros(n + 1, dtype=np.int32)
+    so[1:] = np.cumsum(Ms)
+    tot = int(so[-1])
+    wp = np.cumsum(rng.uniform(-1.0, 1.0, size=(tot + n, 3)), axis=0)
+    T = rng.uniform(0.4, 2.0, size=tot)
+    bc = rng.uniform(-1.0, 1.0, size=(n, 2, r - 1, 3))
+    dev = torch.device("cuda", 0)
+    d_so, d_wp, d_T, d_bc = (torch.from_numpy(x).to(dev) for x in (so, wp, T, bc))
+    res = {}
+    try:
+        for mode in (1, 2, 0):
+            gpu_ctx.set_settings(ragged_window_sort=mode)
+            out = torch.full((tot * 6 * r,), np.nan, dtype=torch.float64, device=dev)
+            st = torch.zeros(n, dtype=torch.int32, device=dev)
+            gpu_ctx.solve_batch_device(r, n, 0, mx, d_so, d_wp, d_T, d_bc, out, st)
+            gpu_ctx.synchronize()
+            res[mode] = (out.cpu().numpy(), st.cpu().numpy())
+    finally:
+        gpu_ctx.set_settings(ragged_window_sort=1)
+    ok = (Ms >= 1) & (Ms <= mx)
+    assert np.array_equal(res[1][1] == U.UAVQP_SOLVED, ok) and np.all(res[1][1][~ok] == U.UAVQP_INVALID_INPUT)
+    for mode in (2, 0):
+        assert np.array_equal(res[mode][1], res[1][1]) and np.array_equal(res[mode][0], res[1][0], equal_nan=True), mode
+    valid = np.repeat(ok, Ms * 6 * r)
+    assert np.all(np.isfinite(res[1][0][valid])) and np.all(np.isnan(res[1][0][~valid]))
+
+
 def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx):
     """Large ragged batches are dealt to the lanes in windows of 16 waves' trajectories by descending segment count
-    (window_sort_kernel + solve_generic2_kernel<R, LSORT>: a lane pair per trajectory, the default; solve_generic_kernel<R, LSORT,
-    NAX>: one lane per trajectory or per (trajectory, axis)).  Which lane solves a trajectory must not change a single bit:
+    (solve_generic2_kernel<R, LSORT>: a lane pair per trajectory, the default -- since round 6 every wave ranks its window itself, setting 2
+    = window_sort_kernel in front as before; solve_generic_kernel<R, LSORT, NAX>: one lane per trajectory or per (trajectory, axis)).  Which lane solves a trajectory must not change a single bit:
     compare with the plain lane order (uavqp_settings.ragged_window_sort = 0) on a batch that needs two grid rounds, is
     not a multiple of the window, and contains single-segment and over-long (flagged invalid) trajectories.  The status
     buffer is pre-filled with 0 (no valid code): a trajectory the dealing dropped would keep it."""
@@ -197,7 +234,13 @@ def test_ragged_dealing_by_segment_count_is_invisible_in_the_results(gpu_ctx):
         return out.cpu().numpy(), st.cpu().numpy()
 
     assert gpu_ctx.get_settings().ragged_window_sort == 1
-    c_deal, st_deal = run()
+    c_deal, st_deal = run()                                  # (round 6: the waves of the pair kernel rank their window themselves)
+    gpu_ctx.set_settings(ragged_window_sort=2)               # the same dealing from window_sort_kernel, its own launch (rounds 2-5)
+    try:
+        c_sep, st_sep = run()
+    finally:
+        gpu_ctx.set_settings(ragged_window_sort=1)
+    assert np.array_equal(st_sep, st_deal) and np.array_equal(c_sep, c_deal, equal_nan=True)
     gpu_ctx.set_settings(ragged_window_sort=0)
     try:
         c_plain, st_plain = run()

@@ -26,6 +26,7 @@ struct BatchArgs {
     const int32_t* perm;  // ragged dealing (generic kernel, LSORT): lane slot -> trajectory
     const int4* perm4;    // the same with the trajectory's first segment and segment count packed in: {b, s0, M, 0} (pair kernel: one
                           // load instead of three dependent ones at the top of the wave)
+    int fused_sort;       // pair kernel, LSORT (round 6): no window_sort_kernel launch -- every wave sorts its window's 512 segment counts itself (qp_generic2.h)
     double* dummy;  // 1 KiB sink for the predicated-off stores of the specialised kernel
 #ifdef UAVQP_PHASE_TIMING
     long long* stamps;  // debug: s_memtime stamps of wave 0 (tools/ubench only)

@@ -18,8 +18,11 @@
 // backward loop alternates between two register sets for the records, re-loads a set two trips ahead and retires the re-loads
 // in the basic block that follows the stores they must not wait for (vmcnt(N) past the stores, not vmcnt(0)).  Coefficients
 // leave through LDS as 64-byte (r = 3: 48-byte) chunks, 4 (3) lanes each, spelled as GLOBAL stores.
-// Ragged batches are dealt to the lane PAIRS by segment count inside windows (window_sort_kernel, 32 trajectories per wave);
-// the rank ranges are rotated by the window index so that the long waves spread over the XCDs.  DESIGN.md section 5.2.
+// Ragged batches are dealt to the lane PAIRS by segment count inside windows of 16 waves x 32 trajectories; the rank ranges are rotated by
+// the window index so that the long waves spread over the XCDs.  Round 6: the waves rank their window themselves (BatchArgs::fused_sort, see
+// the top of the round loop) -- window_sort_kernel in front (rounds 2-5, uavqp_settings.ragged_window_sort = 2) cost a launch boundary and
+// 8 + 16 bytes of permutation per trajectory for a sort of 512 small integers; the ranking costs the kernel ~2.5 us, the step is 0.1-1.3 us
+// shorter inside a hipGraph and ~1 us with eager launches (tools/g2_fused_ab.sh).  DESIGN.md section 5.2.
 #pragma once
 #include "qp_core_kernels.h"
 #include "qp_wave_utils.h"
@@ -124,7 +127,98 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
         int s0 = 0, M = 0;
         bool packed = false;
         if constexpr (LSORT) {
-            if (b < a.n_traj) {
+            if (a.fused_sort) {
+                // ---- the dealing, by the wave itself (round 6; was window_sort_kernel behind its own launch boundary: 4.8 us of a 40 us step).
+                // The 16 waves of a window each rank the window's 512 trajectories by (segment count descending, index ascending) -- the SAME
+                // deterministic order in every one of them, no atomics -- and take their own 32 ranks.  Trajectory i = 8 lane + j:
+                //   * C[k][l] (16 bit) = how many of lane l's eight have count k; lane k turns row k into exclusive prefix sums along l (SWAR),
+                //     starting from the number of trajectories with a LARGER count (suffix scan of the row totals over the lanes);
+                //   * rank = C[k][lane] + (earlier ones of the same count in the own eight).
+                // Counts are clamped to 0..63 for the ranking (the host uses this path up to 63 segments); the record keeps the real count.
+                const int win = blockIdx.x >> 4, q = ((blockIdx.x & 15) + win) & 15;
+                const int wbase = round * n_items + win * 512;
+                // (rows of 72 halfwords = 144 bytes: with 128 the 64 lanes that each scan their own row would all start on the same LDS bank)
+                constexpr int CS = 72;
+                unsigned short* const C = reinterpret_cast<unsigned short*>(s_in);          // [64][CS], on top of the input slots (free until the staging)
+                int4* const SLOT = reinterpret_cast<int4*>(s_in + 64 * CS / 4);              // [32] records of this wave's ranks
+                int off[9], key[8], dupb[8];
+                const int t0 = wbase + lane * 8;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) off[j] = t0 + j <= a.n_traj ? a.seg_offsets[t0 + j] : 0;
+                wave_lds_sync();      // (the previous round's slots and staging rows have been read by everybody)
+#pragma unroll
+                for (int p = 0; p < CS / 8; ++p) *reinterpret_cast<double2*>(s_in + 2 * (p * 64 + lane)) = make_double2(0.0, 0.0);     // C = 0 (9 KB)
+                if (lane < 32) SLOT[lane] = make_int4(a.n_traj, 0, 0, 0);                                                        // (rank beyond the window's trajectories: nobody)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = off[j + 1] - off[j];
+                    key[j] = t0 + j < a.n_traj ? (c < 0 ? 0 : (c > 63 ? 63 : c)) : -1;
+                }
+                int same[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int before = 0, all = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = key[i] == key[j] ? 1 : 0;
+                        all += e;
+                        if (i < j) before += e;
+                    }
+                    dupb[j] = before;
+                    same[j] = all;
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (key[j] >= 0) C[key[j] * CS + lane] = (unsigned short)same[j];
+                wave_lds_sync();
+                // lane k: exclusive prefix of row k along the lanes, two 16-bit counts per dword
+                {
+                    int tot;
+                    unsigned int* const row = reinterpret_cast<unsigned int*>(C + lane * CS);
+                    unsigned int d[32];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * p);
+                        d[4 * p] = v.x; d[4 * p + 1] = v.y; d[4 * p + 2] = v.z; d[4 * p + 3] = v.w;
+                    }
+                    // total of the row first (the start of a count = the trajectories with a larger one: suffix sum over the lanes), then the
+                    // exclusive prefix along the lanes with that start as its first carry: an entry of the table IS the rank of the lane's first
+                    // trajectory of that count
+                    unsigned int acc = 0;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc += d[i];
+                    tot = (int)((acc & 0xFFFFu) + (acc >> 16));
+                    int suf = tot;        // inclusive suffix sum over the lanes (= counts): trajectories with a count >= this lane's
+#pragma unroll
+                    for (int dd = 1; dd < 64; dd <<= 1) {
+                        const int v = __shfl_down(suf, dd, 64);
+                        if (lane + dd < 64) suf += v;
+                    }
+                    unsigned int carry = (unsigned int)(suf - tot);
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        const unsigned int lo_ = d[i] & 0xFFFFu, hi_ = d[i] >> 16;
+                        const unsigned int e_hi = carry + lo_;
+                        d[i] = carry | (e_hi << 16);
+                        carry = e_hi + hi_;
+                    }
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) *reinterpret_cast<uint4*>(row + 4 * p) = make_uint4(d[4 * p], d[4 * p + 1], d[4 * p + 2], d[4 * p + 3]);
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = key[j] < 0 ? 0 : key[j];
+                    const int pos = (int)C[k * CS + lane] + dupb[j] - 32 * q;
+                    if (key[j] >= 0 && pos >= 0 && pos < 32) SLOT[pos] = make_int4(t0 + j, off[j], off[j + 1] - off[j], 0);
+                }
+                wave_lds_sync();
+                const int4 rec = SLOT[item];
+                b = rec.x; s0 = rec.y; M = rec.z;
+                packed = true;
+                wave_lds_sync();      // (the slots are read before the staging below writes over them)
+            } else if (b < a.n_traj) {
                 if (a.perm4) {   // {trajectory, first segment, segment count}: one load (the sort kernel had all three in hand)
                     const int4 rec = a.perm4[b];
                     b = rec.x; s0 = rec.y; M = rec.z;

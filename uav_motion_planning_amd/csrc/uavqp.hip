@@ -235,7 +235,7 @@ extern "C" int uavqp_set_settings(uavqp_ctx* ctx, const uavqp_settings* st) {
     if (rc != UAVQP_OK) return rc;
     ctx->settings = *st;
     ctx->settings.warm_start = st->warm_start ? 1 : 0;
-    ctx->settings.ragged_window_sort = st->ragged_window_sort ? 1 : 0;
+    ctx->settings.ragged_window_sort = st->ragged_window_sort == 2 ? 2 : (st->ragged_window_sort ? 1 : 0);     // (2: the dealing as its own launch, rounds 2-5)
     ctx->settings.corridor_initial_guess = st->corridor_initial_guess < 0 ? 0 : (st->corridor_initial_guess > 2 ? 2 : st->corridor_initial_guess);
     // (cloud_window: any value outside 0..3 means "on" = 1, as before round 5; corridor_prelude_lanes sits in what used to be padding: a value
     //  that is none of 0 / 1 / 8 -- a struct filled field by field without uavqp_default_settings -- is taken as the default, not refused)
@@ -397,6 +397,7 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     a.coeff = d_coeff_out;
     a.status = d_status_out;
     a.dummy = ctx->dummy;
+    a.fused_sort = 0;
     a.perm = nullptr;
     a.perm4 = nullptr;
 
@@ -468,7 +469,10 @@ extern "C" int uavqp_solve_batch_device(uavqp_ctx* ctx, int r, int n_traj, int u
     a.ws = ctx->ws;
     a.perm = nullptr;
     a.perm4 = nullptr;
-    if (lsort) {
+    // round 6: the pair kernel's waves rank their window themselves (qp_generic2.h) -- no window_sort_kernel launch in front of the solve, no
+    // permutation in HBM; ragged_window_sort = 2 keeps the separate launch (A/B, cross-check test)
+    a.fused_sort = (lsort && pair && Mmax <= 63 && ctx->settings.ragged_window_sort != 2) ? 1 : 0;
+    if (lsort && !a.fused_sort) {
         // dealing permutation: one counting sort per window of 16 waves' trajectories (see window_sort_kernel)
         if ((size_t)n_traj > ctx->perm_count) {
             UAVQP_HIP(hipStreamSynchronize(ctx->stream));
