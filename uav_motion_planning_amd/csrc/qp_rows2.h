@@ -104,26 +104,59 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
         if (a.uniform > 0) { M = a.uniform; s0 = b * M; } else { s0 = a.seg_offsets[b]; M = a.seg_offsets[b + 1] - s0; }
         const bool shape_ok = present && (M >= 1) && (a.uniform > 0 || M <= a.max_segments) && M <= HL - 1;
         const bool seg = shape_ok && hl < M;                    // this lane has a segment
-        bool t_bad = false;
+        // Every load of the trajectory is issued HERE, before anything is decided (round 6): the kernel moves 0.31 GB and was bound by the four
+        // memory round trips a wave made one after the other (durations -> ballot -> knot boxes -> rows -> the functionals' inputs; PMC: VALU
+        // active 5 % of the wave cycles, waiting 54 %).  What a load brings in is only used if the checks that used to guard it pass.
         double t_seg = 1.0;
-        if (seg) { t_seg = a.times[s0 + hl]; t_bad = !((t_seg > 0.0) && (t_seg < INFINITY)); }
+        if (seg) t_seg = a.times[s0 + hl];
+        const bool kn = shape_ok && hl >= 1 && hl < M;          // lane k = interior knot k = 1..M-1, the three axes are 24 contiguous bytes per array
+        double kl[3] = {0.0, 0.0, 0.0}, kh[3] = {0.0, 0.0, 0.0};
+        if (kn) {
+            const long long at = 3LL * ((long long)s0 + b + hl);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                kl[ax] = a.corr_lo ? a.corr_lo[at + ax] : a.waypoints[at + ax];
+                kh[ax] = a.corr_hi ? a.corr_hi[at + ax] : a.waypoints[at + ax];
+            }
+        }
+        int rd[K];
+        double rtau[K], rl[K][3], rh[K][3];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            rd[j] = -1; rtau[j] = 0.0;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { rl[j][ax] = 0.0; rh[j][ax] = 0.0; }
+            if (seg) {
+                const size_t e = (size_t)(s0 + hl) * K + j;
+                rd[j] = a.row_deriv[e];
+                rtau[j] = a.row_tau[e];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) { rl[j][ax] = a.row_lo[e * 3 + ax]; rh[j][ax] = a.row_hi[e * 3 + ax]; }
+            }
+        }
+        // (the functionals' first pass: one (segment, row slot) per lane -- 32 of them per half-wave, one trip for up to 16 segments with K = 2)
+        const int mk = (aa.prep_gfun && shape_ok) ? M * K : 0;
+        int gd = -1;
+        double gtau = 0.0, gtq = 1.0;
+        if (hl < mk) {
+            const size_t e = (size_t)s0 * K + hl;
+            gd = a.row_deriv[e];
+            gtau = a.row_tau[e];
+            gtq = a.times[s0 + hl / K];
+        }
+
+        const bool t_bad = seg && !((t_seg > 0.0) && (t_seg < INFINITY));
         const bool t_ok = shape_ok && hballot(t_bad) == 0ull;
         // first kernel of the step: the outputs every later kernel only lowers / raises / ORs into start here
         if (present && hl == 0 && a.iters) a.iters[b] = 0;
         if (present && aa.init_warm_box && hl < 6) aa.init_warm_box[(size_t)b * 6 + hl] = 0ull;
         if (present && aa.init_warm_rows && hl < 6 * K) aa.init_warm_rows[(size_t)b * 6 * K + hl] = 0ull;
-        // knot boxes: lane k = interior knot k = 1..M-1, the three axes are 24 contiguous bytes per array
-        const bool knot = t_ok && hl >= 1 && hl < M;
+        const bool knot = t_ok && kn;
         bool kbad[3] = {false, false, false}, keq[3] = {false, false, false};
-        if (knot) {
-            const long long at = 3LL * ((long long)s0 + b + hl);
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const double l = a.corr_lo ? a.corr_lo[at + ax] : a.waypoints[at + ax];
-                const double h = a.corr_hi ? a.corr_hi[at + ax] : a.waypoints[at + ax];
-                kbad[ax] = !(l <= h);
-                keq[ax] = l == h;
-            }
+        for (int ax = 0; ax < 3; ++ax) {
+            kbad[ax] = knot && !(kl[ax] <= kh[ax]);
+            keq[ax] = knot && kl[ax] == kh[ax];
         }
         // rows of segment `hl`
         bool rused[K], rbad_any[K], rbad[K][3], req[K][3];
@@ -138,15 +171,15 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
             // prelude and for every solve of the rows kernel): one (segment, row slot) per lane and trip -- contiguous loads and stores, every
             // lane busy (lane = segment would leave three quarters of the wave idle in the longest part of this kernel); zeros for an unused or
             // invalid row
-            const int mk = shape_ok ? M * K : 0;
             int mk_max = mk;
             if (TW == 2) mk_max = max(mk_max, __shfl_xor(mk_max, 32, 64));
             for (int e0 = 0; e0 < mk_max; e0 += HL) {
                 const int el = e0 + hl;
                 if (el < mk) {
                     const size_t e = (size_t)s0 * K + el;
-                    const int d = a.row_deriv[e];
-                    const double tau = a.row_tau[e], tq = a.times[s0 + el / K];
+                    int d = gd;
+                    double tau = gtau, tq = gtq;
+                    if (e0 > 0) { d = a.row_deriv[e]; tau = a.row_tau[e]; tq = a.times[s0 + el / K]; }      // (more than HL rows: a round trip per further trip)
                     double gl[R], gr[R];
 #pragma unroll
                     for (int c = 0; c < R; ++c) { gl[c] = 0.0; gr[c] = 0.0; }
@@ -169,15 +202,14 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(Rows2Args aa) {
         if (t_ok && hl < M) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const size_t e = (size_t)(s0 + hl) * K + j;
-                const int d = a.row_deriv[e];
+                const int d = rd[j];
                 if (d < 0) continue;
-                const double tau = a.row_tau[e];
+                const double tau = rtau[j];
                 rused[j] = true;
                 rbad_any[j] = !((d < R) && (tau >= 0.0) && (tau < 1.0) && !(tau == 0.0 && d == 0));
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {
-                    const double l = a.row_lo[e * 3 + ax], h = a.row_hi[e * 3 + ax];
+                    const double l = rl[j][ax], h = rh[j][ax];
                     rbad[j][ax] = !(l <= h);
                     req[j][ax] = l == h;
                 }
