@@ -21,8 +21,8 @@
 // Ragged batches are dealt to the lane PAIRS by segment count inside windows of 16 waves x 32 trajectories; the rank ranges are rotated by
 // the window index so that the long waves spread over the XCDs.  Round 6: the waves rank their window themselves (BatchArgs::fused_sort, see
 // the top of the round loop) -- window_sort_kernel in front (rounds 2-5, uavqp_settings.ragged_window_sort = 2) cost a launch boundary and
-// 8 + 16 bytes of permutation per trajectory for a sort of 512 small integers; the ranking costs the kernel ~2.5 us, the step is 0.1-1.3 us
-// shorter inside a hipGraph and ~1 us with eager launches (tools/g2_fused_ab.sh).  DESIGN.md section 5.2.
+// 8 + 16 bytes of permutation per trajectory for a sort of 512 small integers; the ranking costs the kernel ~1.8 us, the step is 0.5-2 us
+// shorter inside a hipGraph and with eager launches (tools/g2_fused_ab.sh).  DESIGN.md section 5.2.
 #pragma once
 #include "qp_core_kernels.h"
 #include "qp_wave_utils.h"
@@ -59,6 +59,18 @@
 #endif
 
 namespace uavqp {
+
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside the DPP rows (row_shr 1 / 2 / 4 / 8, zero fill), then the rows' totals across
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ int wave_incl_scan_add(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 
 // 16-byte store to an address that went through LDS as an integer: spelled as a GLOBAL store (address space 1) -- from a generic
 // pointer the compiler emits flat_store, and a pending FLAT operation makes it wait with vmcnt(0) / lgkmcnt(0) everywhere
@@ -130,88 +142,54 @@ __global__ __launch_bounds__(64) void solve_generic2_kernel(BatchArgs a) {
             if (a.fused_sort) {
                 // ---- the dealing, by the wave itself (round 6; was window_sort_kernel behind its own launch boundary: 4.8 us of a 40 us step).
                 // The 16 waves of a window each rank the window's 512 trajectories by (segment count descending, index ascending) -- the SAME
-                // deterministic order in every one of them, no atomics -- and take their own 32 ranks.  Trajectory i = 8 lane + j:
-                //   * C[k][l] (16 bit) = how many of lane l's eight have count k; lane k turns row k into exclusive prefix sums along l (SWAR),
-                //     starting from the number of trajectories with a LARGER count (suffix scan of the row totals over the lanes);
-                //   * rank = C[k][lane] + (earlier ones of the same count in the own eight).
-                // Counts are clamped to 0..63 for the ranking (the host uses this path up to 63 segments); the record keeps the real count.
+                // deterministic order in every one of them -- and take their own 32 ranks.  Trajectory i = 8 lane + j:
+                //   * H[k] = trajectories of the window with count k (LDS adds: sums do not depend on their order), start[k] = those with a larger
+                //     count (the window's total minus the inclusive prefix sum over the lanes, lane = count);
+                //   * only the counts whose rank range [start, start + H) meets this wave's [32 q, 32 q + 32) matter to it -- one to three of them
+                //     on a batch like config 4: for each, an exclusive scan over the lanes of "how many of my eight have it" (DPP) orders its
+                //     trajectories by index, rank = start + lanes in front + earlier ones of the own eight.
+                // (First version: a [64][64] table of 16-bit counts, every row scanned by its lane -- the whole order, of which a wave needs a
+                // sixteenth: 3 us per wave.)  Counts are clamped to 0..63 for the ranking (the host uses this path up to 63 segments); the record
+                // keeps the real count.
                 const int win = blockIdx.x >> 4, q = ((blockIdx.x & 15) + win) & 15;
                 const int wbase = round * n_items + win * 512;
-                // (rows of 72 halfwords = 144 bytes: with 128 the 64 lanes that each scan their own row would all start on the same LDS bank)
-                constexpr int CS = 72;
-                unsigned short* const C = reinterpret_cast<unsigned short*>(s_in);          // [64][CS], on top of the input slots (free until the staging)
-                int4* const SLOT = reinterpret_cast<int4*>(s_in + 64 * CS / 4);              // [32] records of this wave's ranks
-                int off[9], key[8], dupb[8];
+                int* const H = reinterpret_cast<int*>(s_in);                                // [64], on top of the input slots (free until the staging)
+                int4* const SLOT = reinterpret_cast<int4*>(s_in + 32);                      // [32] records of this wave's ranks
+                int off[9], key[8];
                 const int t0 = wbase + lane * 8;
 #pragma unroll
                 for (int j = 0; j < 9; ++j) off[j] = t0 + j <= a.n_traj ? a.seg_offsets[t0 + j] : 0;
                 wave_lds_sync();      // (the previous round's slots and staging rows have been read by everybody)
-#pragma unroll
-                for (int p = 0; p < CS / 8; ++p) *reinterpret_cast<double2*>(s_in + 2 * (p * 64 + lane)) = make_double2(0.0, 0.0);     // C = 0 (9 KB)
-                if (lane < 32) SLOT[lane] = make_int4(a.n_traj, 0, 0, 0);                                                        // (rank beyond the window's trajectories: nobody)
+                H[lane] = 0;
+                if (lane < 32) SLOT[lane] = make_int4(a.n_traj, 0, 0, 0);                    // (rank beyond the window's trajectories: nobody)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = off[j + 1] - off[j];
                     key[j] = t0 + j < a.n_traj ? (c < 0 ? 0 : (c > 63 ? 63 : c)) : -1;
                 }
-                int same[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int before = 0, all = 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int e = key[i] == key[j] ? 1 : 0;
-                        all += e;
-                        if (i < j) before += e;
-                    }
-                    dupb[j] = before;
-                    same[j] = all;
-                }
                 wave_lds_sync();
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (key[j] >= 0) C[key[j] * CS + lane] = (unsigned short)same[j];
+                    if (key[j] >= 0) atomicAdd(&H[key[j]], 1);
                 wave_lds_sync();
-                // lane k: exclusive prefix of row k along the lanes, two 16-bit counts per dword
-                {
-                    int tot;
-                    unsigned int* const row = reinterpret_cast<unsigned int*>(C + lane * CS);
-                    unsigned int d[32];
+                const int tot = H[lane];
+                const int pre = wave_incl_scan_add(tot);                                      // trajectories with a count <= this lane's (lane = count)
+                const int start = __builtin_amdgcn_readlane(pre, 63) - pre;                    // ... with a larger one: the first rank of this count
+                const int r0 = 32 * q;
+                unsigned long long rel = __ballot(tot > 0 && start < r0 + 32 && start + tot > r0);
+                while (rel != 0ull) {            // (wave-uniform)
+                    const int k = __ffsll((long long)rel) - 1;
+                    rel &= rel - 1ull;
+                    const int st_k = __builtin_amdgcn_readlane(start, k);
+                    int before[8], cnt = 0;
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * p);
-                        d[4 * p] = v.x; d[4 * p + 1] = v.y; d[4 * p + 2] = v.z; d[4 * p + 3] = v.w;
+                    for (int j = 0; j < 8; ++j) { before[j] = cnt; cnt += key[j] == k ? 1 : 0; }
+                    const int excl = wave_incl_scan_add(cnt) - cnt;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int pos = st_k + excl + before[j] - r0;
+                        if (key[j] == k && pos >= 0 && pos < 32) SLOT[pos] = make_int4(t0 + j, off[j], off[j + 1] - off[j], 0);
                     }
-                    // total of the row first (the start of a count = the trajectories with a larger one: suffix sum over the lanes), then the
-                    // exclusive prefix along the lanes with that start as its first carry: an entry of the table IS the rank of the lane's first
-                    // trajectory of that count
-                    unsigned int acc = 0;
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) acc += d[i];
-                    tot = (int)((acc & 0xFFFFu) + (acc >> 16));
-                    int suf = tot;        // inclusive suffix sum over the lanes (= counts): trajectories with a count >= this lane's
-#pragma unroll
-                    for (int dd = 1; dd < 64; dd <<= 1) {
-                        const int v = __shfl_down(suf, dd, 64);
-                        if (lane + dd < 64) suf += v;
-                    }
-                    unsigned int carry = (unsigned int)(suf - tot);
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) {
-                        const unsigned int lo_ = d[i] & 0xFFFFu, hi_ = d[i] >> 16;
-                        const unsigned int e_hi = carry + lo_;
-                        d[i] = carry | (e_hi << 16);
-                        carry = e_hi + hi_;
-                    }
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) *reinterpret_cast<uint4*>(row + 4 * p) = make_uint4(d[4 * p], d[4 * p + 1], d[4 * p + 2], d[4 * p + 3]);
-                }
-                wave_lds_sync();
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = key[j] < 0 ? 0 : key[j];
-                    const int pos = (int)C[k * CS + lane] + dupb[j] - 32 * q;
-                    if (key[j] >= 0 && pos >= 0 && pos < 32) SLOT[pos] = make_int4(t0 + j, off[j], off[j + 1] - off[j], 0);
                 }
                 wave_lds_sync();
                 const int4 rec = SLOT[item];
